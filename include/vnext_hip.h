@@ -1,0 +1,124 @@
+/*
+ * include/vnext_hip.h -- C ABI of libvnext_hip.so (MI355X / gfx950).
+ *
+ * This is the drop-in boundary for VNext's data-parallel hot path.  Every entry
+ * point takes plain device pointers, sizes and a HIP stream, returns an int
+ * status, never allocates, never synchronises and never keeps a pointer after
+ * it returns, so a call is re-entrant and hipGraph-capturable.  No torch type
+ * appears here; the Python module `MultiScaleDeformableAttention` (repo root)
+ * and vnext_amd/ bind these symbols through ctypes (INTEGRATION.md shows the
+ * binding a VNext maintainer would add).
+ *
+ * Reference interfaces replaced (paths relative to the VNext tree):
+ *   vnx_msda_forward   <- ms_deform_attn_forward
+ *        projects/SeqFormer/seqformer/models/ops/src/ms_deform_attn.h:20-39,
+ *        src/cuda/ms_deform_attn_cuda.cu:20-80, src/vision.cpp:14
+ *   vnx_msda_backward  <- ms_deform_attn_backward
+ *        .../src/ms_deform_attn.h:41-61, src/cuda/ms_deform_attn_cuda.cu:83-153,
+ *        src/vision.cpp:15
+ *
+ * Tensor layouts are the reference's (all contiguous, ms_deform_attn_cuda.cu:28-38):
+ *   value            [batch, spatial_size, num_heads, channels]
+ *   spatial_shapes   [num_levels, 2]  int64, (H_l, W_l), DEVICE memory
+ *   level_start_index[num_levels]     int64, DEVICE memory
+ *   sampling_loc     [batch, num_query, num_heads, num_levels, num_point, 2]  (x, y) in [0,1]
+ *   attn_weight      [batch, num_query, num_heads, num_levels, num_point]
+ *   output / grad_output [batch, num_query, num_heads*channels]
+ */
+#ifndef VNEXT_HIP_H_
+#define VNEXT_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VNX_ABI_VERSION 1
+
+/* element types */
+enum {
+  VNX_F32 = 0,
+  VNX_F64 = 1,
+  VNX_BF16 = 2,
+  VNX_F16 = 3
+};
+
+/* status codes */
+enum {
+  VNX_OK = 0,
+  VNX_ERR_INVALID_ARGUMENT = 1, /* null pointer, non-positive size, bad dtype combination */
+  VNX_ERR_UNSUPPORTED = 2,      /* shape outside what the kernels address (see vnx_last_error) */
+  VNX_ERR_WORKSPACE = 3,        /* workspace missing or too small */
+  VNX_ERR_LAUNCH = 4            /* hipGetLastError() != hipSuccess after the launch */
+};
+
+/* Library identification.  vnx_abi_version() == VNX_ABI_VERSION. */
+int vnx_abi_version(void);
+/* Static string for a status code. */
+const char* vnx_status_string(int status);
+/* Thread-local detail of the last non-OK status returned on this thread. */
+const char* vnx_last_error(void);
+
+/*
+ * Multi-scale deformable attention, forward.
+ *   output[b,q,m,:] = sum_{l,k} attn[b,q,m,l,k] * bilinear(value_l[b,:,m,:], loc[b,q,m,l,k])
+ * zero padding outside the maps, pixel convention x*W-0.5 / y*H-0.5
+ * (ms_deform_im2col_cuda.cuh:285-288).  `output` is fully written (it does not
+ * need the reference's zero pre-fill, ms_deform_attn_cuda.cu:54).
+ *
+ * value_dtype: type of value and output (F32, F64, BF16, F16).
+ * loc_dtype  : type of sampling_loc and attn_weight; equal to value_dtype, or
+ *              VNX_F32 with a 16-bit value (the autocast case).
+ * The reference's im2col_step chunking (ms_deform_attn_cuda.cu:50-75) is a host
+ * concern and is not part of this ABI: one call covers the whole batch.
+ */
+int vnx_msda_forward(int value_dtype, int loc_dtype,
+                     const void* value, const int64_t* spatial_shapes,
+                     const int64_t* level_start_index, const void* sampling_loc,
+                     const void* attn_weight, void* output,
+                     int batch, int spatial_size, int num_heads, int channels,
+                     int num_levels, int num_query, int num_point,
+                     void* hip_stream);
+
+/*
+ * Bytes of scratch vnx_msda_backward needs for these sizes (0 for F32 / F64;
+ * an fp32 accumulation image of grad_value for 16-bit values).
+ */
+size_t vnx_msda_backward_workspace_bytes(int value_dtype, int batch, int spatial_size,
+                                         int num_heads, int channels);
+
+/*
+ * Multi-scale deformable attention, backward (ms_deform_im2col_cuda.cuh:87-159).
+ * All three gradient buffers are fully written; they need no zero pre-fill by
+ * the caller (the reference's three at::zeros_like, ms_deform_attn_cuda.cu:121-123,
+ * are done on `hip_stream` inside the call where still needed).
+ *   grad_value        like value        (value_dtype)
+ *   grad_sampling_loc like sampling_loc (loc_dtype)
+ *   grad_attn_weight  like attn_weight  (loc_dtype)
+ * grad_value is accumulated with floating-point atomics, so its low-order bits
+ * depend on scheduling, exactly as in the reference.
+ */
+int vnx_msda_backward(int value_dtype, int loc_dtype,
+                      const void* value, const int64_t* spatial_shapes,
+                      const int64_t* level_start_index, const void* sampling_loc,
+                      const void* attn_weight, const void* grad_output,
+                      void* grad_value, void* grad_sampling_loc, void* grad_attn_weight,
+                      int batch, int spatial_size, int num_heads, int channels,
+                      int num_levels, int num_query, int num_point,
+                      void* workspace, size_t workspace_bytes,
+                      void* hip_stream);
+
+/*
+ * Kernel selection override for A/B measurements and tests (process-wide):
+ *   0 = automatic (default), 1 = force the generic kernels,
+ *   >= 2 = implementation-defined tuned variants.
+ */
+void vnx_set_kernel_variant(int variant);
+int vnx_get_kernel_variant(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VNEXT_HIP_H_ */

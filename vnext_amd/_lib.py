@@ -1,0 +1,69 @@
+"""ctypes binding of libvnext_hip.so (include/vnext_hip.h).
+
+The library is the product: there is no CPU or PyTorch fallback behind these
+calls.  If the .so is missing `lib()` raises; run `python -m vnext_amd.build`
+(or `__graft_entry__.build()`) first.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvnext_hip.so")
+
+VNX_F32, VNX_F64, VNX_BF16, VNX_F16 = 0, 1, 2, 3
+VNX_OK = 0
+ABI_VERSION = 1
+
+_vp, _i, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/vnext_hip.h declaration by declaration
+SIGNATURES = {
+    "vnx_abi_version": (_i, []),
+    "vnx_status_string": (ctypes.c_char_p, [_i]),
+    "vnx_last_error": (ctypes.c_char_p, []),
+    "vnx_msda_forward": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp] + [_i] * 7 + [_vp]),
+    "vnx_msda_backward_workspace_bytes": (_sz, [_i] * 5),
+    "vnx_msda_backward": (_i, [_i, _i] + [_vp] * 9 + [_i] * 7 + [_vp, _sz, _vp]),
+    "vnx_set_kernel_variant": (None, [_i]),
+    "vnx_get_kernel_variant": (_i, []),
+}
+
+_lib = None
+
+
+class VnextHipError(RuntimeError):
+    pass
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise VnextHipError(
+                f"{LIB_PATH} is missing: the HIP library is the only implementation of this "
+                "path (no CPU fallback). Build it with `python -m vnext_amd.build`.")
+        # torch ships its own libamdhip64.so.7; import it first so this library binds to
+        # the HIP runtime torch's allocator and streams live in.
+        import torch  # noqa: F401
+        cdll = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(cdll, name)
+            fn.restype = res
+            fn.argtypes = args
+        if cdll.vnx_abi_version() != ABI_VERSION:
+            raise VnextHipError(f"ABI version {cdll.vnx_abi_version()} != {ABI_VERSION}; rebuild")
+        _lib = cdll
+    return _lib
+
+
+def check(status: int) -> None:
+    if status != VNX_OK:
+        l = lib()
+        raise VnextHipError(
+            f"{l.vnx_status_string(status).decode()}: {l.vnx_last_error().decode()}")
+
+
+def set_kernel_variant(v: int) -> None:
+    lib().vnx_set_kernel_variant(int(v))

@@ -1,0 +1,179 @@
+// capi.hip -- the extern "C" surface of libvnext_hip.so (include/vnext_hip.h).
+// Argument validation, kernel selection and error reporting live here; the
+// kernels themselves are in msda_generic.hip / msda_d32.hip.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "vnx_common.h"
+
+namespace vnx {
+
+static thread_local char t_error[512] = "";
+int g_kernel_variant = 0;
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(t_error, sizeof t_error, fmt, ap);
+  va_end(ap);
+}
+
+// The reference only printf()s a failed launch (ms_deform_im2col_cuda.cuh:948-952);
+// here it becomes a status the caller must look at.
+int check_launch(const char* what) {
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+    return VNX_ERR_LAUNCH;
+  }
+  return VNX_OK;
+}
+
+int msda_forward_generic(int, int, const void*, const int64_t*, const int64_t*, const void*,
+                         const void*, void*, MsdaDims, hipStream_t);
+int msda_backward_generic(int, int, const void*, const int64_t*, const int64_t*, const void*,
+                          const void*, const void*, void*, void*, void*, MsdaDims, hipStream_t);
+int convert_f32_to(int, const void*, void*, int64_t, hipStream_t);
+bool msda_d32_fwd_supported(int vdt, int ldt, const MsdaDims& d);
+bool msda_d32_bwd_supported(int vdt, int ldt, const MsdaDims& d);
+int msda_forward_d32(int, int, const void*, const int64_t*, const int64_t*, const void*,
+                     const void*, void*, MsdaDims, int variant, hipStream_t);
+int msda_backward_d32(int, int, const void*, const int64_t*, const int64_t*, const void*,
+                      const void*, const void*, void*, void*, void*, MsdaDims, int variant,
+                      hipStream_t);
+
+static int check_common(const char* fn, int vdt, int ldt, const void* value,
+                        const int64_t* shapes, const int64_t* lsi, const void* loc,
+                        const void* attn, const MsdaDims& d) {
+  if (elem_size(vdt) == 0) {
+    set_error("%s: unknown value_dtype %d", fn, vdt);
+    return VNX_ERR_INVALID_ARGUMENT;
+  }
+  const bool pair_ok = (ldt == vdt) || (ldt == VNX_F32 && (vdt == VNX_BF16 || vdt == VNX_F16));
+  if (!pair_ok) {
+    set_error("%s: loc_dtype %d must equal value_dtype %d, or be f32 with a 16-bit value", fn,
+              ldt, vdt);
+    return VNX_ERR_INVALID_ARGUMENT;
+  }
+  if (d.B < 0 || d.S < 0 || d.Lq < 0 || d.M <= 0 || d.D <= 0 || d.L <= 0 || d.P <= 0) {
+    set_error("%s: bad sizes batch=%d spatial=%d heads=%d channels=%d levels=%d query=%d point=%d",
+              fn, d.B, d.S, d.M, d.D, d.L, d.Lq, d.P);
+    return VNX_ERR_INVALID_ARGUMENT;
+  }
+  const bool empty = (d.B == 0 || d.Lq == 0);
+  if (!shapes || !lsi || (!empty && (!loc || !attn)) || (!empty && d.S > 0 && !value)) {
+    set_error("%s: null pointer argument", fn);
+    return VNX_ERR_INVALID_ARGUMENT;
+  }
+  // level-local pixel offsets and per-batch element offsets are 32-bit in the kernels
+  if (int64_t(d.S) * d.M * d.D >= (int64_t(1) << 31)) {
+    set_error("%s: spatial_size*heads*channels = %lld does not fit 31 bits", fn,
+              (long long)(int64_t(d.S) * d.M * d.D));
+    return VNX_ERR_UNSUPPORTED;
+  }
+  return VNX_OK;
+}
+
+}  // namespace vnx
+
+using namespace vnx;
+
+extern "C" {
+
+int vnx_abi_version(void) { return VNX_ABI_VERSION; }
+
+const char* vnx_status_string(int status) {
+  switch (status) {
+    case VNX_OK: return "ok";
+    case VNX_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case VNX_ERR_UNSUPPORTED: return "unsupported shape";
+    case VNX_ERR_WORKSPACE: return "workspace missing or too small";
+    case VNX_ERR_LAUNCH: return "kernel launch failed";
+    default: return "unknown status";
+  }
+}
+
+const char* vnx_last_error(void) { return t_error; }
+
+void vnx_set_kernel_variant(int variant) { g_kernel_variant = variant; }
+int vnx_get_kernel_variant(void) { return g_kernel_variant; }
+
+int vnx_msda_forward(int value_dtype, int loc_dtype, const void* value,
+                     const int64_t* spatial_shapes, const int64_t* level_start_index,
+                     const void* sampling_loc, const void* attn_weight, void* output, int batch,
+                     int spatial_size, int num_heads, int channels, int num_levels, int num_query,
+                     int num_point, void* hip_stream) {
+  const MsdaDims d{batch, spatial_size, num_heads, channels, num_levels, num_query, num_point};
+  int st = check_common("vnx_msda_forward", value_dtype, loc_dtype, value, spatial_shapes,
+                        level_start_index, sampling_loc, attn_weight, d);
+  if (st != VNX_OK) return st;
+  if (batch == 0 || num_query == 0) return VNX_OK;
+  if (!output) {
+    set_error("vnx_msda_forward: null output");
+    return VNX_ERR_INVALID_ARGUMENT;
+  }
+  hipStream_t stream = (hipStream_t)hip_stream;
+  const int variant = g_kernel_variant;
+  if (variant != 1 && msda_d32_fwd_supported(value_dtype, loc_dtype, d))
+    return msda_forward_d32(value_dtype, loc_dtype, value, spatial_shapes, level_start_index,
+                            sampling_loc, attn_weight, output, d, variant, stream);
+  return msda_forward_generic(value_dtype, loc_dtype, value, spatial_shapes, level_start_index,
+                              sampling_loc, attn_weight, output, d, stream);
+}
+
+size_t vnx_msda_backward_workspace_bytes(int value_dtype, int batch, int spatial_size,
+                                         int num_heads, int channels) {
+  if (value_dtype != VNX_BF16 && value_dtype != VNX_F16) return 0;
+  return sizeof(float) * size_t(batch) * size_t(spatial_size) * size_t(num_heads) * size_t(channels);
+}
+
+int vnx_msda_backward(int value_dtype, int loc_dtype, const void* value,
+                      const int64_t* spatial_shapes, const int64_t* level_start_index,
+                      const void* sampling_loc, const void* attn_weight, const void* grad_output,
+                      void* grad_value, void* grad_sampling_loc, void* grad_attn_weight, int batch,
+                      int spatial_size, int num_heads, int channels, int num_levels, int num_query,
+                      int num_point, void* workspace, size_t workspace_bytes, void* hip_stream) {
+  const MsdaDims d{batch, spatial_size, num_heads, channels, num_levels, num_query, num_point};
+  int st = check_common("vnx_msda_backward", value_dtype, loc_dtype, value, spatial_shapes,
+                        level_start_index, sampling_loc, attn_weight, d);
+  if (st != VNX_OK) return st;
+  hipStream_t stream = (hipStream_t)hip_stream;
+  const size_t n_value = size_t(batch) * size_t(spatial_size) * size_t(num_heads) * size_t(channels);
+  const size_t need = vnx_msda_backward_workspace_bytes(value_dtype, batch, spatial_size, num_heads, channels);
+  if (n_value > 0 && !grad_value) {
+    set_error("vnx_msda_backward: null grad_value");
+    return VNX_ERR_INVALID_ARGUMENT;
+  }
+  if (need > 0 && (!workspace || workspace_bytes < need)) {
+    set_error("vnx_msda_backward: needs %zu workspace bytes, got %zu", need, workspace_bytes);
+    return VNX_ERR_WORKSPACE;
+  }
+  void* gv_acc = need > 0 ? workspace : grad_value;
+  const size_t acc_bytes = need > 0 ? need : n_value * size_t(elem_size(value_dtype));
+  if (acc_bytes > 0) {
+    const hipError_t e = hipMemsetAsync(gv_acc, 0, acc_bytes, stream);
+    if (e != hipSuccess) {
+      set_error("vnx_msda_backward: hipMemsetAsync failed: %s", hipGetErrorString(e));
+      return VNX_ERR_LAUNCH;
+    }
+  }
+  if (batch == 0 || num_query == 0) return VNX_OK;
+  if (!grad_output || !grad_sampling_loc || !grad_attn_weight) {
+    set_error("vnx_msda_backward: null gradient pointer");
+    return VNX_ERR_INVALID_ARGUMENT;
+  }
+  const int variant = g_kernel_variant;
+  if (variant != 1 && msda_d32_bwd_supported(value_dtype, loc_dtype, d))
+    st = msda_backward_d32(value_dtype, loc_dtype, value, spatial_shapes, level_start_index,
+                           sampling_loc, attn_weight, grad_output, gv_acc, grad_sampling_loc,
+                           grad_attn_weight, d, variant, stream);
+  else
+    st = msda_backward_generic(value_dtype, loc_dtype, value, spatial_shapes, level_start_index,
+                               sampling_loc, attn_weight, grad_output, gv_acc, grad_sampling_loc,
+                               grad_attn_weight, d, stream);
+  if (st != VNX_OK) return st;
+  if (need > 0) return convert_f32_to(value_dtype, workspace, grad_value, int64_t(n_value), stream);
+  return VNX_OK;
+}
+
+}  // extern "C"

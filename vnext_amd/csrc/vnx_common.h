@@ -1,0 +1,68 @@
+// vnx_common.h -- shared device/host helpers for libvnext_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+#include "../../include/vnext_hip.h"
+
+namespace vnx {
+
+constexpr int kWave = 64;  // CDNA wavefront
+
+// ---- element types ---------------------------------------------------------
+struct bf16_t { uint16_t bits; };
+struct f16_t { _Float16 v; };
+
+template <typename T> struct acc_of { using type = float; };
+template <> struct acc_of<double> { using type = double; };
+template <typename T> using acc_t = typename acc_of<T>::type;
+
+__device__ __forceinline__ float to_acc(float x) { return x; }
+__device__ __forceinline__ double to_acc(double x) { return x; }
+__device__ __forceinline__ float to_acc(bf16_t x) { return __uint_as_float(uint32_t(x.bits) << 16); }
+__device__ __forceinline__ float to_acc(f16_t x) { return float(x.v); }
+
+// round-to-nearest-even fp32 -> bf16 (NaN kept quiet)
+__device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return uint16_t((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return uint16_t(u >> 16);
+}
+
+template <typename T> __device__ __forceinline__ T from_acc(acc_t<T> x);
+template <> __device__ __forceinline__ float from_acc<float>(float x) { return x; }
+template <> __device__ __forceinline__ double from_acc<double>(double x) { return x; }
+template <> __device__ __forceinline__ bf16_t from_acc<bf16_t>(float x) { return bf16_t{f32_to_bf16_bits(x)}; }
+template <> __device__ __forceinline__ f16_t from_acc<f16_t>(float x) { return f16_t{_Float16(x)}; }
+
+// hardware floating-point atomics (global_atomic_add_f32 / _f64), agent scope
+__device__ __forceinline__ void atomic_add(float* p, float v) { unsafeAtomicAdd(p, v); }
+__device__ __forceinline__ void atomic_add(double* p, double v) { unsafeAtomicAdd(p, v); }
+
+__device__ __forceinline__ float floor_acc(float x) { return floorf(x); }
+__device__ __forceinline__ double floor_acc(double x) { return floor(x); }
+
+// ---- host side ---------------------------------------------------------------
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+extern int g_kernel_variant;
+
+struct MsdaDims {
+  int B, S, M, D, L, Lq, P;
+};
+
+inline int elem_size(int dtype) {
+  switch (dtype) {
+    case VNX_F32: return 4;
+    case VNX_F64: return 8;
+    case VNX_BF16: return 2;
+    case VNX_F16: return 2;
+    default: return 0;
+  }
+}
+
+}  // namespace vnx

@@ -1,0 +1,127 @@
+"""The `MultiScaleDeformableAttention` extension surface, bound to libvnext_hip.so.
+
+Mirrors the two functions the reference's compiled extension exports
+(projects/SeqFormer/seqformer/models/ops/src/vision.cpp:13-16):
+
+    ms_deform_attn_forward(value, spatial_shapes, level_start_index,
+                           sampling_loc, attn_weight, im2col_step) -> Tensor[B, Lq, M*D]
+    ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc,
+                            attn_weight, grad_output, im2col_step) -> [gv, gloc, gattn]
+
+with the argument checks and messages of ms_deform_attn.h:20-61 and
+ms_deform_attn_cuda.cu:28-52,93-119.  Differences, all supersets:
+  * bf16 / fp16 `value` is accepted (the reference dispatches float/double only,
+    ms_deform_attn_cuda.cu:64); sampling_loc / attn_weight may then stay fp32.
+  * the whole batch goes down in ONE launch; `im2col_step` is validated with the
+    reference's rule (batch % min(batch, im2col_step) == 0) but no longer chunks.
+  * outputs are torch.empty (the kernels write every element) instead of zeros.
+  * a failed launch raises instead of printf (ms_deform_im2col_cuda.cuh:948-952).
+There is no CPU path, as in the reference (ms_deform_attn.h:38,60).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+_DT = {torch.float32: _lib.VNX_F32, torch.float64: _lib.VNX_F64,
+       torch.bfloat16: _lib.VNX_BF16, torch.float16: _lib.VNX_F16}
+
+
+def _check_inputs(tensors):
+    # dispatcher first (ms_deform_attn.h:28,38): a non-GPU `value` has no implementation
+    if not tensors[0][1].is_cuda:
+        raise RuntimeError("Not implemented on the CPU")
+    for name, t in tensors:  # ms_deform_attn_cuda.cu:28-32
+        if not t.is_contiguous():
+            raise RuntimeError(f"{name} tensor has to be contiguous")
+    for name, t in tensors:  # ms_deform_attn_cuda.cu:34-38
+        if not t.is_cuda:
+            raise RuntimeError(f"{name} must be a CUDA tensor")
+    dev = tensors[0][1].device
+    for name, t in tensors:
+        if t.device != dev:
+            raise RuntimeError(f"{name} is on {t.device}, value is on {dev}")
+
+
+def _dims_and_types(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step):
+    if value.dim() != 4 or sampling_loc.dim() != 6 or attn_weight.dim() != 5 or spatial_shapes.dim() != 2:
+        raise RuntimeError(
+            "expected value [B,S,M,D], spatial_shapes [L,2], sampling_loc [B,Lq,M,L,P,2], "
+            f"attn_weight [B,Lq,M,L,P]; got {tuple(value.shape)}, {tuple(spatial_shapes.shape)}, "
+            f"{tuple(sampling_loc.shape)}, {tuple(attn_weight.shape)}")
+    batch, spatial_size, num_heads, channels = value.shape
+    num_levels = spatial_shapes.shape[0]
+    num_query, num_point = sampling_loc.shape[1], sampling_loc.shape[4]
+    if spatial_shapes.dtype != torch.int64 or level_start_index.dtype != torch.int64:
+        raise RuntimeError("spatial_shapes and level_start_index must be int64 (Long) tensors")
+    if tuple(sampling_loc.shape) != (batch, num_query, num_heads, num_levels, num_point, 2) or \
+            tuple(attn_weight.shape) != (batch, num_query, num_heads, num_levels, num_point) or \
+            spatial_shapes.shape[1] != 2 or level_start_index.numel() != num_levels:
+        raise RuntimeError("inconsistent MSDeformAttn argument shapes")
+    if value.dtype not in _DT:
+        raise RuntimeError(f"ms_deform_attn: unsupported value dtype {value.dtype}")
+    if sampling_loc.dtype != attn_weight.dtype or sampling_loc.dtype not in _DT:
+        raise RuntimeError("sampling_loc and attn_weight must share a floating dtype")
+    if sampling_loc.dtype != value.dtype and not (
+            sampling_loc.dtype == torch.float32 and value.dtype in (torch.bfloat16, torch.float16)):
+        raise RuntimeError(
+            f"sampling_loc dtype {sampling_loc.dtype} must equal value dtype {value.dtype} "
+            "(or be float32 with a 16-bit value)")
+    # ms_deform_attn_cuda.cu:50-52
+    step = min(batch, int(im2col_step))
+    if batch > 0 and (step <= 0 or batch % step != 0):
+        raise RuntimeError(f"batch({batch}) must divide im2col_step({step})")
+    return (batch, spatial_size, num_heads, channels, num_levels, num_query, num_point)
+
+
+def _stream_ptr(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
+                           im2col_step):
+    _check_inputs([("value", value), ("spatial_shapes", spatial_shapes),
+                   ("level_start_index", level_start_index), ("sampling_loc", sampling_loc),
+                   ("attn_weight", attn_weight)])
+    dims = _dims_and_types(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
+                           im2col_step)
+    batch, _, num_heads, channels, _, num_query, _ = dims
+    output = torch.empty((batch, num_query, num_heads * channels), dtype=value.dtype,
+                         device=value.device)
+    with torch.cuda.device(value.device):
+        st = _lib.lib().vnx_msda_forward(
+            _DT[value.dtype], _DT[sampling_loc.dtype], value.data_ptr(), spatial_shapes.data_ptr(),
+            level_start_index.data_ptr(), sampling_loc.data_ptr(), attn_weight.data_ptr(),
+            output.data_ptr(), *dims, _stream_ptr(value.device))
+    _lib.check(st)
+    return output
+
+
+def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
+                            grad_output, im2col_step):
+    _check_inputs([("value", value), ("spatial_shapes", spatial_shapes),
+                   ("level_start_index", level_start_index), ("sampling_loc", sampling_loc),
+                   ("attn_weight", attn_weight), ("grad_output", grad_output)])
+    dims = _dims_and_types(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
+                           im2col_step)
+    batch, spatial_size, num_heads, channels, _, num_query, _ = dims
+    if grad_output.dtype != value.dtype or grad_output.numel() != batch * num_query * num_heads * channels:
+        raise RuntimeError("grad_output must be [B, Lq, M*D] with value's dtype")
+    grad_value = torch.empty_like(value)
+    grad_sampling_loc = torch.empty_like(sampling_loc)
+    grad_attn_weight = torch.empty_like(attn_weight)
+    l = _lib.lib()
+    ws_bytes = l.vnx_msda_backward_workspace_bytes(_DT[value.dtype], batch, spatial_size, num_heads,
+                                                   channels)
+    workspace = torch.empty((ws_bytes,), dtype=torch.uint8, device=value.device) if ws_bytes else None
+    with torch.cuda.device(value.device):
+        st = l.vnx_msda_backward(
+            _DT[value.dtype], _DT[sampling_loc.dtype], value.data_ptr(), spatial_shapes.data_ptr(),
+            level_start_index.data_ptr(), sampling_loc.data_ptr(), attn_weight.data_ptr(),
+            grad_output.data_ptr(), grad_value.data_ptr(), grad_sampling_loc.data_ptr(),
+            grad_attn_weight.data_ptr(), *dims,
+            workspace.data_ptr() if workspace is not None else None, ws_bytes,
+            _stream_ptr(value.device))
+    _lib.check(st)
+    return [grad_value, grad_sampling_loc, grad_attn_weight]
