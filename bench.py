@@ -1,0 +1,309 @@
+"""bench.py -- headline measurement of the MI355X hot path.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Metric (BASELINE.json): MSDeformAttn fwd+bwd Gpoints/s at T=5, L=4, Q=300, H=8, K=4.
+One step = one forward + one backward of the op over one T=5 360p clip folded
+into the batch (B=5, Lq=300, S=5100, M=8, D=32, L=4, K=4; fp32; sampling
+locations uniform in [0,1)^2, the reference's test convention, ops/test.py:34).
+A point is one (b, q, head, level, k) bilinear sample: 192 000 per step.
+
+Timed region: inputs are resident in HBM and ROTATE through more than 256 MiB of
+distinct input sets, so neither the 256 MiB Infinity Cache nor the L2s hold a
+step's inputs from the previous use ("cold" numbers).  The K steps are launched
+as hipGraph replays (a step is three stream operations of a few microseconds;
+launching them from Python one by one would time the interpreter), bracketed by
+barrier + synchronize; rank 0 prints one JSON line.
+
+N > 1: clips shard across ranks with no data-path collective (the op has no
+exchange step) -- weak scaling, value = all ranks' points / max
+time.  The gradient all-reduce of the model-level step lives with the model path.
+
+Besides the contract keys the line carries:
+  roofline      forward kernel (the kernel the north star sets the 60 % target on),
+                algorithmic bytes / avg launch time measured here with events
+  roofline_bwd  the same for the backward kernel (+ its zero-fill)
+  cpu_baseline  the oracle (oracle/, "port") timed on the host cores on the same
+                workload, plus the grid_sample fallback technique of the reference
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 measured copy ceiling
+
+SHAPES = {
+    "360p": [(48, 80), (24, 40), (12, 20), (6, 10)],     # S = 5100
+    "720p": [(92, 160), (46, 80), (23, 40), (12, 20)],   # S = 19560
+}
+
+
+def algorithmic_bytes(B, S, Lq, e=4, e_loc=4, M=8, D=32, L=4, K=4):
+    """fwd = value + loc + attn + out; bwd = value + grad_value +
+    grad_out + loc + attn + grad_loc + grad_attn."""
+    fwd = B * (e * S * M * D + e_loc * Lq * M * L * K * 3 + e * Lq * M * D)
+    bwd = B * (2 * e * S * M * D + e * Lq * M * D + 2 * e_loc * Lq * M * L * K * 3)
+    return fwd, bwd
+
+
+def make_set(res, B, Lq, seed, device, dist="U"):
+    g = torch.Generator(device=device).manual_seed(seed)
+    shapes = torch.tensor(SHAPES[res], dtype=torch.long, device=device)
+    S = int(shapes.prod(1).sum())
+    lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    value = torch.randn(B, S, 8, 32, device=device, generator=g)
+    if dist == "U":
+        loc = torch.rand(B, Lq, 8, 4, 4, 2, device=device, generator=g)
+    else:
+        ref = torch.rand(B, Lq, 1, 1, 1, 2, device=device, generator=g)
+        wh = torch.stack([shapes[:, 1], shapes[:, 0]], -1).float().view(1, 1, 1, 4, 1, 2)
+        loc = (ref + 2.0 * torch.randn(B, Lq, 8, 4, 4, 2, device=device, generator=g) / wh).contiguous()
+    attn = torch.softmax(torch.randn(B, Lq, 8, 16, device=device, generator=g), -1).view(B, Lq, 8, 4, 4)
+    grad_out = torch.randn(B, Lq, 256, device=device, generator=g)
+    out = torch.empty(B, Lq, 256, device=device)
+    gv, gl, ga = torch.empty_like(value), torch.empty_like(loc), torch.empty_like(attn)
+    return dict(shapes=shapes, lsi=lsi, value=value, loc=loc, attn=attn.contiguous(),
+                grad_out=grad_out, out=out, gv=gv, gl=gl, ga=ga, S=S)
+
+
+class Op:
+    """Direct C-ABI launches into preallocated buffers (no allocation in the timed region)."""
+
+    def __init__(self, device):
+        from vnext_amd import _lib
+        self.lib = _lib.lib()
+        self._lib = _lib
+        self.device = device
+
+    def fwd(self, s, B, Lq):
+        st = self.lib.vnx_msda_forward(
+            0, 0, s["value"].data_ptr(), s["shapes"].data_ptr(), s["lsi"].data_ptr(),
+            s["loc"].data_ptr(), s["attn"].data_ptr(), s["out"].data_ptr(),
+            B, s["S"], 8, 32, 4, Lq, 4, torch.cuda.current_stream().cuda_stream)
+        self._lib.check(st)
+
+    def bwd(self, s, B, Lq):
+        st = self.lib.vnx_msda_backward(
+            0, 0, s["value"].data_ptr(), s["shapes"].data_ptr(), s["lsi"].data_ptr(),
+            s["loc"].data_ptr(), s["attn"].data_ptr(), s["grad_out"].data_ptr(),
+            s["gv"].data_ptr(), s["gl"].data_ptr(), s["ga"].data_ptr(),
+            B, s["S"], 8, 32, 4, Lq, 4, None, 0, torch.cuda.current_stream().cuda_stream)
+        self._lib.check(st)
+
+
+def capture(fns):
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for f in fns[: min(len(fns), 4)]:
+            f()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for f in fns:
+            f()
+    return graph
+
+
+def event_time_us(graph, launches, reps=15):
+    """Median microseconds per launch over `reps` replays, HIP events on the launch stream."""
+    graph.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ts = []
+    for _ in range(reps):
+        e0.record()
+        graph.replay()
+        e1.record()
+        e1.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3 / launches)
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+def largest_divisor_leq(n, cap):
+    for d in range(min(n, cap), 0, -1):
+        if n % d == 0:
+            return d
+    return 1
+
+
+def cpu_baseline(B, Lq, res, budget_s=12.0):
+    """Oracle ("port") on the host cores, same workload; plus the grid_sample technique."""
+    import numpy as np
+    from oracle import msda_oracle as O
+    from oracle.msda_torch_fallback import msda_grid_sample
+    shapes = np.array(SHAPES[res], dtype=np.int64)
+    lsi = O.level_start_index(shapes)
+    S = int((shapes[:, 0] * shapes[:, 1]).sum())
+    rng = np.random.default_rng(3)
+    value = rng.standard_normal((B, S, 8, 32)).astype(np.float32)
+    loc = rng.random((B, Lq, 8, 4, 4, 2)).astype(np.float32)
+    attn = rng.random((B, Lq, 8, 4, 4)).astype(np.float32)
+    attn /= attn.sum((-1, -2), keepdims=True)
+    go = rng.standard_normal((B, Lq, 256)).astype(np.float32)
+    points = 128 * B * Lq
+    cores = os.cpu_count() or 1
+    best = None
+    for nt in sorted({1, cores}):
+        ts = []
+        t_start = time.perf_counter()
+        while len(ts) < 3 or (time.perf_counter() - t_start < budget_s / 3 and len(ts) < 25):
+            t0 = time.perf_counter()
+            O.msda_forward(value, shapes, lsi, loc, attn, nthreads=nt)
+            O.msda_backward(value, shapes, lsi, loc, attn, go, nthreads=nt)
+            ts.append(time.perf_counter() - t0)
+        med = sorted(ts)[len(ts) // 2]
+        if best is None or med < best[0]:
+            best = (med, nt, len(ts))
+    med, nt, n = best
+    # the reference's fallback technique (grid_sample + autograd), all host threads
+    torch.set_num_threads(cores)
+    tv, tl, ta = (torch.from_numpy(x).requires_grad_(True) for x in (value, loc, attn))
+    tg = torch.from_numpy(go)
+    ts = []
+    t_start = time.perf_counter()
+    while len(ts) < 3 or (time.perf_counter() - t_start < budget_s / 3 and len(ts) < 25):
+        t0 = time.perf_counter()
+        out = msda_grid_sample(tv, shapes, tl, ta)
+        out.backward(tg)
+        ts.append(time.perf_counter() - t0)
+        tv.grad = tl.grad = ta.grad = None
+    gmed = sorted(ts)[len(ts) // 2]
+    return {
+        "value": points / med / 1e9, "unit": "Gpoints/s", "cores": nt, "kind": "port",
+        "sample": f"{n} x (fwd+bwd) of the same B={B},Lq={Lq},{res} fp32 workload through "
+                  f"oracle/msda_oracle.c, median; host has {cores} cores",
+        "ms_per_step": med * 1e3,
+        "torch_grid_sample_fallback": {
+            "value": points / gmed / 1e9, "unit": "Gpoints/s", "cores": cores,
+            "ms_per_step": gmed * 1e3,
+            "note": "grid_sample + autograd statement of the reference's pure-PyTorch path "
+                    "(oracle/msda_torch_fallback.py), torch intra-op threads = host cores"},
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--res", default="360p", choices=list(SHAPES))
+    ap.add_argument("--lq", type=int, default=300)
+    ap.add_argument("--batch", type=int, default=5)
+    ap.add_argument("--dist", default="U", choices=["U", "M"])
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP library is the only implementation")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+    n_gpus = world if world > 1 else 1
+
+    B, Lq, res = a.batch, a.lq, a.res
+    op = Op(device)
+    probe = make_set(res, B, Lq, 0, device, a.dist)
+    S = probe["S"]
+    bytes_fwd, bytes_bwd = algorithmic_bytes(B, S, Lq)
+    set_bytes = sum(probe[k].numel() * probe[k].element_size()
+                    for k in ("value", "loc", "attn", "grad_out", "out", "gv", "gl", "ga"))
+    input_bytes = sum(probe[k].numel() * probe[k].element_size() for k in ("value", "loc", "attn", "grad_out"))
+    nsets = max(2, math.ceil(320 * 2**20 / input_bytes))
+    sets = [probe] + [make_set(res, B, Lq, 1000 * rank + i, device, a.dist) for i in range(1, nsets)]
+    points = 128 * B * Lq
+
+    def step_fns(i):
+        s = sets[i % nsets]
+        return [lambda: op.fwd(s, B, Lq), lambda: op.bwd(s, B, Lq)]
+
+    # ---- the timed region: K steps as replays of a graph of `chunk` steps ------------
+    chunk = largest_divisor_leq(a.steps, 100)
+    fns = [f for i in range(chunk) for f in step_fns(i)]
+    graph = capture(fns)
+    for _ in range(math.ceil(a.warmup / chunk)):
+        graph.replay()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps // chunk):
+        graph.replay()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed * 1e3 / a.steps
+    value = points * n_gpus / (ms_per_step * 1e-3) / 1e9
+
+    line = {
+        "metric": "MSDeformAttn fwd+bwd Gpoints/s (T=5,L=4,Q=300,H=8,K=4)",
+        "value": value, "unit": "Gpoints/s", "n_gpus": n_gpus, "steps": a.steps,
+        "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"SeqFormer-R50 T=5 {res} clip folded to B={B}: MSDeformAttn "
+                               f"decoder call, Lq={Lq}, S={S}, M=8, D=32, L=4, K=4, "
+                               f"loc~{'U[0,1)' if a.dist == 'U' else 'model-like'}; 1 step = fwd+bwd",
+                   "points_per_step": points, "input_rotation_sets": nsets,
+                   "input_rotation_MiB": round(nsets * input_bytes / 2**20, 1),
+                   "parallelism": f"dp{n_gpus} (clips sharded, no data-path collective)"},
+    }
+
+    if rank == 0:
+        # ---- per-kernel rooflines, measured live with events on the launch stream -------
+        inner = max(nsets, 24)
+        g_fwd = capture([(lambda s=sets[i % nsets]: op.fwd(s, B, Lq)) for i in range(inner)])
+        g_bwd = capture([(lambda s=sets[i % nsets]: op.bwd(s, B, Lq)) for i in range(inner)])
+        g_fwd_warm = capture([(lambda: op.fwd(sets[0], B, Lq)) for _ in range(inner)])
+        us_fwd = event_time_us(g_fwd, inner)
+        us_bwd = event_time_us(g_bwd, inner)
+        us_fwd_warm = event_time_us(g_fwd_warm, inner)
+
+        def roof(nbytes, us, what):
+            gbs = nbytes / us / 1e3
+            return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": gbs / HBM_PEAK_GBS, "traffic": None, "kernel": what,
+                    "algorithmic_bytes_per_launch": nbytes, "us_per_launch": us,
+                    "timing": "HIP events around a hipGraph of back-to-back launches over "
+                              "rotating inputs (cold); includes the inter-kernel gap"}
+
+        line["roofline"] = roof(bytes_fwd, us_fwd, "msda_fwd_d32_kernel (ms_deform_attn_forward)")
+        line["roofline"]["warm_us_per_launch"] = us_fwd_warm
+        line["roofline"]["warm_frac"] = bytes_fwd / us_fwd_warm / 1e3 / HBM_PEAK_GBS
+        line["roofline_bwd"] = roof(bytes_bwd, us_bwd,
+                                    "msda_bwd_d32_kernel + grad_value zero-fill (ms_deform_attn_backward)")
+        line["fwd_gpoints_per_s"] = points / us_fwd / 1e3
+        if not a.no_cpu:
+            line["cpu_baseline"] = cpu_baseline(B, Lq, res)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

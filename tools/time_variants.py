@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--B", type=int, default=5)
     ap.add_argument("--variants", default="0,1,2,3,4,5,12,13,14,15")
     ap.add_argument("--bwd", action="store_true")
+    ap.add_argument("--bwd-only", action="store_true")
     ap.add_argument("--inner", type=int, default=24)
     a = ap.parse_args()
     res = a.shape[3:]
@@ -104,7 +105,7 @@ def main():
             if bwd:
                 return lambda: MSDA.ms_deform_attn_backward(val, sh, lsi, loc, attn, go, 64)
             return lambda: MSDA.ms_deform_attn_forward(val, sh, lsi, loc, attn, 64)
-        for bwd in ([False, True] if a.bwd else [False]):
+        for bwd in ([True] if a.bwd_only else [False, True] if a.bwd else [False]):
             cold = time_graph([mk(i, bwd) for i in range(a.inner)])
             warm = time_graph([mk(0, bwd) for _ in range(a.inner)])
             by = bytes_bwd if bwd else bytes_fwd

@@ -57,13 +57,15 @@ __device__ __forceinline__ float4_t load_tap<bf16_t>(__amdgpu_buffer_rsrc_t rsrc
   v.z = __uint_as_float(r.y << 16); v.w = __uint_as_float(r.y & 0xffff0000u);
   return v;
 }
+__device__ __forceinline__ float half_bits_to_float(uint32_t bits16) {
+  return float(__builtin_bit_cast(_Float16, uint16_t(bits16)));
+}
 template <>
 __device__ __forceinline__ float4_t load_tap<f16_t>(__amdgpu_buffer_rsrc_t rsrc, uint32_t off) {
   uint2_t r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, int(off), 0, 0);
-  typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
-  half2_t lo = __builtin_bit_cast(half2_t, r.x), hi = __builtin_bit_cast(half2_t, r.y);
   float4_t v;
-  v.x = float(lo.x); v.y = float(lo.y); v.z = float(hi.x); v.w = float(hi.y);
+  v.x = half_bits_to_float(r.x & 0xffffu); v.y = half_bits_to_float(r.x >> 16);
+  v.z = half_bits_to_float(r.y & 0xffffu); v.w = half_bits_to_float(r.y >> 16);
   return v;
 }
 
@@ -80,12 +82,15 @@ __device__ __forceinline__ void store_row4<bf16_t>(bf16_t* p, float4_t v) {
   r.y = uint32_t(f32_to_bf16_bits(v.z)) | (uint32_t(f32_to_bf16_bits(v.w)) << 16);
   *reinterpret_cast<uint2_t*>(p) = r;
 }
+__device__ __forceinline__ uint32_t float_to_half_bits(float f) {
+  return uint32_t(__builtin_bit_cast(uint16_t, _Float16(f)));
+}
 template <>
 __device__ __forceinline__ void store_row4<f16_t>(f16_t* p, float4_t v) {
-  typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
-  half4_t h;
-  h.x = _Float16(v.x); h.y = _Float16(v.y); h.z = _Float16(v.z); h.w = _Float16(v.w);
-  *reinterpret_cast<half4_t*>(p) = h;
+  uint2_t r;
+  r.x = float_to_half_bits(v.x) | (float_to_half_bits(v.y) << 16);
+  r.y = float_to_half_bits(v.z) | (float_to_half_bits(v.w) << 16);
+  *reinterpret_cast<uint2_t*>(p) = r;
 }
 
 // -----------------------------------------------------------------------------
@@ -271,7 +276,6 @@ bool msda_d32_fwd_supported(int vdt, int ldt, const MsdaDims& d) {
   return true;
 }
 
-bool msda_d32_bwd_supported(int, int, const MsdaDims&) { return false; }
 
 int msda_forward_d32(int vdt, int ldt, const void* value, const int64_t* shapes,
                      const int64_t* lsi, const void* loc, const void* attn, void* out, MsdaDims d,
@@ -285,10 +289,271 @@ int msda_forward_d32(int vdt, int ldt, const void* value, const int64_t* shapes,
   return VNX_ERR_INVALID_ARGUMENT;
 }
 
-int msda_backward_d32(int, int, const void*, const int64_t*, const int64_t*, const void*,
-                      const void*, const void*, void*, void*, void*, MsdaDims, int, hipStream_t) {
-  set_error("msda_backward_d32: not built");
+// -----------------------------------------------------------------------------
+// backward
+// -----------------------------------------------------------------------------
+// 8-lane sum that leaves the total in every lane of the group: two quad
+// permutes and a half-row mirror, all DPP (no LDS traffic).
+__device__ __forceinline__ float group8_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  return v;
+}
+
+template <typename TV>
+__device__ __forceinline__ float4_t load_row4(const TV* p);
+template <>
+__device__ __forceinline__ float4_t load_row4<float>(const float* p) {
+  return *reinterpret_cast<const float4_t*>(p);
+}
+template <>
+__device__ __forceinline__ float4_t load_row4<bf16_t>(const bf16_t* p) {
+  const uint2_t r = *reinterpret_cast<const uint2_t*>(p);
+  float4_t v;
+  v.x = __uint_as_float(r.x << 16); v.y = __uint_as_float(r.x & 0xffff0000u);
+  v.z = __uint_as_float(r.y << 16); v.w = __uint_as_float(r.y & 0xffff0000u);
+  return v;
+}
+template <>
+__device__ __forceinline__ float4_t load_row4<f16_t>(const f16_t* p) {
+  const uint2_t r = *reinterpret_cast<const uint2_t*>(p);
+  float4_t v;
+  v.x = half_bits_to_float(r.x & 0xffffu); v.y = half_bits_to_float(r.x >> 16);
+  v.z = half_bits_to_float(r.y & 0xffffu); v.w = half_bits_to_float(r.y >> 16);
+  return v;
+}
+
+template <typename TL>
+__device__ __forceinline__ void store_loc(TL* p, float v) { *p = from_acc<TL>(v); }
+
+// Same lane map as the forward (QPW queries x 8/QPW sample groups x 8 channel
+// lanes) with three phases per wave:
+//   1. one lane per (query, sample): geometry -> LDS record {4 tap offsets | lh, lw, attn, -}
+//   2. 8-lane groups walk their samples: 4 tap loads, 16 hardware fp32 atomics into
+//      the grad_value image (taps outside the map carry an out-of-range offset, which
+//      the buffer unit drops for atomics just as it zero-fills loads), channel partial
+//      sums of the three scalar gradients reduced over the 8 lanes with DPP;
+//   3. the phase-1 lane of each sample scales by (W, H) and writes grad_loc /
+//      grad_attn coalesced -- once, no atomics (the reference's block reductions,
+//      cuh:376-394, become 9 DPP adds).
+// grad_value accumulates in fp32 (`gv`: grad_value itself for fp32, the workspace
+// image for 16-bit values), laid out [B,S,M,32] fp32.
+template <typename TV, typename TL, int QPW, int WPB, int LP_T, bool ATOMICS>
+__global__ void __launch_bounds__(64 * WPB)
+msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ shapes,
+                    const int64_t* __restrict__ lsi, const TL* __restrict__ loc,
+                    const TL* __restrict__ attn, const TV* __restrict__ grad_out,
+                    float* __restrict__ gv, TL* __restrict__ grad_loc, TL* __restrict__ grad_attn,
+                    MsdaDims d, int tiles_per_batch) {
+  constexpr int D = 32;
+  constexpr int PG = 8 / QPW;
+  constexpr int kRowBytes = D * int(sizeof(TV));
+  constexpr int kLaneBytes = kRowBytes / 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int LP = LP_T > 0 ? LP_T : d.L * d.P;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int m = blockIdx.x % d.M;
+  const int tile = blockIdx.x / d.M;
+  const int b = tile / tiles_per_batch;
+  const int q0 = (tile - b * tiles_per_batch) * (QPW * WPB) + wave * QPW;
+
+  // per-wave LDS: tap offsets, geometry, results
+  const int ent = QPW * (LP + 1);
+  uint4_t* s_off = reinterpret_cast<uint4_t*>(smem) + size_t(wave) * 3 * ent;
+  float4_t* s_geo = reinterpret_cast<float4_t*>(s_off + ent);
+  float4_t* s_res = s_geo + ent;
+
+  const uint32_t pixel_elems = uint32_t(d.M * D);
+
+  // ---- phase 1 ------------------------------------------------------------------
+  const int pairs = QPW * LP;
+  for (int e = lane; e < pairs; e += 64) {
+    const int qi = e / LP, p = e - qi * LP;
+    const int q = q0 + qi;
+    uint4_t o4 = {kTapOutside, kTapOutside, kTapOutside, kTapOutside};
+    float4_t g4 = {0.f, 0.f, 0.f, 0.f};
+    if (q < d.Lq) {
+      const int l = p / d.P;
+      const int64_t wi = ((int64_t(b) * d.Lq + q) * d.M + m) * LP + p;
+      const float x = to_acc(loc[2 * wi]), y = to_acc(loc[2 * wi + 1]);
+      const float a = to_acc(attn[wi]);
+      const int H = int(shapes[2 * l]), W = int(shapes[2 * l + 1]);
+      const int start = int(lsi[l]);
+      const float h = y * float(H) - 0.5f, w = x * float(W) - 0.5f;
+      if (h > -1.f && w > -1.f && h < float(H) && w < float(W)) {
+        const float hf = floorf(h), wf = floorf(w);
+        const int h0 = int(hf), w0 = int(wf);
+        const bool top = h0 >= 0, bot = h0 + 1 <= H - 1, lef = w0 >= 0, rig = w0 + 1 <= W - 1;
+        // element (not byte) offsets: the same record addresses `value` (x sizeof(TV))
+        // and the fp32 gradient image (x 4)
+        const uint32_t o00 = uint32_t(start + h0 * W + w0) * pixel_elems;  // mod 2^32 on purpose
+        o4.x = (top && lef) ? o00 : kTapOutside;
+        o4.y = (top && rig) ? o00 + pixel_elems : kTapOutside;
+        o4.z = (bot && lef) ? o00 + uint32_t(W) * pixel_elems : kTapOutside;
+        o4.w = (bot && rig) ? o00 + uint32_t(W + 1) * pixel_elems : kTapOutside;
+        g4.x = h - hf; g4.y = w - wf; g4.z = a;
+      }
+    }
+    s_off[qi * (LP + 1) + p] = o4;
+    s_geo[qi * (LP + 1) + p] = g4;
+  }
+  if (WPB > 1) __syncthreads(); else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+
+  // ---- phase 2 ------------------------------------------------------------------
+  const int ch = lane & 7;
+  const int qi = (lane >> 3) % QPW;
+  const int pg = lane / (8 * QPW);
+  const int q = q0 + qi;
+
+  const int64_t head_elem = (int64_t(b) * d.S * d.M + m) * D;
+  const uint32_t head_elems = uint32_t((int64_t(d.S) * d.M - m) * D);
+  const TV* vbase = value + head_elem;
+  float* gbase = gv + head_elem;
+  const __amdgpu_buffer_rsrc_t vsrc = make_rsrc(
+      reinterpret_cast<const void*>(
+          uintptr_t(__builtin_amdgcn_readfirstlane(uint32_t(uintptr_t(vbase)))) |
+          (uintptr_t(__builtin_amdgcn_readfirstlane(uint32_t(uintptr_t(vbase) >> 32))) << 32)),
+      __builtin_amdgcn_readfirstlane(head_elems * uint32_t(sizeof(TV))));
+  const __amdgpu_buffer_rsrc_t gsrc = make_rsrc(
+      reinterpret_cast<const void*>(
+          uintptr_t(__builtin_amdgcn_readfirstlane(uint32_t(uintptr_t(gbase)))) |
+          (uintptr_t(__builtin_amdgcn_readfirstlane(uint32_t(uintptr_t(gbase) >> 32))) << 32)),
+      __builtin_amdgcn_readfirstlane(head_elems * 4u));
+
+  float4_t top = {0.f, 0.f, 0.f, 0.f};
+  if (q < d.Lq) top = load_row4<TV>(grad_out + ((int64_t(b) * d.Lq + q) * d.M + m) * D + ch * 4);
+
+  const int per_group = LP / PG;
+  const uint4_t* g_off = s_off + qi * (LP + 1) + pg * per_group;
+  const float4_t* g_geo = s_geo + qi * (LP + 1) + pg * per_group;
+  float4_t* g_res = s_res + qi * (LP + 1) + pg * per_group;
+
+  constexpr int kUnroll = LP_T > 0 ? (LP_T / PG >= 4 ? 4 : LP_T / PG) : 1;
+#pragma unroll kUnroll
+  for (int i = 0; i < per_group; ++i) {
+    const uint4_t o = g_off[i];
+    const float4_t geo = g_geo[i];
+    const float lh = geo.x, lw = geo.y, a = geo.z;
+    const float hh = 1.f - lh, hw = 1.f - lw;
+    const float4_t v1 = load_tap<TV>(vsrc, o.x * uint32_t(sizeof(TV)) + ch * kLaneBytes);
+    const float4_t v2 = load_tap<TV>(vsrc, o.y * uint32_t(sizeof(TV)) + ch * kLaneBytes);
+    const float4_t v3 = load_tap<TV>(vsrc, o.z * uint32_t(sizeof(TV)) + ch * kLaneBytes);
+    const float4_t v4 = load_tap<TV>(vsrc, o.w * uint32_t(sizeof(TV)) + ch * kLaneBytes);
+    const float4_t tg = top * a;
+    if (ATOMICS) {
+      const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+      const float4_t g1 = tg * w1, g2 = tg * w2, g3 = tg * w3, g4 = tg * w4;
+      const uint32_t b1 = o.x * 4u + ch * 16u, b2 = o.y * 4u + ch * 16u;
+      const uint32_t b3 = o.z * 4u + ch * 16u, b4 = o.w * 4u + ch * 16u;
+#define VNX_ATOM4(g, bo)                                                               \
+      __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(g.x, gsrc, int(bo), 0, 0);         \
+      __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(g.y, gsrc, int(bo + 4), 0, 0);     \
+      __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(g.z, gsrc, int(bo + 8), 0, 0);     \
+      __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(g.w, gsrc, int(bo + 12), 0, 0);
+      VNX_ATOM4(g1, b1) VNX_ATOM4(g2, b2) VNX_ATOM4(g3, b3) VNX_ATOM4(g4, b4)
+#undef VNX_ATOM4
+    }
+    // per-channel: val = bilinear tap, gh / gw = d(val)/d(h, w)   (cuh:123-151)
+    const float4_t dh = hw * (v3 - v1) + lw * (v4 - v2);
+    const float4_t dw = hh * (v2 - v1) + lh * (v4 - v3);
+    const float4_t val = hh * (hw * v1 + lw * v2) + lh * (hw * v3 + lw * v4);
+    float s_ga = top.x * val.x + top.y * val.y + top.z * val.z + top.w * val.w;
+    float s_gx = tg.x * dw.x + tg.y * dw.y + tg.z * dw.z + tg.w * dw.w;
+    float s_gy = tg.x * dh.x + tg.y * dh.y + tg.z * dh.z + tg.w * dh.w;
+    s_ga = group8_sum(s_ga);
+    s_gx = group8_sum(s_gx);
+    s_gy = group8_sum(s_gy);
+    if (ch == 0) {
+      float4_t r = {s_gx, s_gy, s_ga, 0.f};
+      g_res[i] = r;
+    }
+  }
+  if (WPB > 1) __syncthreads(); else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+
+  // ---- phase 3 ------------------------------------------------------------------
+  for (int e = lane; e < pairs; e += 64) {
+    const int qi3 = e / LP, p = e - qi3 * LP;
+    const int q3 = q0 + qi3;
+    if (q3 < d.Lq) {
+      const int l = p / d.P;
+      const int64_t wi = ((int64_t(b) * d.Lq + q3) * d.M + m) * LP + p;
+      const float4_t r = s_res[qi3 * (LP + 1) + p];
+      const float Hf = float(int(shapes[2 * l])), Wf = float(int(shapes[2 * l + 1]));
+      store_loc<TL>(grad_loc + 2 * wi, Wf * r.x);       // cuh:157
+      store_loc<TL>(grad_loc + 2 * wi + 1, Hf * r.y);   // cuh:158
+      store_loc<TL>(grad_attn + wi, r.z);               // cuh:156
+    }
+  }
+}
+
+template <typename TV, typename TL, int QPW, int WPB>
+static int launch_bwd_cfg(const void* value, const int64_t* shapes, const int64_t* lsi,
+                          const void* loc, const void* attn, const void* grad_out, void* gv,
+                          void* grad_loc, void* grad_attn, const MsdaDims& d, bool atomics,
+                          hipStream_t stream) {
+  const int LP = d.L * d.P;
+  const int tiles_per_batch = (d.Lq + QPW * WPB - 1) / (QPW * WPB);
+  const int64_t blocks = int64_t(d.B) * tiles_per_batch * d.M;
+  if (blocks >= (int64_t(1) << 31)) {
+    set_error("msda_backward: %lld workgroups exceed the grid limit", (long long)blocks);
+    return VNX_ERR_UNSUPPORTED;
+  }
+  const size_t lds = size_t(WPB) * 3 * QPW * (LP + 1) * 16;
+#define VNX_LAUNCH(LPT, AT)                                                                     \
+  hipLaunchKernelGGL((msda_bwd_d32_kernel<TV, TL, QPW, WPB, LPT, AT>), dim3(uint32_t(blocks)),   \
+                     dim3(64 * WPB), lds, stream, (const TV*)value, shapes, lsi, (const TL*)loc, \
+                     (const TL*)attn, (const TV*)grad_out, (float*)gv, (TL*)grad_loc,            \
+                     (TL*)grad_attn, d, tiles_per_batch)
+  if (!atomics) { if (LP == 16) VNX_LAUNCH(16, false); else VNX_LAUNCH(0, false); }
+  else { if (LP == 16) VNX_LAUNCH(16, true); else VNX_LAUNCH(0, true); }
+#undef VNX_LAUNCH
+  return check_launch("msda_bwd_d32");
+}
+
+template <typename TV, typename TL>
+static int launch_bwd(const void* value, const int64_t* shapes, const int64_t* lsi,
+                      const void* loc, const void* attn, const void* grad_out, void* gv,
+                      void* grad_loc, void* grad_attn, const MsdaDims& d, int variant,
+                      hipStream_t stream) {
+  // variant 100+v: ablation without the grad_value atomics (timing only, wrong grad_value)
+  const bool atomics = variant < 100;
+  const FwdCfg c = pick_fwd_cfg(d, atomics ? variant : variant - 100);
+#define VNX_CASE(Q, W)                                                                       \
+  if (c.qpw == Q && c.wpb == W)                                                              \
+    return launch_bwd_cfg<TV, TL, Q, W>(value, shapes, lsi, loc, attn, grad_out, gv, grad_loc, \
+                                        grad_attn, d, atomics, stream);
+  VNX_CASE(8, 4) VNX_CASE(4, 4) VNX_CASE(2, 4) VNX_CASE(1, 4)
+  VNX_CASE(8, 1) VNX_CASE(4, 1) VNX_CASE(2, 1) VNX_CASE(1, 1)
+  VNX_CASE(4, 2)
+#undef VNX_CASE
+  set_error("msda_backward: no kernel for qpw=%d wpb=%d", c.qpw, c.wpb);
   return VNX_ERR_UNSUPPORTED;
+}
+
+bool msda_d32_bwd_supported(int vdt, int ldt, const MsdaDims& d) {
+  if (!msda_d32_fwd_supported(vdt, ldt, d)) return false;
+  // the fp32 gradient image of one batch element must fit the descriptor too
+  return int64_t(d.S) * d.M * 32 * 4 < (int64_t(1) << 31);
+}
+
+int msda_backward_d32(int vdt, int ldt, const void* value, const int64_t* shapes,
+                      const int64_t* lsi, const void* loc, const void* attn,
+                      const void* grad_out, void* gv, void* grad_loc, void* grad_attn, MsdaDims d,
+                      int variant, hipStream_t stream) {
+#define VNX_ARGS value, shapes, lsi, loc, attn, grad_out, gv, grad_loc, grad_attn, d, variant, stream
+  if (vdt == VNX_F32) return launch_bwd<float, float>(VNX_ARGS);
+  if (vdt == VNX_BF16 && ldt == VNX_F32) return launch_bwd<bf16_t, float>(VNX_ARGS);
+  if (vdt == VNX_BF16 && ldt == VNX_BF16) return launch_bwd<bf16_t, bf16_t>(VNX_ARGS);
+  if (vdt == VNX_F16 && ldt == VNX_F32) return launch_bwd<f16_t, float>(VNX_ARGS);
+  if (vdt == VNX_F16 && ldt == VNX_F16) return launch_bwd<f16_t, f16_t>(VNX_ARGS);
+#undef VNX_ARGS
+  set_error("msda_backward_d32: unsupported dtype pair (%d, %d)", vdt, ldt);
+  return VNX_ERR_INVALID_ARGUMENT;
 }
 
 }  // namespace vnx
