@@ -26,7 +26,10 @@
 
 namespace vnx {
 
-constexpr uint32_t kTapOutside = 0x80000000u;  // > any num_records the host admits
+constexpr uint32_t kTapOutside = 0x80000000u;  // byte offset > any num_records the host admits
+// The backward keeps ELEMENT offsets (one record addresses both `value` and the fp32 gradient
+// image); x2 or x4 of this marker is still out of range and does not wrap 32 bits.
+constexpr uint32_t kTapOutsideElem = 0x20000000u;
 
 typedef float float4_t __attribute__((ext_vector_type(4)));
 typedef uint32_t uint4_t __attribute__((ext_vector_type(4)));
@@ -35,6 +38,15 @@ typedef uint32_t uint2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes) {
   // wave-uniform inputs only (callers pass readfirstlane'd values)
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, int(bytes), 0x00020000);
+}
+
+// Descriptor over [base, base+bytes) whose words the compiler can prove wave-uniform
+// (readfirstlane of both pointer halves; through uint32_t so nothing sign-extends).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* base, uint32_t bytes) {
+  const uint32_t lo = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(uintptr_t(base)))));
+  const uint32_t hi = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(uintptr_t(base) >> 32))));
+  const uint32_t n = uint32_t(__builtin_amdgcn_readfirstlane(int(bytes)));
+  return make_rsrc(reinterpret_cast<const void*>(uintptr_t(lo) | (uintptr_t(hi) << 32)), n);
 }
 
 // 4 consecutive channels of one tap as fp32
@@ -167,11 +179,7 @@ msda_fwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
 
   const TV* head_base = value + (int64_t(b) * d.S * d.M + m) * D;
   const uint32_t head_bytes = uint32_t((int64_t(d.S) * d.M - m) * kRowBytes);
-  const uint32_t lo = __builtin_amdgcn_readfirstlane(uint32_t(uintptr_t(head_base)));
-  const uint32_t hi = __builtin_amdgcn_readfirstlane(uint32_t(uintptr_t(head_base) >> 32));
-  const __amdgpu_buffer_rsrc_t rsrc =
-      make_rsrc(reinterpret_cast<const void*>(uintptr_t(lo) | (uintptr_t(hi) << 32)),
-                __builtin_amdgcn_readfirstlane(head_bytes));
+  const __amdgpu_buffer_rsrc_t rsrc = uniform_rsrc(head_base, head_bytes);
 
   const int per_group = LP / PG;  // host guarantees LP % PG == 0
   const uint4_t* g_off = s_off + qi * (LP + 1) + pg * per_group;
@@ -373,7 +381,7 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
   for (int e = lane; e < pairs; e += 64) {
     const int qi = e / LP, p = e - qi * LP;
     const int q = q0 + qi;
-    uint4_t o4 = {kTapOutside, kTapOutside, kTapOutside, kTapOutside};
+    uint4_t o4 = {kTapOutsideElem, kTapOutsideElem, kTapOutsideElem, kTapOutsideElem};
     float4_t g4 = {0.f, 0.f, 0.f, 0.f};
     if (q < d.Lq) {
       const int l = p / d.P;
@@ -390,10 +398,10 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
         // element (not byte) offsets: the same record addresses `value` (x sizeof(TV))
         // and the fp32 gradient image (x 4)
         const uint32_t o00 = uint32_t(start + h0 * W + w0) * pixel_elems;  // mod 2^32 on purpose
-        o4.x = (top && lef) ? o00 : kTapOutside;
-        o4.y = (top && rig) ? o00 + pixel_elems : kTapOutside;
-        o4.z = (bot && lef) ? o00 + uint32_t(W) * pixel_elems : kTapOutside;
-        o4.w = (bot && rig) ? o00 + uint32_t(W + 1) * pixel_elems : kTapOutside;
+        o4.x = (top && lef) ? o00 : kTapOutsideElem;
+        o4.y = (top && rig) ? o00 + pixel_elems : kTapOutsideElem;
+        o4.z = (bot && lef) ? o00 + uint32_t(W) * pixel_elems : kTapOutsideElem;
+        o4.w = (bot && rig) ? o00 + uint32_t(W + 1) * pixel_elems : kTapOutsideElem;
         g4.x = h - hf; g4.y = w - wf; g4.z = a;
       }
     }
@@ -413,16 +421,8 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
   const uint32_t head_elems = uint32_t((int64_t(d.S) * d.M - m) * D);
   const TV* vbase = value + head_elem;
   float* gbase = gv + head_elem;
-  const __amdgpu_buffer_rsrc_t vsrc = make_rsrc(
-      reinterpret_cast<const void*>(
-          uintptr_t(__builtin_amdgcn_readfirstlane(uint32_t(uintptr_t(vbase)))) |
-          (uintptr_t(__builtin_amdgcn_readfirstlane(uint32_t(uintptr_t(vbase) >> 32))) << 32)),
-      __builtin_amdgcn_readfirstlane(head_elems * uint32_t(sizeof(TV))));
-  const __amdgpu_buffer_rsrc_t gsrc = make_rsrc(
-      reinterpret_cast<const void*>(
-          uintptr_t(__builtin_amdgcn_readfirstlane(uint32_t(uintptr_t(gbase)))) |
-          (uintptr_t(__builtin_amdgcn_readfirstlane(uint32_t(uintptr_t(gbase) >> 32))) << 32)),
-      __builtin_amdgcn_readfirstlane(head_elems * 4u));
+  const __amdgpu_buffer_rsrc_t vsrc = uniform_rsrc(vbase, head_elems * uint32_t(sizeof(TV)));
+  const __amdgpu_buffer_rsrc_t gsrc = uniform_rsrc(gbase, head_elems * 4u);
 
   float4_t top = {0.f, 0.f, 0.f, 0.f};
   if (q < d.Lq) top = load_row4<TV>(grad_out + ((int64_t(b) * d.Lq + q) * d.M + m) * D + ch * 4);
@@ -537,8 +537,8 @@ static int launch_bwd(const void* value, const int64_t* shapes, const int64_t* l
 
 bool msda_d32_bwd_supported(int vdt, int ldt, const MsdaDims& d) {
   if (!msda_d32_fwd_supported(vdt, ldt, d)) return false;
-  // the fp32 gradient image of one batch element must fit the descriptor too
-  return int64_t(d.S) * d.M * 32 * 4 < (int64_t(1) << 31);
+  // element offsets stay below the out-of-range marker (2^29 elements)
+  return int64_t(d.S) * d.M * 32 < int64_t(kTapOutsideElem);
 }
 
 int msda_backward_d32(int vdt, int ldt, const void* value, const int64_t* shapes,
