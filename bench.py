@@ -98,7 +98,7 @@ class Op:
             0, 0, s["value"].data_ptr(), s["shapes"].data_ptr(), s["lsi"].data_ptr(),
             s["loc"].data_ptr(), s["attn"].data_ptr(), s["grad_out"].data_ptr(),
             s["gv"].data_ptr(), s["gl"].data_ptr(), s["ga"].data_ptr(),
-            B, s["S"], 8, 32, 4, Lq, 4, None, 0, torch.cuda.current_stream().cuda_stream)
+            B, s["S"], 8, 32, 4, Lq, 4, 1, None, 0, torch.cuda.current_stream().cuda_stream)
         self._lib.check(st)
 
 

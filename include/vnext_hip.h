@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define VNX_ABI_VERSION 1
+#define VNX_ABI_VERSION 2
 
 /* element types */
 enum {
@@ -82,23 +82,42 @@ int vnx_msda_forward(int value_dtype, int loc_dtype,
                      int num_levels, int num_query, int num_point,
                      void* hip_stream);
 
+/* flags of vnx_msda_backward */
+enum {
+  /*
+   * The caller guarantees the levels are packed back to back in order:
+   * level_start_index[l] == sum_{j<l} H_j*W_j and the sum over all levels ==
+   * spatial_size -- the layout the reference always builds
+   * (projects/SeqFormer/seqformer/models/deformable_transformer.py:97-106).
+   * Without the flag the library works out the same predicate ON THE DEVICE and
+   * issues both the fast kernels and the general ones, each set exiting at once when
+   * the predicate is not theirs (no host synchronisation, ~2 empty launches).
+   */
+  VNX_MSDA_LEVELS_PACKED = 1
+};
+
 /*
- * Bytes of scratch vnx_msda_backward needs for these sizes (0 for F32 / F64;
- * an fp32 accumulation image of grad_value for 16-bit values).
+ * Bytes of scratch vnx_msda_backward needs for these sizes and flags: 0 for F32 /
+ * F64, and for 16-bit values whose levels are promised packed; otherwise an fp32
+ * accumulation image of grad_value.
  */
-size_t vnx_msda_backward_workspace_bytes(int value_dtype, int batch, int spatial_size,
-                                         int num_heads, int channels);
+size_t vnx_msda_backward_workspace_bytes(int value_dtype, int loc_dtype, int batch,
+                                         int spatial_size, int num_heads, int channels,
+                                         int num_levels, int num_query, int num_point, int flags);
 
 /*
  * Multi-scale deformable attention, backward (ms_deform_im2col_cuda.cuh:87-159).
  * All three gradient buffers are fully written; they need no zero pre-fill by
  * the caller (the reference's three at::zeros_like, ms_deform_attn_cuda.cu:121-123,
- * are done on `hip_stream` inside the call where still needed).
+ * disappear, or happen on `hip_stream` inside the call where the general path
+ * still needs one).
  *   grad_value        like value        (value_dtype)
  *   grad_sampling_loc like sampling_loc (loc_dtype)
  *   grad_attn_weight  like attn_weight  (loc_dtype)
- * grad_value is accumulated with floating-point atomics, so its low-order bits
- * depend on scheduling, exactly as in the reference.
+ * With 32-channel heads and packed levels grad_value is produced without global
+ * atomics (one owner per row, accumulation in LDS); otherwise it is accumulated
+ * with hardware floating-point atomics as in the reference.  Either way its
+ * low-order bits depend on scheduling.
  */
 int vnx_msda_backward(int value_dtype, int loc_dtype,
                       const void* value, const int64_t* spatial_shapes,
@@ -106,7 +125,7 @@ int vnx_msda_backward(int value_dtype, int loc_dtype,
                       const void* attn_weight, const void* grad_output,
                       void* grad_value, void* grad_sampling_loc, void* grad_attn_weight,
                       int batch, int spatial_size, int num_heads, int channels,
-                      int num_levels, int num_query, int num_point,
+                      int num_levels, int num_query, int num_point, int flags,
                       void* workspace, size_t workspace_bytes,
                       void* hip_stream);
 

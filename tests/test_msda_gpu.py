@@ -223,7 +223,7 @@ def test_forward_16bit(dtype, loc_fp32, variant):
         assert np.abs(out - ref).max() <= tight * scale_of(ref)
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 5, 12, 15, 300, 303])
 @pytest.mark.parametrize("Lq,uniform", [(300, True), (37, False), (1, False)])
 def test_backward_f32_vs_oracle(variant, Lq, uniform):
     g = make_case(200 + Lq, 3, 8, 32, PYRAMID, Lq, 4, model_like=not uniform)
@@ -249,6 +249,63 @@ def test_backward_16bit(dtype, variant):
     np.testing.assert_allclose(gv, rv, rtol=0, atol=1e-2 * scale_of(rv))
     np.testing.assert_allclose(gl, rl, rtol=0, atol=1e-4 * scale_of(rl))
     np.testing.assert_allclose(ga, ra, rtol=0, atol=1e-4 * scale_of(ra))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_backward_levels_packed_promise_changes_nothing(dtype):
+    """The packed-levels promise only removes launches; values are the same kernels' output."""
+    g = make_case(33, 2, 8, 32, PYRAMID, 77, 4)
+    ldt = torch.float32
+    args = (dev(g["value"], dtype), dev(g["shapes"]), dev(g["lsi"]), dev(g["loc"], ldt),
+            dev(g["attn"], ldt), dev(g["grad_out"], dtype), 64)
+    a = MSDA.ms_deform_attn_backward(*args)
+    b = MSDA.ms_deform_attn_backward(*args, levels_packed=True)
+    torch.cuda.synchronize()
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    for x, y in zip(a, b):
+        s = float(x.float().abs().max())
+        assert float((x.float() - y.float()).abs().max()) <= tol * s
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_backward_unpacked_levels_take_the_general_path(dtype):
+    """Levels stored out of order with gaps: the reference semantics (any
+    level_start_index) must survive; the owner-computes kernels stand down on the device."""
+    g = make_case(35, 2, 8, 32, [(6, 9), (4, 5), (2, 3)], 41, 4)
+    sizes = [54, 20, 6]
+    lsi = np.array([40, 100, 3], dtype=np.int64)       # level 2 first, gaps everywhere
+    S = 160
+    rng = np.random.default_rng(0)
+    value = rng.standard_normal((2, S, 8, 32)).astype(np.float32)
+    g = dict(g, lsi=lsi, value=value)
+    vq = torch.from_numpy(value).to(dtype).double().numpy()
+    goq = torch.from_numpy(g["grad_out"]).to(dtype).double().numpy()
+    ref = O.msda_forward(vq, g["shapes"], lsi, g["loc"].astype(np.float64), g["attn"].astype(np.float64))
+    rv, rl, ra = O.msda_backward(vq, g["shapes"], lsi, g["loc"].astype(np.float64),
+                                 g["attn"].astype(np.float64), goq)
+    out = run_fwd(g, dtype, loc_dtype=torch.float32)
+    gv, gl, ga = run_bwd(dict(g, grad_out=goq), dtype, loc_dtype=torch.float32)
+    tol = 2e-5 if dtype == torch.float32 else 1e-2
+    np.testing.assert_allclose(out, ref, rtol=0, atol=tol * scale_of(ref))
+    np.testing.assert_allclose(gv, rv, rtol=0, atol=tol * scale_of(rv))
+    np.testing.assert_allclose(gl, rl, rtol=0, atol=tol * scale_of(rl))
+    np.testing.assert_allclose(ga, ra, rtol=0, atol=tol * scale_of(ra))
+    used = np.zeros(S, bool)
+    for s0, n in zip(lsi, sizes):
+        used[s0:s0 + n] = True
+    assert np.all(gv[:, ~used] == 0)
+
+
+@pytest.mark.parametrize("units_min", [1, 2, 8, 16])
+def test_backward_owner_units_split(units_min):
+    """grad_value does not depend on how the levels are cut into owner units."""
+    g = make_case(37, 2, 8, 32, [(31, 33), (16, 17), (8, 9), (1, 1)], 90, 4, spread=3.0)
+    rv, rl, ra = O.msda_backward(g["value"].astype(np.float64), g["shapes"], g["lsi"],
+                                 g["loc"].astype(np.float64), g["attn"].astype(np.float64),
+                                 g["grad_out"], nthreads=4)
+    gv, gl, ga = run_bwd(g, torch.float32, variant=200 + units_min)
+    np.testing.assert_allclose(gv, rv, rtol=0, atol=2e-5 * scale_of(rv))
+    np.testing.assert_allclose(gl, rl, rtol=0, atol=2e-5 * scale_of(rl))
 
 
 # ------------------------------------------------------------------ edge cases

@@ -72,6 +72,9 @@ def time_graph(fn_list, reps=20):
     return ts[len(ts) // 2], ts[0]
 
 
+PACKED = True
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shape", default="dec360")
@@ -103,7 +106,7 @@ def main():
         def mk(i, bwd):
             sh, lsi, val, loc, attn, go = sets[i % nsets]
             if bwd:
-                return lambda: MSDA.ms_deform_attn_backward(val, sh, lsi, loc, attn, go, 64)
+                return lambda: MSDA.ms_deform_attn_backward(val, sh, lsi, loc, attn, go, 64, levels_packed=PACKED)
             return lambda: MSDA.ms_deform_attn_forward(val, sh, lsi, loc, attn, 64)
         for bwd in ([True] if a.bwd_only else [False, True] if a.bwd else [False]):
             cold = time_graph([mk(i, bwd) for i in range(a.inner)])

@@ -14,7 +14,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "libvnext_hip.so")
 
 VNX_F32, VNX_F64, VNX_BF16, VNX_F16 = 0, 1, 2, 3
 VNX_OK = 0
-ABI_VERSION = 1
+ABI_VERSION = 2
+MSDA_LEVELS_PACKED = 1
 
 _vp, _i, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
 
@@ -24,8 +25,8 @@ SIGNATURES = {
     "vnx_status_string": (ctypes.c_char_p, [_i]),
     "vnx_last_error": (ctypes.c_char_p, []),
     "vnx_msda_forward": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp] + [_i] * 7 + [_vp]),
-    "vnx_msda_backward_workspace_bytes": (_sz, [_i] * 5),
-    "vnx_msda_backward": (_i, [_i, _i] + [_vp] * 9 + [_i] * 7 + [_vp, _sz, _vp]),
+    "vnx_msda_backward_workspace_bytes": (_sz, [_i] * 10),
+    "vnx_msda_backward": (_i, [_i, _i] + [_vp] * 9 + [_i] * 8 + [_vp, _sz, _vp]),
     "vnx_set_kernel_variant": (None, [_i]),
     "vnx_get_kernel_variant": (_i, []),
 }

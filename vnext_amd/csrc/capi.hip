@@ -32,8 +32,14 @@ int check_launch(const char* what) {
 int msda_forward_generic(int, int, const void*, const int64_t*, const int64_t*, const void*,
                          const void*, void*, MsdaDims, hipStream_t);
 int msda_backward_generic(int, int, const void*, const int64_t*, const int64_t*, const void*,
-                          const void*, const void*, void*, void*, void*, MsdaDims, hipStream_t);
-int convert_f32_to(int, const void*, void*, int64_t, hipStream_t);
+                          const void*, const void*, void*, void*, void*, MsdaDims,
+                          int only_if_not_packed, hipStream_t);
+int convert_f32_to(int, const void*, void*, int64_t, const int64_t*, const int64_t*, int, int,
+                   hipStream_t);
+bool msda_d32_gv_supported(int vdt, int ldt, const MsdaDims& d);
+int msda_backward_gv_d32(int, int, const int64_t*, const int64_t*, const void*, const void*,
+                         const void*, void*, MsdaDims, int variant, hipStream_t);
+int zero_if_not_packed(const int64_t*, const int64_t*, int, int, void*, size_t, hipStream_t);
 bool msda_d32_fwd_supported(int vdt, int ldt, const MsdaDims& d);
 bool msda_d32_bwd_supported(int vdt, int ldt, const MsdaDims& d);
 int msda_forward_d32(int, int, const void*, const int64_t*, const int64_t*, const void*,
@@ -121,9 +127,19 @@ int vnx_msda_forward(int value_dtype, int loc_dtype, const void* value,
                               sampling_loc, attn_weight, output, d, stream);
 }
 
-size_t vnx_msda_backward_workspace_bytes(int value_dtype, int batch, int spatial_size,
-                                         int num_heads, int channels) {
+static bool bwd_fast_path(int vdt, int ldt, const MsdaDims& d, int variant) {
+  return variant != 1 && !(variant >= 300 && variant < 400) &&
+         msda_d32_bwd_supported(vdt, ldt, d) && msda_d32_gv_supported(vdt, ldt, d);
+}
+
+size_t vnx_msda_backward_workspace_bytes(int value_dtype, int loc_dtype, int batch,
+                                         int spatial_size, int num_heads, int channels,
+                                         int num_levels, int num_query, int num_point, int flags) {
   if (value_dtype != VNX_BF16 && value_dtype != VNX_F16) return 0;
+  const MsdaDims d{batch, spatial_size, num_heads, channels, num_levels, num_query, num_point};
+  // packed levels promised + owner-computes kernels available: no fp32 image needed
+  if ((flags & VNX_MSDA_LEVELS_PACKED) && bwd_fast_path(value_dtype, loc_dtype, d, g_kernel_variant))
+    return 0;
   return sizeof(float) * size_t(batch) * size_t(spatial_size) * size_t(num_heads) * size_t(channels);
 }
 
@@ -132,14 +148,18 @@ int vnx_msda_backward(int value_dtype, int loc_dtype, const void* value,
                       const void* sampling_loc, const void* attn_weight, const void* grad_output,
                       void* grad_value, void* grad_sampling_loc, void* grad_attn_weight, int batch,
                       int spatial_size, int num_heads, int channels, int num_levels, int num_query,
-                      int num_point, void* workspace, size_t workspace_bytes, void* hip_stream) {
+                      int num_point, int flags, void* workspace, size_t workspace_bytes,
+                      void* hip_stream) {
   const MsdaDims d{batch, spatial_size, num_heads, channels, num_levels, num_query, num_point};
   int st = check_common("vnx_msda_backward", value_dtype, loc_dtype, value, spatial_shapes,
                         level_start_index, sampling_loc, attn_weight, d);
   if (st != VNX_OK) return st;
   hipStream_t stream = (hipStream_t)hip_stream;
+  const int variant = g_kernel_variant;
   const size_t n_value = size_t(batch) * size_t(spatial_size) * size_t(num_heads) * size_t(channels);
-  const size_t need = vnx_msda_backward_workspace_bytes(value_dtype, batch, spatial_size, num_heads, channels);
+  const size_t need = vnx_msda_backward_workspace_bytes(value_dtype, loc_dtype, batch, spatial_size,
+                                                        num_heads, channels, num_levels, num_query,
+                                                        num_point, flags);
   if (n_value > 0 && !grad_value) {
     set_error("vnx_msda_backward: null grad_value");
     return VNX_ERR_INVALID_ARGUMENT;
@@ -148,8 +168,50 @@ int vnx_msda_backward(int value_dtype, int loc_dtype, const void* value,
     set_error("vnx_msda_backward: needs %zu workspace bytes, got %zu", need, workspace_bytes);
     return VNX_ERR_WORKSPACE;
   }
+  const bool empty = (batch == 0 || num_query == 0);
+  if (!empty && (!grad_output || !grad_sampling_loc || !grad_attn_weight)) {
+    set_error("vnx_msda_backward: null gradient pointer");
+    return VNX_ERR_INVALID_ARGUMENT;
+  }
   void* gv_acc = need > 0 ? workspace : grad_value;
   const size_t acc_bytes = need > 0 ? need : n_value * size_t(elem_size(value_dtype));
+
+  if (!empty && bwd_fast_path(value_dtype, loc_dtype, d, variant)) {
+    // (1) grad_loc / grad_attn: per-query gather kernel, no atomics.
+    // (2) grad_value: owner-computes slabs; does nothing on the device unless the levels
+    //     are packed.
+    // (3) unless the caller promised packed levels: the general path, each kernel of which
+    //     does nothing on the device when the levels ARE packed.  No host sync either way.
+    const bool only_gl = variant >= 100 && variant < 200;  // timing ablations
+    const bool only_gv = variant == 400;
+    if (!only_gv) {
+      st = msda_backward_d32(value_dtype, loc_dtype, value, spatial_shapes, level_start_index,
+                             sampling_loc, attn_weight, grad_output, nullptr, grad_sampling_loc,
+                             grad_attn_weight, d, only_gl ? variant : 100 + (variant < 100 ? variant : 0),
+                             stream);
+      if (st != VNX_OK) return st;
+    }
+    if (!only_gl) {
+      st = msda_backward_gv_d32(value_dtype, loc_dtype, spatial_shapes, level_start_index,
+                                sampling_loc, attn_weight, grad_output, grad_value, d, variant, stream);
+      if (st != VNX_OK) return st;
+    }
+    if (!(flags & VNX_MSDA_LEVELS_PACKED) && !only_gl && !only_gv) {
+      st = zero_if_not_packed(spatial_shapes, level_start_index, num_levels, spatial_size, gv_acc,
+                              acc_bytes, stream);
+      if (st != VNX_OK) return st;
+      st = msda_backward_generic(value_dtype, loc_dtype, value, spatial_shapes, level_start_index,
+                                 sampling_loc, attn_weight, grad_output, gv_acc, grad_sampling_loc,
+                                 grad_attn_weight, d, /*only_if_not_packed=*/1, stream);
+      if (st != VNX_OK) return st;
+      if (need > 0)
+        return convert_f32_to(value_dtype, workspace, grad_value, int64_t(n_value), spatial_shapes,
+                              level_start_index, num_levels, spatial_size, stream);
+    }
+    return VNX_OK;
+  }
+
+  // general path: zero-filled image + hardware fp32/fp64 atomics
   if (acc_bytes > 0) {
     const hipError_t e = hipMemsetAsync(gv_acc, 0, acc_bytes, stream);
     if (e != hipSuccess) {
@@ -157,22 +219,19 @@ int vnx_msda_backward(int value_dtype, int loc_dtype, const void* value,
       return VNX_ERR_LAUNCH;
     }
   }
-  if (batch == 0 || num_query == 0) return VNX_OK;
-  if (!grad_output || !grad_sampling_loc || !grad_attn_weight) {
-    set_error("vnx_msda_backward: null gradient pointer");
-    return VNX_ERR_INVALID_ARGUMENT;
-  }
-  const int variant = g_kernel_variant;
-  if (variant != 1 && msda_d32_bwd_supported(value_dtype, loc_dtype, d))
+  if (empty) return VNX_OK;
+  if (variant >= 300 && variant < 400 && msda_d32_bwd_supported(value_dtype, loc_dtype, d))
     st = msda_backward_d32(value_dtype, loc_dtype, value, spatial_shapes, level_start_index,
                            sampling_loc, attn_weight, grad_output, gv_acc, grad_sampling_loc,
-                           grad_attn_weight, d, variant, stream);
+                           grad_attn_weight, d, variant - 300, stream);
   else
     st = msda_backward_generic(value_dtype, loc_dtype, value, spatial_shapes, level_start_index,
                                sampling_loc, attn_weight, grad_output, gv_acc, grad_sampling_loc,
-                               grad_attn_weight, d, stream);
+                               grad_attn_weight, d, /*only_if_not_packed=*/0, stream);
   if (st != VNX_OK) return st;
-  if (need > 0) return convert_f32_to(value_dtype, workspace, grad_value, int64_t(n_value), stream);
+  if (need > 0)
+    return convert_f32_to(value_dtype, workspace, grad_value, int64_t(n_value), nullptr, nullptr, 0, 0,
+                          stream);
   return VNX_OK;
 }
 

@@ -93,8 +93,9 @@ msda_bwd_generic_kernel(const TV* __restrict__ value, const int64_t* __restrict_
                         const int64_t* __restrict__ lsi, const TL* __restrict__ loc,
                         const TL* __restrict__ attn, const TV* __restrict__ grad_out,
                         TG* __restrict__ grad_value, TL* __restrict__ grad_loc,
-                        TL* __restrict__ grad_attn, MsdaDims d, int width) {
+                        TL* __restrict__ grad_attn, MsdaDims d, int width, int only_if_not_packed) {
   using A = acc_t<TV>;
+  if (only_if_not_packed && levels_packed(shapes, lsi, d.L, d.S)) return;
   const int groups_per_block = blockDim.x / width;
   const int gib = threadIdx.x / width;
   const int lig = threadIdx.x % width;
@@ -165,7 +166,10 @@ msda_bwd_generic_kernel(const TV* __restrict__ value, const int64_t* __restrict_
 // fp32 accumulation image -> 16-bit grad_value
 template <typename TV>
 __global__ void __launch_bounds__(256)
-convert_f32_kernel(const float* __restrict__ src, TV* __restrict__ dst, int64_t n) {
+convert_f32_kernel(const float* __restrict__ src, TV* __restrict__ dst, int64_t n,
+                   const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi, int L, int S) {
+  // shapes != nullptr: run only when the levels are NOT packed (general-path tail)
+  if (shapes != nullptr && levels_packed(shapes, lsi, L, S)) return;
   for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
        i += int64_t(gridDim.x) * blockDim.x)
     dst[i] = from_acc<TV>(src[i]);
@@ -207,21 +211,22 @@ template <typename TV, typename TL, typename TG>
 static int launch_bwd_generic(const void* value, const int64_t* shapes, const int64_t* lsi,
                               const void* loc, const void* attn, const void* grad_out,
                               void* gv_acc, void* grad_loc, void* grad_attn, MsdaDims d,
-                              hipStream_t stream) {
+                              int only_if_not_packed, hipStream_t stream) {
   int width = 1;
   while (width < d.D && width < kWave) width <<= 1;
   const int64_t rows = int64_t(d.B) * d.Lq * d.M;
   hipLaunchKernelGGL((msda_bwd_generic_kernel<TV, TL, TG>), dim3(grid_for(rows, 256 / width)),
                      dim3(256), 0, stream, (const TV*)value, shapes, lsi, (const TL*)loc,
                      (const TL*)attn, (const TV*)grad_out, (TG*)gv_acc, (TL*)grad_loc,
-                     (TL*)grad_attn, d, width);
+                     (TL*)grad_attn, d, width, only_if_not_packed);
   return check_launch("msda_bwd_generic");
 }
 
 template <typename TV>
-static int launch_convert(const void* src, void* dst, int64_t n, hipStream_t stream) {
+static int launch_convert(const void* src, void* dst, int64_t n, const int64_t* shapes,
+                          const int64_t* lsi, int L, int S, hipStream_t stream) {
   hipLaunchKernelGGL((convert_f32_kernel<TV>), dim3(grid_for(n, 256)), dim3(256), 0, stream,
-                     (const float*)src, (TV*)dst, n);
+                     (const float*)src, (TV*)dst, n, shapes, lsi, L, S);
   return check_launch("convert_f32");
 }
 
@@ -229,20 +234,22 @@ static int launch_convert(const void* src, void* dst, int64_t n, hipStream_t str
 int msda_backward_generic(int vdt, int ldt, const void* value, const int64_t* shapes,
                           const int64_t* lsi, const void* loc, const void* attn,
                           const void* grad_out, void* gv_acc, void* grad_loc, void* grad_attn,
-                          MsdaDims d, hipStream_t stream) {
-  if (vdt == VNX_F32) return launch_bwd_generic<float, float, float>(value, shapes, lsi, loc, attn, grad_out, gv_acc, grad_loc, grad_attn, d, stream);
-  if (vdt == VNX_F64) return launch_bwd_generic<double, double, double>(value, shapes, lsi, loc, attn, grad_out, gv_acc, grad_loc, grad_attn, d, stream);
-  if (vdt == VNX_BF16 && ldt == VNX_BF16) return launch_bwd_generic<bf16_t, bf16_t, float>(value, shapes, lsi, loc, attn, grad_out, gv_acc, grad_loc, grad_attn, d, stream);
-  if (vdt == VNX_BF16 && ldt == VNX_F32) return launch_bwd_generic<bf16_t, float, float>(value, shapes, lsi, loc, attn, grad_out, gv_acc, grad_loc, grad_attn, d, stream);
-  if (vdt == VNX_F16 && ldt == VNX_F16) return launch_bwd_generic<f16_t, f16_t, float>(value, shapes, lsi, loc, attn, grad_out, gv_acc, grad_loc, grad_attn, d, stream);
-  if (vdt == VNX_F16 && ldt == VNX_F32) return launch_bwd_generic<f16_t, float, float>(value, shapes, lsi, loc, attn, grad_out, gv_acc, grad_loc, grad_attn, d, stream);
+                          MsdaDims d, int only_if_not_packed, hipStream_t stream) {
+  if (vdt == VNX_F32) return launch_bwd_generic<float, float, float>(value, shapes, lsi, loc, attn, grad_out, gv_acc, grad_loc, grad_attn, d, only_if_not_packed, stream);
+  if (vdt == VNX_F64) return launch_bwd_generic<double, double, double>(value, shapes, lsi, loc, attn, grad_out, gv_acc, grad_loc, grad_attn, d, only_if_not_packed, stream);
+  if (vdt == VNX_BF16 && ldt == VNX_BF16) return launch_bwd_generic<bf16_t, bf16_t, float>(value, shapes, lsi, loc, attn, grad_out, gv_acc, grad_loc, grad_attn, d, only_if_not_packed, stream);
+  if (vdt == VNX_BF16 && ldt == VNX_F32) return launch_bwd_generic<bf16_t, float, float>(value, shapes, lsi, loc, attn, grad_out, gv_acc, grad_loc, grad_attn, d, only_if_not_packed, stream);
+  if (vdt == VNX_F16 && ldt == VNX_F16) return launch_bwd_generic<f16_t, f16_t, float>(value, shapes, lsi, loc, attn, grad_out, gv_acc, grad_loc, grad_attn, d, only_if_not_packed, stream);
+  if (vdt == VNX_F16 && ldt == VNX_F32) return launch_bwd_generic<f16_t, float, float>(value, shapes, lsi, loc, attn, grad_out, gv_acc, grad_loc, grad_attn, d, only_if_not_packed, stream);
   set_error("msda_backward: unsupported dtype pair (%d, %d)", vdt, ldt);
   return VNX_ERR_INVALID_ARGUMENT;
 }
 
-int convert_f32_to(int vdt, const void* src, void* dst, int64_t n, hipStream_t stream) {
-  if (vdt == VNX_BF16) return launch_convert<bf16_t>(src, dst, n, stream);
-  if (vdt == VNX_F16) return launch_convert<f16_t>(src, dst, n, stream);
+// shapes == nullptr: unconditional; otherwise only when the levels are not packed
+int convert_f32_to(int vdt, const void* src, void* dst, int64_t n, const int64_t* shapes,
+                   const int64_t* lsi, int L, int S, hipStream_t stream) {
+  if (vdt == VNX_BF16) return launch_convert<bf16_t>(src, dst, n, shapes, lsi, L, S, stream);
+  if (vdt == VNX_F16) return launch_convert<f16_t>(src, dst, n, shapes, lsi, L, S, stream);
   set_error("convert_f32_to: dtype %d is not 16-bit", vdt);
   return VNX_ERR_INVALID_ARGUMENT;
 }

@@ -43,6 +43,18 @@ template <> __device__ __forceinline__ f16_t from_acc<f16_t>(float x) { return f
 __device__ __forceinline__ void atomic_add(float* p, float v) { unsafeAtomicAdd(p, v); }
 __device__ __forceinline__ void atomic_add(double* p, double v) { unsafeAtomicAdd(p, v); }
 
+// True when the levels tile [0, S) back to back in order (level_start_index[l] is the
+// running sum of H*W and the total is spatial_size).
+__device__ __forceinline__ bool levels_packed(const int64_t* shapes, const int64_t* lsi, int L, int S) {
+  int64_t running = 0;
+  bool ok = true;
+  for (int l = 0; l < L; ++l) {
+    ok = ok && (lsi[l] == running);
+    running += shapes[2 * l] * shapes[2 * l + 1];
+  }
+  return ok && running == S;
+}
+
 __device__ __forceinline__ float floor_acc(float x) { return floorf(x); }
 __device__ __forceinline__ double floor_acc(double x) { return floor(x); }
 

@@ -99,7 +99,12 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
 
 
 def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
-                            grad_output, im2col_step):
+                            grad_output, im2col_step, levels_packed: bool = False):
+    """`levels_packed=True` (not in the reference signature; optional) promises
+    level_start_index is the running sum of H*W with total spatial_size -- what the
+    reference's transformer always builds -- and lets the library skip the
+    general-path launches.  Left False, the library checks the same thing on the
+    device and stays correct for any layout."""
     _check_inputs([("value", value), ("spatial_shapes", spatial_shapes),
                    ("level_start_index", level_start_index), ("sampling_loc", sampling_loc),
                    ("attn_weight", attn_weight), ("grad_output", grad_output)])
@@ -112,15 +117,16 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     grad_sampling_loc = torch.empty_like(sampling_loc)
     grad_attn_weight = torch.empty_like(attn_weight)
     l = _lib.lib()
-    ws_bytes = l.vnx_msda_backward_workspace_bytes(_DT[value.dtype], batch, spatial_size, num_heads,
-                                                   channels)
+    flags = _lib.MSDA_LEVELS_PACKED if levels_packed else 0
+    ws_bytes = l.vnx_msda_backward_workspace_bytes(_DT[value.dtype], _DT[sampling_loc.dtype], *dims,
+                                                   flags)
     workspace = torch.empty((ws_bytes,), dtype=torch.uint8, device=value.device) if ws_bytes else None
     with torch.cuda.device(value.device):
         st = l.vnx_msda_backward(
             _DT[value.dtype], _DT[sampling_loc.dtype], value.data_ptr(), spatial_shapes.data_ptr(),
             level_start_index.data_ptr(), sampling_loc.data_ptr(), attn_weight.data_ptr(),
             grad_output.data_ptr(), grad_value.data_ptr(), grad_sampling_loc.data_ptr(),
-            grad_attn_weight.data_ptr(), *dims,
+            grad_attn_weight.data_ptr(), *dims, flags,
             workspace.data_ptr() if workspace is not None else None, ws_bytes,
             _stream_ptr(value.device))
     _lib.check(st)

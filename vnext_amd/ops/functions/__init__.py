@@ -1,1 +1,1 @@
-from .ms_deform_attn_func import MSDeformAttnFunction, ms_deform_attn  # noqa: F401
+from .ms_deform_attn_func import MSDeformAttnFunction, mark_levels_packed, ms_deform_attn  # noqa: F401

@@ -25,6 +25,10 @@ class MSDeformAttnFunction(Function):
     def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations,
                 attention_weights, im2col_step):
         ctx.im2col_step = im2col_step
+        # Callers that built level_start_index as the running sum of H*W (every caller in
+        # the reference does) may tag the tensor; the backward then skips the general-path
+        # launches.  Untagged tensors stay correct: the library checks on the device.
+        ctx.levels_packed = bool(getattr(value_level_start_index, "_vnx_levels_packed", False))
         output = MSDA.ms_deform_attn_forward(
             value, value_spatial_shapes, value_level_start_index, sampling_locations,
             attention_weights, ctx.im2col_step)
@@ -38,8 +42,14 @@ class MSDeformAttnFunction(Function):
         value, shapes, level_start, sampling_locations, attention_weights = ctx.saved_tensors
         grad_value, grad_sampling_loc, grad_attn_weight = MSDA.ms_deform_attn_backward(
             value, shapes, level_start, sampling_locations, attention_weights,
-            grad_output.contiguous(), ctx.im2col_step)
+            grad_output.contiguous(), ctx.im2col_step, levels_packed=ctx.levels_packed)
         return grad_value, None, None, grad_sampling_loc, grad_attn_weight, None
+
+
+def mark_levels_packed(level_start_index):
+    """Tag a level_start_index tensor built as cumsum(H*W) (see MSDeformAttnFunction.forward)."""
+    level_start_index._vnx_levels_packed = True
+    return level_start_index
 
 
 def ms_deform_attn(value, value_spatial_shapes, value_level_start_index, sampling_locations,
