@@ -8,13 +8,19 @@
 // of 76 us under the T=5 decoder call (24.6 M dword atomics) -- 6x its HBM time.
 //
 // Here every row of grad_value has exactly one owner.  A workgroup ("unit") owns a
-// contiguous range of pixels of ONE level for one (batch, head), keeps that slab
-// [rows][32] in LDS (fp32), scans all samples of its level for that (batch, head),
-// and for each tap landing in its range adds w*attn*grad_out[q, head, :] into the
-// slab with LDS atomics (32 consecutive banks, conflict-free).  The slab is then
-// written once with 16-B stores: no zero-fill pass, no global atomic, no fp32
-// workspace / convert pass for 16-bit tensors, and the result does not depend on
-// the order workgroups run in.
+// contiguous range of pixels of ONE level for one (batch, head) and keeps that slab
+// [rows][32] in LDS (fp32).  It walks the queries in chunks:
+//   * the chunk's grad_out rows of this head go to LDS once (coalesced 16-B loads),
+//     and one thread per sample of the unit's level computes the bilinear geometry;
+//     samples with a tap inside the unit's range append a 24-B record
+//     {query slot | tap mask, first tap row, 4 weights*attn} to an LDS list;
+//   * half-waves then take records: 32 lanes = the 32 channels; one LDS read of the
+//     grad_out row, up to four ds_add_f32 into the slab (32 consecutive banks).
+//   * the next chunk's global loads are issued before the records are processed, so
+//     their latency hides behind the LDS work.
+// The slab is finally written once with 16-B stores: no zero-fill pass, no global
+// atomic, no fp32 workspace / convert pass for 16-bit tensors, and nothing depends
+// on the order workgroups run in.
 //
 // The unit table is derived ON DEVICE from spatial_shapes / level_start_index (the
 // ABI hands these over as device tensors, ms_deform_attn_cuda.cu:67-68): each level
@@ -24,17 +30,39 @@
 // previous H*W and their total == spatial_size), which is how the reference builds
 // them (deformable_transformer.py:97-106).  Every workgroup re-derives that
 // predicate; when it fails the kernel does nothing and the general path (atomics
-// into a zero-filled image) does the work -- see msda_backward in capi.hip.
+// into a zero-filled image) does the work -- see vnx_msda_backward in capi.hip.
 #include "vnx_common.h"
 
 namespace vnx {
 
 typedef float float4_t __attribute__((ext_vector_type(4)));
 typedef uint32_t uint2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t uint4_t __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float gv_to_float(float x) { return x; }
-__device__ __forceinline__ float gv_to_float(bf16_t x) { return to_acc(x); }
-__device__ __forceinline__ float gv_to_float(f16_t x) { return to_acc(x); }
+template <typename TV>
+__device__ __forceinline__ float4_t gv_load4(const TV* p);
+template <>
+__device__ __forceinline__ float4_t gv_load4<float>(const float* p) {
+  return *reinterpret_cast<const float4_t*>(p);
+}
+template <>
+__device__ __forceinline__ float4_t gv_load4<bf16_t>(const bf16_t* p) {
+  const uint2_t r = *reinterpret_cast<const uint2_t*>(p);
+  float4_t v;
+  v.x = __uint_as_float(r.x << 16); v.y = __uint_as_float(r.x & 0xffff0000u);
+  v.z = __uint_as_float(r.y << 16); v.w = __uint_as_float(r.y & 0xffff0000u);
+  return v;
+}
+template <>
+__device__ __forceinline__ float4_t gv_load4<f16_t>(const f16_t* p) {
+  const uint2_t r = *reinterpret_cast<const uint2_t*>(p);
+  float4_t v;
+  v.x = float(__builtin_bit_cast(_Float16, uint16_t(r.x & 0xffffu)));
+  v.y = float(__builtin_bit_cast(_Float16, uint16_t(r.x >> 16)));
+  v.z = float(__builtin_bit_cast(_Float16, uint16_t(r.y & 0xffffu)));
+  v.w = float(__builtin_bit_cast(_Float16, uint16_t(r.y >> 16)));
+  return v;
+}
 
 template <typename TV>
 __device__ __forceinline__ void gv_store4(TV* p, float4_t v);
@@ -57,23 +85,32 @@ __device__ __forceinline__ void gv_store4<f16_t>(f16_t* p, float4_t v) {
   *reinterpret_cast<uint2_t*>(p) = r;
 }
 
-constexpr int kRowBits = 10;  // slab rows per unit <= 1024
+constexpr int kGvWaves = 8;      // 512 threads
+constexpr int kGvThreads = 64 * kGvWaves;
+constexpr int kGvRowsMax = 384;  // 48 KiB slab
+constexpr int kGvQcMax = 128;    // queries per chunk (16 KiB of grad_out rows)
+constexpr int kGvSamplesMax = kGvThreads;  // one sample per thread per chunk
+// slab 48 K + rows 16 K + records 12 K + counters = 76 KiB + 16 B -> two units per CU
 
-template <typename TV, typename TL, int WAVES, int ROWS_MAX>
-__global__ void __launch_bounds__(64 * WAVES)
+// A record = {query slot in the chunk | tap mask << 16, first tap's row relative to the unit
+// (may be negative / beyond)} + 4 weights, kept as two arrays so both stay naturally aligned.
+
+template <typename TV, typename TL>
+__global__ void __launch_bounds__(kGvThreads)
 msda_bwd_gv_tile_kernel(const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
                         const TL* __restrict__ loc, const TL* __restrict__ attn,
                         const TV* __restrict__ grad_out, TV* __restrict__ grad_value, MsdaDims d,
-                        int units_min, int units_bound) {
-  static_assert(ROWS_MAX <= (1 << kRowBits), "row index must fit the record");
+                        int units_min, int units_bound, int qc) {
   constexpr int D = 32;
-  constexpr int kList = 256;  // taps one wave can emit per 64-sample step
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* slab = reinterpret_cast<float*>(smem);
-  uint2_t* lists = reinterpret_cast<uint2_t*>(smem + size_t(ROWS_MAX) * D * 4);
+  float* grows = slab + kGvRowsMax * D;                                   // [qc][32]
+  uint4_t* rec_w = reinterpret_cast<uint4_t*>(grows + kGvQcMax * D);      // [samples] 4 weights
+  uint2_t* rec_h = reinterpret_cast<uint2_t*>(rec_w + kGvSamplesMax);     // [samples] slot|mask, row
+  uint32_t* counters = reinterpret_cast<uint32_t*>(rec_h + kGvSamplesMax);  // [2]
 
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
   const int m = blockIdx.x % d.M;
   const int rest = blockIdx.x / d.M;
   const int unit = rest % units_bound;
@@ -91,7 +128,7 @@ msda_bwd_gv_tile_kernel(const int64_t* __restrict__ shapes, const int64_t* __res
       packed = packed && (lsi[l] == running);
       running += n;
       if (lvl < 0 && n > 0) {
-        int units = (n + ROWS_MAX - 1) / ROWS_MAX;
+        int units = (n + kGvRowsMax - 1) / kGvRowsMax;
         if (units < units_min) units = units_min;
         if (units > n) units = n;
         const int rows_per_unit = (n + units - 1) / units;
@@ -110,93 +147,124 @@ msda_bwd_gv_tile_kernel(const int64_t* __restrict__ shapes, const int64_t* __res
   }
   const int rows = r1 - r0;
 
-  // ---- zero the slab ------------------------------------------------------------------
-  for (int i = threadIdx.x; i < rows * (D / 4); i += 64 * WAVES)
+  // ---- zero the slab and the counters ------------------------------------------------
+  for (int i = tid; i < rows * (D / 4); i += kGvThreads)
     reinterpret_cast<float4_t*>(slab)[i] = float4_t{0.f, 0.f, 0.f, 0.f};
+  if (tid < 2) counters[tid] = 0;
   __syncthreads();
 
-  // ---- scan this level's samples of (b, m) ----------------------------------------------
-  uint2_t* list = lists + wave * kList;
   const int LP = d.L * d.P;
-  const int n_samples = d.Lq * d.P;
-  const int half = lane >> 5, c = lane & 31;
   const float Hf = float(Hl), Wf = float(Wl);
-  for (int base = wave * 64; base < n_samples; base += WAVES * 64) {
-    const int e = base + lane;
-    int rt[4] = {0, 0, 0, 0};
-    float wt[4] = {0.f, 0.f, 0.f, 0.f};
-    bool ok[4] = {false, false, false, false};
-    int q = 0;
-    if (e < n_samples) {
-      q = e / d.P;
-      const int k = e - q * d.P;
-      const int64_t wi = ((int64_t(b) * d.Lq + q) * d.M + m) * LP + lvl * d.P + k;
-      const float x = to_acc(loc[2 * wi]), y = to_acc(loc[2 * wi + 1]);
-      const float a = to_acc(attn[wi]);
-      const float h = y * Hf - 0.5f, w = x * Wf - 0.5f;
+  const int n_chunks = (d.Lq + qc - 1) / qc;
+  const int64_t row_stride = int64_t(d.M) * D;  // grad_out elements between queries
+  const TV* go_head = grad_out + (int64_t(b) * d.Lq * d.M + m) * D;
+
+  // this thread's sample in a chunk, and its two 16-B pieces of the chunk's grad_out rows
+  const int sq = tid / d.P, sk = tid - sq * d.P;         // query slot, point
+  const bool has_sample = sq < qc;
+  const int g0 = tid, g1 = tid + kGvThreads;             // float4 index in [qc][8]
+
+  // prefetch registers
+  float px = 0.f, py = 0.f, pa = 0.f;
+  float4_t pg0 = {0.f, 0.f, 0.f, 0.f}, pg1 = {0.f, 0.f, 0.f, 0.f};
+  auto prefetch = [&](int chunk) {
+    const int q_base = chunk * qc;
+    const int q = q_base + sq;
+    if (has_sample && q < d.Lq) {
+      const int64_t wi = ((int64_t(b) * d.Lq + q) * d.M + m) * LP + lvl * d.P + sk;
+      px = to_acc(loc[2 * wi]); py = to_acc(loc[2 * wi + 1]); pa = to_acc(attn[wi]);
+    } else {
+      px = -4.f; py = -4.f; pa = 0.f;  // fails the range test below
+    }
+    const int qa = q_base + (g0 >> 3), qb = q_base + (g1 >> 3);
+    if ((g0 >> 3) < qc && qa < d.Lq) pg0 = gv_load4<TV>(go_head + int64_t(qa) * row_stride + (g0 & 7) * 4);
+    if ((g1 >> 3) < qc && qb < d.Lq) pg1 = gv_load4<TV>(go_head + int64_t(qb) * row_stride + (g1 & 7) * 4);
+  };
+  prefetch(0);
+
+  for (int chunk = 0; chunk < n_chunks; ++chunk) {
+    uint32_t* counter = counters + (chunk & 1);
+    // ---- stage this chunk: grad_out rows -> LDS, geometry -> records -----------------------
+    if ((g0 >> 3) < qc) reinterpret_cast<float4_t*>(grows)[g0] = pg0;
+    if ((g1 >> 3) < qc) reinterpret_cast<float4_t*>(grows)[g1] = pg1;
+    {
+      const float h = py * Hf - 0.5f, w = px * Wf - 0.5f;
+      bool mine = false;
+      uint32_t mask = 0;
+      int row00 = 0;
+      float w0 = 0.f, w1 = 0.f, w2 = 0.f, w3 = 0.f;
       if (h > -1.f && w > -1.f && h < Hf && w < Wf) {
         const float hf = floorf(h), wf = floorf(w);
-        const int h0 = int(hf), w0 = int(wf);
+        const int h0 = int(hf), w0i = int(wf);
         const float lh = h - hf, lw = w - wf, hh = 1.f - lh, hw = 1.f - lw;
-        const bool top = h0 >= 0, bot = h0 + 1 <= Hl - 1, lef = w0 >= 0, rig = w0 + 1 <= Wl - 1;
-        const int p00 = h0 * Wl + w0;
-        rt[0] = p00; rt[1] = p00 + 1; rt[2] = p00 + Wl; rt[3] = p00 + Wl + 1;
-        wt[0] = a * (hh * hw); wt[1] = a * (hh * lw); wt[2] = a * (lh * hw); wt[3] = a * (lh * lw);
-        ok[0] = top && lef; ok[1] = top && rig; ok[2] = bot && lef; ok[3] = bot && rig;
+        const bool top = h0 >= 0, bot = h0 + 1 <= Hl - 1, lef = w0i >= 0, rig = w0i + 1 <= Wl - 1;
+        const int p00 = h0 * Wl + w0i;
+        const int pa_ = p00, pb_ = p00 + 1, pc_ = p00 + Wl, pd_ = p00 + Wl + 1;
+        mask = (uint32_t(top && lef && pa_ >= r0 && pa_ < r1)) |
+               (uint32_t(top && rig && pb_ >= r0 && pb_ < r1) << 1) |
+               (uint32_t(bot && lef && pc_ >= r0 && pc_ < r1) << 2) |
+               (uint32_t(bot && rig && pd_ >= r0 && pd_ < r1) << 3);
+        mine = mask != 0;
+        row00 = p00 - r0;
+        w0 = pa * (hh * hw); w1 = pa * (hh * lw); w2 = pa * (lh * hw); w3 = pa * (lh * lw);
+      }
+      const unsigned long long ballot = __ballot(mine);
+      if (ballot != 0) {
+        const int n_mine = __builtin_popcountll(ballot);
+        uint32_t base = 0;
+        if (lane == 0) base = __hip_atomic_fetch_add(counter, uint32_t(n_mine), __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_WORKGROUP);
+        base = uint32_t(__builtin_amdgcn_readfirstlane(int(base)));
+        if (mine) {
+          const uint32_t pos = base + __builtin_amdgcn_mbcnt_hi(uint32_t(ballot >> 32),
+                                                                __builtin_amdgcn_mbcnt_lo(uint32_t(ballot), 0));
+          rec_h[pos] = uint2_t{uint32_t(sq) | (mask << 16), uint32_t(row00)};
+          rec_w[pos] = uint4_t{__float_as_uint(w0), __float_as_uint(w1), __float_as_uint(w2),
+                               __float_as_uint(w3)};
+        }
       }
     }
-    // compact the taps that land in [r0, r1) into this wave's list
-    int cnt = 0;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const bool mine = ok[t] && rt[t] >= r0 && rt[t] < r1;
-      const unsigned long long mask = __ballot(mine);
-      const int pos = cnt + __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32),
-                                                      __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0));
-      if (mine) list[pos] = uint2_t{(uint32_t(q) << kRowBits) | uint32_t(rt[t] - r0), __float_as_uint(wt[t])};
-      cnt += __builtin_popcountll(mask);
+    // ---- next chunk's loads go out now; they land while the records are processed -----------
+    if (chunk + 1 < n_chunks) prefetch(chunk + 1);
+    __syncthreads();
+    const int n_rec = int(*counter);
+    if (tid == 0) counters[(chunk + 1) & 1] = 0;
+
+    // ---- half-waves take records; 32 lanes = the 32 channels of the rows -----------------
+    const int hw_id = tid >> 5, c = tid & 31;
+    constexpr int kHalfWaves = kGvThreads / 32;
+    for (int i = hw_id; i < n_rec; i += 2 * kHalfWaves) {
+      // two records in flight per half-wave
+      const int i2 = i + kHalfWaves;
+      const bool second = i2 < n_rec;
+      const int ib = second ? i2 : i;
+      const uint2_t ha = rec_h[i], hb = rec_h[ib];
+      const uint4_t wa = rec_w[i], wb = rec_w[ib];
+      const float ga = grows[(ha.x & 0xffffu) * D + c];
+      const float gb = grows[(hb.x & 0xffffu) * D + c];
+      float* sa = slab + int(ha.y) * D + c;
+      float* sb = slab + int(hb.y) * D + c;
+      const uint32_t ma = ha.x >> 16, mb = second ? hb.x >> 16 : 0u;
+      if (ma & 1u) unsafeAtomicAdd(sa, __uint_as_float(wa.x) * ga);
+      if (ma & 2u) unsafeAtomicAdd(sa + D, __uint_as_float(wa.y) * ga);
+      if (ma & 4u) unsafeAtomicAdd(sa + Wl * D, __uint_as_float(wa.z) * ga);
+      if (ma & 8u) unsafeAtomicAdd(sa + (Wl + 1) * D, __uint_as_float(wa.w) * ga);
+      if (mb & 1u) unsafeAtomicAdd(sb, __uint_as_float(wb.x) * gb);
+      if (mb & 2u) unsafeAtomicAdd(sb + D, __uint_as_float(wb.y) * gb);
+      if (mb & 4u) unsafeAtomicAdd(sb + Wl * D, __uint_as_float(wb.z) * gb);
+      if (mb & 8u) unsafeAtomicAdd(sb + (Wl + 1) * D, __uint_as_float(wb.w) * gb);
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // two taps per step (one per half-wave); 32 lanes = the 32 channels of the tap's row
-    const int64_t go_base = (int64_t(b) * d.Lq * d.M + m) * D + c;
-    constexpr int UN = 4;
-    for (int i = 0; i < cnt; i += 2 * UN) {
-      uint2_t rec[UN];
-      float g[UN];
-#pragma unroll
-      for (int j = 0; j < UN; ++j) {
-        const int idx = i + 2 * j + half;
-        rec[j] = idx < cnt ? list[idx] : uint2_t{0u, 0u};
-      }
-#pragma unroll
-      for (int j = 0; j < UN; ++j) {
-        const int idx = i + 2 * j + half;
-        g[j] = idx < cnt ? gv_to_float(grad_out[go_base + int64_t(rec[j].x >> kRowBits) * d.M * D]) : 0.f;
-      }
-#pragma unroll
-      for (int j = 0; j < UN; ++j) {
-        const int idx = i + 2 * j + half;
-        if (idx < cnt)
-          unsafeAtomicAdd(&slab[(rec[j].x & ((1u << kRowBits) - 1u)) * D + c], __uint_as_float(rec[j].y) * g[j]);
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
   }
-  __syncthreads();
 
   // ---- write the slab: one owner per row, 16 B per lane, whole 128-B lines -----------------
   TV* out = grad_value + ((int64_t(b) * d.S + start + r0) * d.M + m) * D;
-  for (int i = threadIdx.x; i < rows * (D / 4); i += 64 * WAVES) {
+  for (int i = tid; i < rows * (D / 4); i += kGvThreads) {
     const int row = i >> 3, ch4 = i & 7;
     const float4_t v = reinterpret_cast<const float4_t*>(slab)[i];
     gv_store4<TV>(out + int64_t(row) * d.M * D + ch4 * 4, v);
   }
 }
-
-constexpr int kGvWaves = 8;
-constexpr int kGvRowsMax = 480;  // 60 KiB slab + 16 KiB lists = 76 KiB -> two units per CU
 
 int msda_gv_units_bound(const MsdaDims& d, int units_min) {
   return d.L * (units_min + 1) + (d.S + kGvRowsMax - 1) / kGvRowsMax;
@@ -205,7 +273,7 @@ int msda_gv_units_bound(const MsdaDims& d, int units_min) {
 bool msda_d32_gv_supported(int vdt, int ldt, const MsdaDims& d) {
   if (d.D != 32 || vdt == VNX_F64) return false;
   if (vdt == VNX_F32 && ldt != VNX_F32) return false;
-  if (d.Lq >= (1 << (32 - kRowBits))) return false;  // query index shares a word with the row
+  if (d.P > 64) return false;  // a chunk holds at least 8 queries x P samples, one per thread
   const int64_t blocks = int64_t(d.B) * d.M * msda_gv_units_bound(d, 16);
   return blocks < (int64_t(1) << 31);
 }
@@ -216,10 +284,12 @@ static int launch_gv(const int64_t* shapes, const int64_t* lsi, const void* loc,
                      hipStream_t stream) {
   const int units_bound = msda_gv_units_bound(d, units_min);
   const int64_t blocks = int64_t(d.B) * d.M * units_bound;
-  const size_t lds = size_t(kGvRowsMax) * 32 * 4 + size_t(kGvWaves) * 256 * 8;
-  hipLaunchKernelGGL((msda_bwd_gv_tile_kernel<TV, TL, kGvWaves, kGvRowsMax>), dim3(uint32_t(blocks)),
-                     dim3(64 * kGvWaves), lds, stream, shapes, lsi, (const TL*)loc, (const TL*)attn,
-                     (const TV*)grad_out, (TV*)grad_value, d, units_min, units_bound);
+  int qc = kGvSamplesMax / d.P;
+  if (qc > kGvQcMax) qc = kGvQcMax;
+  const size_t lds = size_t(kGvRowsMax) * 128 + size_t(kGvQcMax) * 128 + size_t(kGvSamplesMax) * 24 + 16;
+  hipLaunchKernelGGL((msda_bwd_gv_tile_kernel<TV, TL>), dim3(uint32_t(blocks)), dim3(kGvThreads), lds,
+                     stream, shapes, lsi, (const TL*)loc, (const TL*)attn, (const TV*)grad_out,
+                     (TV*)grad_value, d, units_min, units_bound, qc);
   return check_launch("msda_bwd_gv_tile");
 }
 
