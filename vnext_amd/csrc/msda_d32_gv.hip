@@ -12,10 +12,14 @@
 // [rows][32] in LDS (fp32).  It walks the queries in chunks:
 //   * the chunk's grad_out rows of this head go to LDS once (coalesced 16-B loads),
 //     and one thread per sample of the unit's level computes the bilinear geometry;
-//     samples with a tap inside the unit's range append a 24-B record
-//     {query slot | tap mask, first tap row, 4 weights*attn} to an LDS list;
-//   * half-waves then take records: 32 lanes = the 32 channels; one LDS read of the
-//     grad_out row, up to four ds_add_f32 into the slab (32 consecutive banks).
+//     every tap that lands inside the unit's range becomes an 8-B record
+//     {query slot | row, weight*attn}, counting-sorted in LDS by the row's owner
+//     (row % 16 -> one of the 16 half-waves; integer LDS atomics only);
+//   * each half-wave applies its own taps: 32 lanes = the 32 channels, one LDS read
+//     of the grad_out row, one plain read-add-write of the slab row.  No floating
+//     point atomics anywhere: ds_add_f32 measures ~170 clk per wave instruction on
+//     gfx950 (tools/lds_atomic_bench.hip), slower than the global atomics it was
+//     meant to replace.
 //   * the next chunk's global loads are issued before the records are processed, so
 //     their latency hides behind the LDS work.
 // The slab is finally written once with 16-B stores: no zero-fill pass, no global
@@ -87,13 +91,15 @@ __device__ __forceinline__ void gv_store4<f16_t>(f16_t* p, float4_t v) {
 
 constexpr int kGvWaves = 8;      // 512 threads
 constexpr int kGvThreads = 64 * kGvWaves;
-constexpr int kGvRowsMax = 384;  // 48 KiB slab
+constexpr int kGvOwners = kGvThreads / 32;  // one row owner per half-wave
+constexpr int kGvRowsMax = 352;  // 44 KiB slab
 constexpr int kGvQcMax = 128;    // queries per chunk (16 KiB of grad_out rows)
 constexpr int kGvSamplesMax = kGvThreads;  // one sample per thread per chunk
-// slab 48 K + rows 16 K + records 12 K + counters = 76 KiB + 16 B -> two units per CU
+// slab 44 K + rows 16 K + tap list 16 K + counters 128 B = 76.1 KiB -> two units per CU
 
-// A record = {query slot in the chunk | tap mask << 16, first tap's row relative to the unit
-// (may be negative / beyond)} + 4 weights, kept as two arrays so both stay naturally aligned.
+// A tap record = {query slot in the chunk << 16 | row relative to the unit, weight*attn}.
+// Row r of the slab belongs to half-wave r % 16: taps are counting-sorted by owner each
+// chunk, so the accumulation needs no atomics at all.
 
 template <typename TV, typename TL>
 __global__ void __launch_bounds__(kGvThreads)
@@ -105,12 +111,10 @@ msda_bwd_gv_tile_kernel(const int64_t* __restrict__ shapes, const int64_t* __res
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* slab = reinterpret_cast<float*>(smem);
   float* grows = slab + kGvRowsMax * D;                                   // [qc][32]
-  uint4_t* rec_w = reinterpret_cast<uint4_t*>(grows + kGvQcMax * D);      // [samples] 4 weights
-  uint2_t* rec_h = reinterpret_cast<uint2_t*>(rec_w + kGvSamplesMax);     // [samples] slot|mask, row
-  uint32_t* counters = reinterpret_cast<uint32_t*>(rec_h + kGvSamplesMax);  // [2]
+  uint2_t* list = reinterpret_cast<uint2_t*>(grows + kGvQcMax * D);       // [4*samples] taps
+  uint32_t* counters = reinterpret_cast<uint32_t*>(list + 4 * kGvSamplesMax);  // [2][owners]
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63;
   const int m = blockIdx.x % d.M;
   const int rest = blockIdx.x / d.M;
   const int unit = rest % units_bound;
@@ -150,7 +154,7 @@ msda_bwd_gv_tile_kernel(const int64_t* __restrict__ shapes, const int64_t* __res
   // ---- zero the slab and the counters ------------------------------------------------
   for (int i = tid; i < rows * (D / 4); i += kGvThreads)
     reinterpret_cast<float4_t*>(slab)[i] = float4_t{0.f, 0.f, 0.f, 0.f};
-  if (tid < 2) counters[tid] = 0;
+  if (tid < 2 * kGvOwners) counters[tid] = 0;
   __syncthreads();
 
   const int LP = d.L * d.P;
@@ -182,17 +186,18 @@ msda_bwd_gv_tile_kernel(const int64_t* __restrict__ shapes, const int64_t* __res
   };
   prefetch(0);
 
+  const int hw_id = tid >> 5, c = tid & 31;  // owner id of this half-wave, channel
   for (int chunk = 0; chunk < n_chunks; ++chunk) {
-    uint32_t* counter = counters + (chunk & 1);
-    // ---- stage this chunk: grad_out rows -> LDS, geometry -> records -----------------------
+    uint32_t* cnt = counters + (chunk & 1) * kGvOwners;
+    // ---- stage this chunk: grad_out rows -> LDS; geometry; rank every in-range tap -----------
     if ((g0 >> 3) < qc) reinterpret_cast<float4_t*>(grows)[g0] = pg0;
     if ((g1 >> 3) < qc) reinterpret_cast<float4_t*>(grows)[g1] = pg1;
+    uint32_t mask = 0;
+    int row00 = 0;
+    float wt[4] = {0.f, 0.f, 0.f, 0.f};
+    uint32_t rank[4] = {0u, 0u, 0u, 0u};
     {
       const float h = py * Hf - 0.5f, w = px * Wf - 0.5f;
-      bool mine = false;
-      uint32_t mask = 0;
-      int row00 = 0;
-      float w0 = 0.f, w1 = 0.f, w2 = 0.f, w3 = 0.f;
       if (h > -1.f && w > -1.f && h < Hf && w < Wf) {
         const float hf = floorf(h), wf = floorf(w);
         const int h0 = int(hf), w0i = int(wf);
@@ -204,55 +209,57 @@ msda_bwd_gv_tile_kernel(const int64_t* __restrict__ shapes, const int64_t* __res
                (uint32_t(top && rig && pb_ >= r0 && pb_ < r1) << 1) |
                (uint32_t(bot && lef && pc_ >= r0 && pc_ < r1) << 2) |
                (uint32_t(bot && rig && pd_ >= r0 && pd_ < r1) << 3);
-        mine = mask != 0;
         row00 = p00 - r0;
-        w0 = pa * (hh * hw); w1 = pa * (hh * lw); w2 = pa * (lh * hw); w3 = pa * (lh * lw);
+        wt[0] = pa * (hh * hw); wt[1] = pa * (hh * lw); wt[2] = pa * (lh * hw); wt[3] = pa * (lh * lw);
       }
-      const unsigned long long ballot = __ballot(mine);
-      if (ballot != 0) {
-        const int n_mine = __builtin_popcountll(ballot);
-        uint32_t base = 0;
-        if (lane == 0) base = __hip_atomic_fetch_add(counter, uint32_t(n_mine), __ATOMIC_RELAXED,
-                                                     __HIP_MEMORY_SCOPE_WORKGROUP);
-        base = uint32_t(__builtin_amdgcn_readfirstlane(int(base)));
-        if (mine) {
-          const uint32_t pos = base + __builtin_amdgcn_mbcnt_hi(uint32_t(ballot >> 32),
-                                                                __builtin_amdgcn_mbcnt_lo(uint32_t(ballot), 0));
-          rec_h[pos] = uint2_t{uint32_t(sq) | (mask << 16), uint32_t(row00)};
-          rec_w[pos] = uint4_t{__float_as_uint(w0), __float_as_uint(w1), __float_as_uint(w2),
-                               __float_as_uint(w3)};
-        }
-      }
+      const int dr[4] = {0, 1, Wl, Wl + 1};
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (mask & (1u << t))  // integer LDS atomics are fast (tools/lds_atomic_bench.hip)
+          rank[t] = __hip_atomic_fetch_add(cnt + ((row00 + dr[t]) & (kGvOwners - 1)), 1u,
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-    // ---- next chunk's loads go out now; they land while the records are processed -----------
+    // ---- next chunk's loads go out now; they land while the taps are applied ----------------
     if (chunk + 1 < n_chunks) prefetch(chunk + 1);
     __syncthreads();
-    const int n_rec = int(*counter);
-    if (tid == 0) counters[(chunk + 1) & 1] = 0;
+    // ---- scatter the taps into per-owner segments of one list (counting sort) --------------
+    {
+      uint32_t run = 0, mine_off = 0, mine_cnt = 0;
+      uint32_t seg[4] = {0u, 0u, 0u, 0u};
+      const int dr[4] = {0, 1, Wl, Wl + 1};
+      int own[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) own[t] = (row00 + dr[t]) & (kGvOwners - 1);
+#pragma unroll
+      for (int o = 0; o < kGvOwners; ++o) {
+        const uint32_t n = cnt[o];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) seg[t] = own[t] == o ? run : seg[t];
+        if (o == hw_id) { mine_off = run; mine_cnt = n; }
+        run += n;
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (mask & (1u << t))
+          list[seg[t] + rank[t]] = uint2_t{(uint32_t(sq) << 16) | uint32_t(row00 + dr[t]), __float_as_uint(wt[t])};
+      __syncthreads();
+      if (tid < kGvOwners) counters[((chunk + 1) & 1) * kGvOwners + tid] = 0;
 
-    // ---- half-waves take records; 32 lanes = the 32 channels of the rows -----------------
-    const int hw_id = tid >> 5, c = tid & 31;
-    constexpr int kHalfWaves = kGvThreads / 32;
-    for (int i = hw_id; i < n_rec; i += 2 * kHalfWaves) {
-      // two records in flight per half-wave
-      const int i2 = i + kHalfWaves;
-      const bool second = i2 < n_rec;
-      const int ib = second ? i2 : i;
-      const uint2_t ha = rec_h[i], hb = rec_h[ib];
-      const uint4_t wa = rec_w[i], wb = rec_w[ib];
-      const float ga = grows[(ha.x & 0xffffu) * D + c];
-      const float gb = grows[(hb.x & 0xffffu) * D + c];
-      float* sa = slab + int(ha.y) * D + c;
-      float* sb = slab + int(hb.y) * D + c;
-      const uint32_t ma = ha.x >> 16, mb = second ? hb.x >> 16 : 0u;
-      if (ma & 1u) unsafeAtomicAdd(sa, __uint_as_float(wa.x) * ga);
-      if (ma & 2u) unsafeAtomicAdd(sa + D, __uint_as_float(wa.y) * ga);
-      if (ma & 4u) unsafeAtomicAdd(sa + Wl * D, __uint_as_float(wa.z) * ga);
-      if (ma & 8u) unsafeAtomicAdd(sa + (Wl + 1) * D, __uint_as_float(wa.w) * ga);
-      if (mb & 1u) unsafeAtomicAdd(sb, __uint_as_float(wb.x) * gb);
-      if (mb & 2u) unsafeAtomicAdd(sb + D, __uint_as_float(wb.y) * gb);
-      if (mb & 4u) unsafeAtomicAdd(sb + Wl * D, __uint_as_float(wb.z) * gb);
-      if (mb & 8u) unsafeAtomicAdd(sb + (Wl + 1) * D, __uint_as_float(wb.w) * gb);
+      // ---- each half-wave applies the taps of the rows it owns: plain read-add-write ------
+      // (ds_add_f32 costs ~170 clk per wave instruction on gfx950, ~9x a read+write pair).
+      const uint2_t* my = list + mine_off;
+      uint2_t rec = mine_cnt > 0 ? my[0] : uint2_t{0u, 0u};
+      float g = grows[(rec.x >> 16) * D + c];
+      for (uint32_t i = 0; i < mine_cnt; ++i) {
+        const uint2_t cur = rec;
+        const float gc = g;
+        if (i + 1 < mine_cnt) {  // next record's operands while this one is applied
+          rec = my[i + 1];
+          g = grows[(rec.x >> 16) * D + c];
+        }
+        float* p = slab + (cur.x & 0xffffu) * D + c;
+        *p += __uint_as_float(cur.y) * gc;
+      }
     }
     __syncthreads();
   }
@@ -286,7 +293,8 @@ static int launch_gv(const int64_t* shapes, const int64_t* lsi, const void* loc,
   const int64_t blocks = int64_t(d.B) * d.M * units_bound;
   int qc = kGvSamplesMax / d.P;
   if (qc > kGvQcMax) qc = kGvQcMax;
-  const size_t lds = size_t(kGvRowsMax) * 128 + size_t(kGvQcMax) * 128 + size_t(kGvSamplesMax) * 24 + 16;
+  const size_t lds = size_t(kGvRowsMax) * 128 + size_t(kGvQcMax) * 128 + size_t(kGvSamplesMax) * 32 +
+                     2 * kGvOwners * 4;
   hipLaunchKernelGGL((msda_bwd_gv_tile_kernel<TV, TL>), dim3(uint32_t(blocks)), dim3(kGvThreads), lds,
                      stream, shapes, lsi, (const TL*)loc, (const TL*)attn, (const TV*)grad_out,
                      (TV*)grad_value, d, units_min, units_bound, qc);
