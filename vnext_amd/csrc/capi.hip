@@ -183,7 +183,7 @@ int vnx_msda_backward(int value_dtype, int loc_dtype, const void* value,
     // (3) unless the caller promised packed levels: the general path, each kernel of which
     //     does nothing on the device when the levels ARE packed.  No host sync either way.
     const bool only_gl = variant >= 100 && variant < 200;  // timing ablations
-    const bool only_gv = variant == 400;
+    const bool only_gv = variant >= 400 && variant < 500;
     if (!only_gv) {
       st = msda_backward_d32(value_dtype, loc_dtype, value, spatial_shapes, level_start_index,
                              sampling_loc, attn_weight, grad_output, nullptr, grad_sampling_loc,

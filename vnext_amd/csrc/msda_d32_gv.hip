@@ -6,22 +6,24 @@
 // ~322 G dwords/s chip-wide whatever the address pattern or working set
 // (tools/atomic_bench.hip; one dword per clock per L2 channel), which puts a floor
 // of 76 us under the T=5 decoder call (24.6 M dword atomics) -- 6x its HBM time.
+// LDS fp32 atomics are no way out either: ds_add_f32 measures ~170 clk per wave
+// instruction (tools/lds_atomic_bench.hip), an order of magnitude slower than an LDS
+// read + write pair.  So this kernel uses no floating-point atomics at all.
 //
-// Here every row of grad_value has exactly one owner.  A workgroup ("unit") owns a
+// Every row of grad_value has exactly one owner.  A workgroup ("unit") owns a
 // contiguous range of pixels of ONE level for one (batch, head) and keeps that slab
 // [rows][32] in LDS (fp32).  It walks the queries in chunks:
 //   * the chunk's grad_out rows of this head go to LDS once (coalesced 16-B loads),
 //     and one thread per sample of the unit's level computes the bilinear geometry;
-//     every tap that lands inside the unit's range becomes an 8-B record
-//     {query slot | row, weight*attn}, counting-sorted in LDS by the row's owner
-//     (row % 16 -> one of the 16 half-waves; integer LDS atomics only);
-//   * each half-wave applies its own taps: 32 lanes = the 32 channels, one LDS read
-//     of the grad_out row, one plain read-add-write of the slab row.  No floating
-//     point atomics anywhere: ds_add_f32 measures ~170 clk per wave instruction on
-//     gfx950 (tools/lds_atomic_bench.hip), slower than the global atomics it was
-//     meant to replace.
-//   * the next chunk's global loads are issued before the records are processed, so
-//     their latency hides behind the LDS work.
+//   * the taps that land inside the unit's range are counting-sorted by destination
+//     row: an integer LDS atomic gives each tap its rank inside its row, a block scan
+//     turns the row counts into segment offsets, each tap record {query slot,
+//     weight*attn} is written to its slot;
+//   * 8-lane groups (16 B per lane = one 32-channel row) then own rows: a row's
+//     segment is summed in registers -- the only serial chain is the FMA -- and added
+//     to the slab row once;
+//   * the next chunk's global loads are issued before the sort, so their latency
+//     hides behind the LDS work.
 // The slab is finally written once with 16-B stores: no zero-fill pass, no global
 // atomic, no fp32 workspace / convert pass for 16-bit tensors, and nothing depends
 // on the order workgroups run in.
@@ -41,7 +43,6 @@ namespace vnx {
 
 typedef float float4_t __attribute__((ext_vector_type(4)));
 typedef uint32_t uint2_t __attribute__((ext_vector_type(2)));
-typedef uint32_t uint4_t __attribute__((ext_vector_type(4)));
 
 template <typename TV>
 __device__ __forceinline__ float4_t gv_load4(const TV* p);
@@ -91,45 +92,74 @@ __device__ __forceinline__ void gv_store4<f16_t>(f16_t* p, float4_t v) {
 
 constexpr int kGvWaves = 8;      // 512 threads
 constexpr int kGvThreads = 64 * kGvWaves;
-constexpr int kGvOwners = kGvThreads / 32;  // one row owner per half-wave
+constexpr int kGvGroups = kGvThreads / 8;  // 8-lane groups
 constexpr int kGvRowsMax = 352;  // 44 KiB slab
 constexpr int kGvQcMax = 128;    // queries per chunk (16 KiB of grad_out rows)
 constexpr int kGvSamplesMax = kGvThreads;  // one sample per thread per chunk
-// slab 44 K + rows 16 K + tap list 16 K + counters 128 B = 76.1 KiB -> two units per CU
-
-// A tap record = {query slot in the chunk << 16 | row relative to the unit, weight*attn}.
-// Row r of the slab belongs to half-wave r % 16: taps are counting-sorted by owner each
-// chunk, so the accumulation needs no atomics at all.
+constexpr int kGvLevelsMax = 64;
+// slab 44 K + rows 16 K + tap list 16 K + 2 x 352 counters/offsets + level table ~ 79.6 KiB
+// -> two units per CU.
+constexpr size_t kGvLdsBytes = size_t(kGvRowsMax) * 128 + size_t(kGvQcMax) * 128 +
+                               size_t(kGvSamplesMax) * 32 + size_t(kGvRowsMax) * 8 + kGvWaves * 4 +
+                               3 * kGvLevelsMax * 4;
 
 template <typename TV, typename TL>
 __global__ void __launch_bounds__(kGvThreads)
 msda_bwd_gv_tile_kernel(const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
                         const TL* __restrict__ loc, const TL* __restrict__ attn,
                         const TV* __restrict__ grad_out, TV* __restrict__ grad_value, MsdaDims d,
-                        int units_min, int units_bound, int qc) {
+                        int units_min, int units_bound, int qc, int ablate) {
   constexpr int D = 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* slab = reinterpret_cast<float*>(smem);
   float* grows = slab + kGvRowsMax * D;                                   // [qc][32]
   uint2_t* list = reinterpret_cast<uint2_t*>(grows + kGvQcMax * D);       // [4*samples] taps
-  uint32_t* counters = reinterpret_cast<uint32_t*>(list + 4 * kGvSamplesMax);  // [2][owners]
+  uint32_t* cnt = reinterpret_cast<uint32_t*>(list + 4 * kGvSamplesMax);  // [rows] taps per row
+  uint32_t* offs = cnt + kGvRowsMax;                                      // [rows] segment starts
+  uint32_t* wtot = offs + kGvRowsMax;                                     // [waves]
+  int* meta = reinterpret_cast<int*>(wtot + kGvWaves);                    // [3*L] H, W, start
 
   const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
   const int m = blockIdx.x % d.M;
   const int rest = blockIdx.x / d.M;
   const int unit = rest % units_bound;
   const int b = rest / units_bound;
 
-  // ---- which (level, pixel range) is this unit? (all scalar) -----------------------
+  const int64_t row_stride = int64_t(d.M) * D;  // grad_out elements between queries
+  const TV* go_head = grad_out + (int64_t(b) * d.Lq * d.M + m) * D;
+  const int g0 = tid, g1 = tid + kGvThreads;    // this thread's float4 slots in [qc][8]
+
+  // chunk 0's grad_out rows do not depend on the unit: request them before anything else
+  float4_t pg0 = {0.f, 0.f, 0.f, 0.f}, pg1 = {0.f, 0.f, 0.f, 0.f};
+  auto prefetch_rows = [&](int chunk) {
+    const int q_base = chunk * qc;
+    const int qa = q_base + (g0 >> 3), qb = q_base + (g1 >> 3);
+    if ((g0 >> 3) < qc && qa < d.Lq) pg0 = gv_load4<TV>(go_head + int64_t(qa) * row_stride + (g0 & 7) * 4);
+    if ((g1 >> 3) < qc && qb < d.Lq) pg1 = gv_load4<TV>(go_head + int64_t(qb) * row_stride + (g1 & 7) * 4);
+  };
+  prefetch_rows(0);
+
+  // ---- level table: one round of vector loads, shared through LDS -------------------------
+  if (tid < d.L) {
+    meta[3 * tid] = int(shapes[2 * tid]);
+    meta[3 * tid + 1] = int(shapes[2 * tid + 1]);
+    meta[3 * tid + 2] = int(lsi[tid]);
+  }
+  for (int i = tid; i < kGvRowsMax; i += kGvThreads) cnt[i] = 0;
+  __syncthreads();
+
+  // ---- which (level, pixel range) is this unit? ------------------------------------------------
   int lvl = -1, r0 = 0, r1 = 0, Hl = 0, Wl = 0, start = 0;
   {
-    int64_t running = 0;
+    int running = 0;
     bool packed = true;
     int u = unit;
     for (int l = 0; l < d.L; ++l) {
-      const int H = int(shapes[2 * l]), W = int(shapes[2 * l + 1]);
+      const int H = meta[3 * l], W = meta[3 * l + 1], st = meta[3 * l + 2];
       const int n = H * W;
-      packed = packed && (lsi[l] == running);
+      packed = packed && (st == running);
       running += n;
       if (lvl < 0 && n > 0) {
         int units = (n + kGvRowsMax - 1) / kGvRowsMax;
@@ -138,7 +168,7 @@ msda_bwd_gv_tile_kernel(const int64_t* __restrict__ shapes, const int64_t* __res
         const int rows_per_unit = (n + units - 1) / units;
         units = (n + rows_per_unit - 1) / rows_per_unit;
         if (u < units) {
-          lvl = l; Hl = H; Wl = W; start = int(lsi[l]);
+          lvl = l; Hl = H; Wl = W; start = st;
           r0 = u * rows_per_unit;
           r1 = r0 + rows_per_unit < n ? r0 + rows_per_unit : n;
         } else {
@@ -147,55 +177,39 @@ msda_bwd_gv_tile_kernel(const int64_t* __restrict__ shapes, const int64_t* __res
       }
     }
     packed = packed && (running == d.S);
-    if (!packed || lvl < 0) return;
+    if (!packed || lvl < 0) return;  // uniform over the workgroup
   }
   const int rows = r1 - r0;
-
-  // ---- zero the slab and the counters ------------------------------------------------
   for (int i = tid; i < rows * (D / 4); i += kGvThreads)
     reinterpret_cast<float4_t*>(slab)[i] = float4_t{0.f, 0.f, 0.f, 0.f};
-  if (tid < 2 * kGvOwners) counters[tid] = 0;
-  __syncthreads();
 
   const int LP = d.L * d.P;
   const float Hf = float(Hl), Wf = float(Wl);
   const int n_chunks = (d.Lq + qc - 1) / qc;
-  const int64_t row_stride = int64_t(d.M) * D;  // grad_out elements between queries
-  const TV* go_head = grad_out + (int64_t(b) * d.Lq * d.M + m) * D;
-
-  // this thread's sample in a chunk, and its two 16-B pieces of the chunk's grad_out rows
-  const int sq = tid / d.P, sk = tid - sq * d.P;         // query slot, point
+  const int sq = tid / d.P, sk = tid - sq * d.P;  // this thread's sample: query slot, point
   const bool has_sample = sq < qc;
-  const int g0 = tid, g1 = tid + kGvThreads;             // float4 index in [qc][8]
-
-  // prefetch registers
   float px = 0.f, py = 0.f, pa = 0.f;
-  float4_t pg0 = {0.f, 0.f, 0.f, 0.f}, pg1 = {0.f, 0.f, 0.f, 0.f};
-  auto prefetch = [&](int chunk) {
-    const int q_base = chunk * qc;
-    const int q = q_base + sq;
+  auto prefetch_sample = [&](int chunk) {
+    const int q = chunk * qc + sq;
     if (has_sample && q < d.Lq) {
       const int64_t wi = ((int64_t(b) * d.Lq + q) * d.M + m) * LP + lvl * d.P + sk;
       px = to_acc(loc[2 * wi]); py = to_acc(loc[2 * wi + 1]); pa = to_acc(attn[wi]);
     } else {
       px = -4.f; py = -4.f; pa = 0.f;  // fails the range test below
     }
-    const int qa = q_base + (g0 >> 3), qb = q_base + (g1 >> 3);
-    if ((g0 >> 3) < qc && qa < d.Lq) pg0 = gv_load4<TV>(go_head + int64_t(qa) * row_stride + (g0 & 7) * 4);
-    if ((g1 >> 3) < qc && qb < d.Lq) pg1 = gv_load4<TV>(go_head + int64_t(qb) * row_stride + (g1 & 7) * 4);
   };
-  prefetch(0);
+  prefetch_sample(0);
 
-  const int hw_id = tid >> 5, c = tid & 31;  // owner id of this half-wave, channel
+  const int grp = tid >> 3, ch4 = tid & 7;
   for (int chunk = 0; chunk < n_chunks; ++chunk) {
-    uint32_t* cnt = counters + (chunk & 1) * kGvOwners;
-    // ---- stage this chunk: grad_out rows -> LDS; geometry; rank every in-range tap -----------
+    // ---- stage the chunk: grad_out rows -> LDS; geometry; rank each tap inside its row -------
     if ((g0 >> 3) < qc) reinterpret_cast<float4_t*>(grows)[g0] = pg0;
     if ((g1 >> 3) < qc) reinterpret_cast<float4_t*>(grows)[g1] = pg1;
     uint32_t mask = 0;
     int row00 = 0;
     float wt[4] = {0.f, 0.f, 0.f, 0.f};
     uint32_t rank[4] = {0u, 0u, 0u, 0u};
+    const int dr[4] = {0, 1, Wl, Wl + 1};
     {
       const float h = py * Hf - 0.5f, w = px * Wf - 0.5f;
       if (h > -1.f && w > -1.f && h < Hf && w < Wf) {
@@ -209,67 +223,72 @@ msda_bwd_gv_tile_kernel(const int64_t* __restrict__ shapes, const int64_t* __res
                (uint32_t(top && rig && pb_ >= r0 && pb_ < r1) << 1) |
                (uint32_t(bot && lef && pc_ >= r0 && pc_ < r1) << 2) |
                (uint32_t(bot && rig && pd_ >= r0 && pd_ < r1) << 3);
+        if (ablate == 2) mask = 0;
         row00 = p00 - r0;
         wt[0] = pa * (hh * hw); wt[1] = pa * (hh * lw); wt[2] = pa * (lh * hw); wt[3] = pa * (lh * lw);
       }
-      const int dr[4] = {0, 1, Wl, Wl + 1};
 #pragma unroll
       for (int t = 0; t < 4; ++t)
         if (mask & (1u << t))  // integer LDS atomics are fast (tools/lds_atomic_bench.hip)
-          rank[t] = __hip_atomic_fetch_add(cnt + ((row00 + dr[t]) & (kGvOwners - 1)), 1u,
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          rank[t] = __hip_atomic_fetch_add(cnt + row00 + dr[t], 1u, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-    // ---- next chunk's loads go out now; they land while the taps are applied ----------------
-    if (chunk + 1 < n_chunks) prefetch(chunk + 1);
+    // the next chunk's loads go out now; they land while this chunk is sorted and applied
+    if (chunk + 1 < n_chunks) { prefetch_rows(chunk + 1); prefetch_sample(chunk + 1); }
     __syncthreads();
-    // ---- scatter the taps into per-owner segments of one list (counting sort) --------------
-    {
-      uint32_t run = 0, mine_off = 0, mine_cnt = 0;
-      uint32_t seg[4] = {0u, 0u, 0u, 0u};
-      const int dr[4] = {0, 1, Wl, Wl + 1};
-      int own[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) own[t] = (row00 + dr[t]) & (kGvOwners - 1);
-#pragma unroll
-      for (int o = 0; o < kGvOwners; ++o) {
-        const uint32_t n = cnt[o];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) seg[t] = own[t] == o ? run : seg[t];
-        if (o == hw_id) { mine_off = run; mine_cnt = n; }
-        run += n;
-      }
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-        if (mask & (1u << t))
-          list[seg[t] + rank[t]] = uint2_t{(uint32_t(sq) << 16) | uint32_t(row00 + dr[t]), __float_as_uint(wt[t])};
-      __syncthreads();
-      if (tid < kGvOwners) counters[((chunk + 1) & 1) * kGvOwners + tid] = 0;
 
-      // ---- each half-wave applies the taps of the rows it owns: plain read-add-write ------
-      // (ds_add_f32 costs ~170 clk per wave instruction on gfx950, ~9x a read+write pair).
-      const uint2_t* my = list + mine_off;
-      uint2_t rec = mine_cnt > 0 ? my[0] : uint2_t{0u, 0u};
-      float g = grows[(rec.x >> 16) * D + c];
-      for (uint32_t i = 0; i < mine_cnt; ++i) {
-        const uint2_t cur = rec;
-        const float gc = g;
-        if (i + 1 < mine_cnt) {  // next record's operands while this one is applied
-          rec = my[i + 1];
-          g = grows[(rec.x >> 16) * D + c];
+    // ---- block-wide exclusive scan of the row counts -> segment offsets ------------------------
+    const uint32_t my_cnt = tid < rows ? cnt[tid] : 0u;
+    uint32_t incl = my_cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t up = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += up;
+    }
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    {
+      uint32_t before = 0;
+#pragma unroll
+      for (int w = 0; w < kGvWaves; ++w) before += (w < wave) ? wtot[w] : 0u;
+      if (tid < rows) offs[tid] = before + incl - my_cnt;
+    }
+    __syncthreads();
+
+    // ---- scatter the taps into their row segments ---------------------------------------------
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      if (mask & (1u << t))
+        list[offs[row00 + dr[t]] + rank[t]] = uint2_t{uint32_t(sq), __float_as_uint(wt[t])};
+    __syncthreads();
+
+    // ---- 8-lane groups own rows: sum the row's segment in registers, one slab update ----------
+    if (ablate != 1) {
+      for (int row = grp; row < rows; row += kGvGroups) {
+        const uint32_t n = cnt[row];
+        if (n == 0) continue;
+        const uint2_t* seg = list + offs[row];
+        float4_t acc = {0.f, 0.f, 0.f, 0.f};
+        for (uint32_t i = 0; i < n; ++i) {
+          const uint2_t rec = seg[i];
+          const float4_t g = reinterpret_cast<const float4_t*>(grows)[rec.x * 8 + ch4];
+          acc += __uint_as_float(rec.y) * g;
         }
-        float* p = slab + (cur.x & 0xffffu) * D + c;
-        *p += __uint_as_float(cur.y) * gc;
+        reinterpret_cast<float4_t*>(slab)[row * 8 + ch4] += acc;
       }
     }
+    __syncthreads();
+    if (tid < rows) cnt[tid] = 0;  // the next chunk's first barrier orders this before any read;
+                                   // its atomics come after the staging writes below it anyway
     __syncthreads();
   }
 
   // ---- write the slab: one owner per row, 16 B per lane, whole 128-B lines -----------------
   TV* out = grad_value + ((int64_t(b) * d.S + start + r0) * d.M + m) * D;
   for (int i = tid; i < rows * (D / 4); i += kGvThreads) {
-    const int row = i >> 3, ch4 = i & 7;
+    const int row = i >> 3, c4 = i & 7;
     const float4_t v = reinterpret_cast<const float4_t*>(slab)[i];
-    gv_store4<TV>(out + int64_t(row) * d.M * D + ch4 * 4, v);
+    gv_store4<TV>(out + int64_t(row) * d.M * D + c4 * 4, v);
   }
 }
 
@@ -280,7 +299,7 @@ int msda_gv_units_bound(const MsdaDims& d, int units_min) {
 bool msda_d32_gv_supported(int vdt, int ldt, const MsdaDims& d) {
   if (d.D != 32 || vdt == VNX_F64) return false;
   if (vdt == VNX_F32 && ldt != VNX_F32) return false;
-  if (d.P > 64) return false;  // a chunk holds at least 8 queries x P samples, one per thread
+  if (d.P > 64 || d.L > kGvLevelsMax) return false;  // >= 8 queries x P samples per chunk; level table in LDS
   const int64_t blocks = int64_t(d.B) * d.M * msda_gv_units_bound(d, 16);
   return blocks < (int64_t(1) << 31);
 }
@@ -288,16 +307,14 @@ bool msda_d32_gv_supported(int vdt, int ldt, const MsdaDims& d) {
 template <typename TV, typename TL>
 static int launch_gv(const int64_t* shapes, const int64_t* lsi, const void* loc, const void* attn,
                      const void* grad_out, void* grad_value, const MsdaDims& d, int units_min,
-                     hipStream_t stream) {
+                     int ablate, hipStream_t stream) {
   const int units_bound = msda_gv_units_bound(d, units_min);
   const int64_t blocks = int64_t(d.B) * d.M * units_bound;
   int qc = kGvSamplesMax / d.P;
   if (qc > kGvQcMax) qc = kGvQcMax;
-  const size_t lds = size_t(kGvRowsMax) * 128 + size_t(kGvQcMax) * 128 + size_t(kGvSamplesMax) * 32 +
-                     2 * kGvOwners * 4;
-  hipLaunchKernelGGL((msda_bwd_gv_tile_kernel<TV, TL>), dim3(uint32_t(blocks)), dim3(kGvThreads), lds,
-                     stream, shapes, lsi, (const TL*)loc, (const TL*)attn, (const TV*)grad_out,
-                     (TV*)grad_value, d, units_min, units_bound, qc);
+  hipLaunchKernelGGL((msda_bwd_gv_tile_kernel<TV, TL>), dim3(uint32_t(blocks)), dim3(kGvThreads),
+                     kGvLdsBytes, stream, shapes, lsi, (const TL*)loc, (const TL*)attn,
+                     (const TV*)grad_out, (TV*)grad_value, d, units_min, units_bound, qc, ablate);
   return check_launch("msda_bwd_gv_tile");
 }
 
@@ -310,7 +327,8 @@ int msda_backward_gv_d32(int vdt, int ldt, const int64_t* shapes, const int64_t*
   if (variant >= 200 && variant < 300) units_min = variant - 200;
   if (units_min < 1) units_min = 1;
   if (units_min > 16) units_min = 16;
-#define VNX_ARGS shapes, lsi, loc, attn, grad_out, grad_value, d, units_min, stream
+  const int ablate = (variant == 401) ? 1 : (variant == 402) ? 2 : 0;  // timing ablations only
+#define VNX_ARGS shapes, lsi, loc, attn, grad_out, grad_value, d, units_min, ablate, stream
   if (vdt == VNX_F32) return launch_gv<float, float>(VNX_ARGS);
   if (vdt == VNX_BF16 && ldt == VNX_F32) return launch_gv<bf16_t, float>(VNX_ARGS);
   if (vdt == VNX_BF16 && ldt == VNX_BF16) return launch_gv<bf16_t, bf16_t>(VNX_ARGS);
