@@ -93,14 +93,14 @@ __device__ __forceinline__ void gv_store4<f16_t>(f16_t* p, float4_t v) {
 constexpr int kGvWaves = 8;      // 512 threads
 constexpr int kGvThreads = 64 * kGvWaves;
 constexpr int kGvGroups = kGvThreads / 8;  // 8-lane groups
-constexpr int kGvRowsMax = 352;  // 44 KiB slab
+constexpr int kGvRowsMax = 336;  // 42 KiB slab
 constexpr int kGvQcMax = 128;    // queries per chunk (16 KiB of grad_out rows)
 constexpr int kGvSamplesMax = kGvThreads;  // one sample per thread per chunk
 constexpr int kGvLevelsMax = 64;
-// slab 44 K + rows 16 K + tap list 16 K + 2 x 352 counters/offsets + level table ~ 79.6 KiB
+// slab 42 K + rows 16 K + tap list 16 K + 3 x 336 counters/offsets + level table ~ 78.8 KiB
 // -> two units per CU.
 constexpr size_t kGvLdsBytes = size_t(kGvRowsMax) * 128 + size_t(kGvQcMax) * 128 +
-                               size_t(kGvSamplesMax) * 32 + size_t(kGvRowsMax) * 8 + kGvWaves * 4 +
+                               size_t(kGvSamplesMax) * 32 + size_t(kGvRowsMax) * 12 + kGvWaves * 4 +
                                3 * kGvLevelsMax * 4;
 
 template <typename TV, typename TL>
@@ -114,8 +114,8 @@ msda_bwd_gv_tile_kernel(const int64_t* __restrict__ shapes, const int64_t* __res
   float* slab = reinterpret_cast<float*>(smem);
   float* grows = slab + kGvRowsMax * D;                                   // [qc][32]
   uint2_t* list = reinterpret_cast<uint2_t*>(grows + kGvQcMax * D);       // [4*samples] taps
-  uint32_t* cnt = reinterpret_cast<uint32_t*>(list + 4 * kGvSamplesMax);  // [rows] taps per row
-  uint32_t* offs = cnt + kGvRowsMax;                                      // [rows] segment starts
+  uint32_t* cnt2 = reinterpret_cast<uint32_t*>(list + 4 * kGvSamplesMax); // [2][rows] taps per row
+  uint32_t* offs = cnt2 + 2 * kGvRowsMax;                                 // [rows] segment starts
   uint32_t* wtot = offs + kGvRowsMax;                                     // [waves]
   int* meta = reinterpret_cast<int*>(wtot + kGvWaves);                    // [3*L] H, W, start
 
@@ -147,7 +147,7 @@ msda_bwd_gv_tile_kernel(const int64_t* __restrict__ shapes, const int64_t* __res
     meta[3 * tid + 1] = int(shapes[2 * tid + 1]);
     meta[3 * tid + 2] = int(lsi[tid]);
   }
-  for (int i = tid; i < kGvRowsMax; i += kGvThreads) cnt[i] = 0;
+  for (int i = tid; i < 2 * kGvRowsMax; i += kGvThreads) cnt2[i] = 0;
   __syncthreads();
 
   // ---- which (level, pixel range) is this unit? ------------------------------------------------
@@ -202,6 +202,8 @@ msda_bwd_gv_tile_kernel(const int64_t* __restrict__ shapes, const int64_t* __res
 
   const int grp = tid >> 3, ch4 = tid & 7;
   for (int chunk = 0; chunk < n_chunks; ++chunk) {
+    uint32_t* cnt = cnt2 + (chunk & 1) * kGvRowsMax;        // this chunk's row counters
+    uint32_t* cnt_next = cnt2 + ((chunk + 1) & 1) * kGvRowsMax;
     // ---- stage the chunk: grad_out rows -> LDS; geometry; rank each tap inside its row -------
     if ((g0 >> 3) < qc) reinterpret_cast<float4_t*>(grows)[g0] = pg0;
     if ((g1 >> 3) < qc) reinterpret_cast<float4_t*>(grows)[g1] = pg1;
@@ -237,21 +239,30 @@ msda_bwd_gv_tile_kernel(const int64_t* __restrict__ shapes, const int64_t* __res
     if (chunk + 1 < n_chunks) { prefetch_rows(chunk + 1); prefetch_sample(chunk + 1); }
     __syncthreads();
 
-    // ---- block-wide exclusive scan of the row counts -> segment offsets ------------------------
-    const uint32_t my_cnt = tid < rows ? cnt[tid] : 0u;
-    uint32_t incl = my_cnt;
+    // ---- exclusive scan of the row counts -> segment offsets (wave 0, 6 rows per lane) -------
+    if (wave == 0) {
+      constexpr int kPer = (kGvRowsMax + 63) / 64;
+      uint32_t c[kPer];
+      uint32_t sum = 0;
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const uint32_t up = __shfl_up(incl, off, 64);
-      if (lane >= off) incl += up;
-    }
-    if (lane == 63) wtot[wave] = incl;
-    __syncthreads();
-    {
-      uint32_t before = 0;
+      for (int j = 0; j < kPer; ++j) {
+        const int r = lane * kPer + j;
+        c[j] = r < rows ? cnt[r] : 0u;
+        sum += c[j];
+      }
+      uint32_t incl = sum;
 #pragma unroll
-      for (int w = 0; w < kGvWaves; ++w) before += (w < wave) ? wtot[w] : 0u;
-      if (tid < rows) offs[tid] = before + incl - my_cnt;
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t up = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += up;
+      }
+      uint32_t run = incl - sum;
+#pragma unroll
+      for (int j = 0; j < kPer; ++j) {
+        const int r = lane * kPer + j;
+        if (r < rows) offs[r] = run;
+        run += c[j];
+      }
     }
     __syncthreads();
 
@@ -263,23 +274,28 @@ msda_bwd_gv_tile_kernel(const int64_t* __restrict__ shapes, const int64_t* __res
     __syncthreads();
 
     // ---- 8-lane groups own rows: sum the row's segment in registers, one slab update ----------
-    if (ablate != 1) {
-      for (int row = grp; row < rows; row += kGvGroups) {
-        const uint32_t n = cnt[row];
-        if (n == 0) continue;
-        const uint2_t* seg = list + offs[row];
-        float4_t acc = {0.f, 0.f, 0.f, 0.f};
-        for (uint32_t i = 0; i < n; ++i) {
-          const uint2_t rec = seg[i];
-          const float4_t g = reinterpret_cast<const float4_t*>(grows)[rec.x * 8 + ch4];
-          acc += __uint_as_float(rec.y) * g;
-        }
-        reinterpret_cast<float4_t*>(slab)[row * 8 + ch4] += acc;
+    for (int row = grp; row < rows; row += kGvGroups) {
+      const uint32_t n = ablate == 1 ? 0u : cnt[row];
+      cnt_next[row] = 0;  // the other parity's counters are idle during this phase
+      if (n == 0) continue;
+      const uint2_t* seg = list + offs[row];
+      const float4_t* g4 = reinterpret_cast<const float4_t*>(grows) + ch4;
+      float4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+      uint32_t i = 0;
+      for (; i + 4 <= n; i += 4) {  // four independent record -> row-read chains in flight
+        const uint2_t r0_ = seg[i], r1_ = seg[i + 1], r2_ = seg[i + 2], r3_ = seg[i + 3];
+        const float4_t x0 = g4[r0_.x * 8], x1 = g4[r1_.x * 8], x2 = g4[r2_.x * 8], x3 = g4[r3_.x * 8];
+        a0 += __uint_as_float(r0_.y) * x0;
+        a1 += __uint_as_float(r1_.y) * x1;
+        a2 += __uint_as_float(r2_.y) * x2;
+        a3 += __uint_as_float(r3_.y) * x3;
       }
+      for (; i < n; ++i) {
+        const uint2_t r = seg[i];
+        a0 += __uint_as_float(r.y) * g4[r.x * 8];
+      }
+      reinterpret_cast<float4_t*>(slab)[row * 8 + ch4] += (a0 + a1) + (a2 + a3);
     }
-    __syncthreads();
-    if (tid < rows) cnt[tid] = 0;  // the next chunk's first barrier orders this before any read;
-                                   // its atomics come after the staging writes below it anyway
     __syncthreads();
   }
 
