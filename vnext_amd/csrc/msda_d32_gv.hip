@@ -14,7 +14,7 @@
 // contiguous range of pixels of ONE level for one (batch, head) and one HALF of the
 // 32 channels, and keeps that slab [rows][16] in LDS (fp32).  Splitting the channels
 // rather than the rows or the queries halves every LDS buffer without adding any
-// floating-point work, so three units fit a CU and a decoder-sized call (300
+// floating-point work, so several units fit a CU and a decoder-sized call (300
 // queries) is one pass with no chunk loop.  Per chunk of queries:
 //   * the chunk's grad_out half-rows of this head go to LDS once (16-B loads), and
 //     each thread computes the bilinear geometry of up to three samples of the
@@ -101,24 +101,57 @@ constexpr int kGvHalf = 16;                 // channels per unit
 constexpr int kGvGroups = kGvThreads / 4;   // 4-lane groups, 16 B per lane
 constexpr int kGvSpt = 3;                   // samples per thread per chunk
 constexpr int kGvRowsMax = 320;             // 20 KiB slab
+constexpr int kGvRpg = (kGvRowsMax + kGvGroups - 1) / kGvGroups;  // rows per 4-lane group
 constexpr int kGvQcMax = 304;               // queries per chunk (19 KiB of grad_out half-rows)
 constexpr int kGvCap = 1280;                // tap records per window (10 KiB)
 constexpr int kGvLevelsMax = 64;
-// 20480 + 19456 + 10240 + 2*1280 (counters, offsets) + 16 + 768 (level table) = 53520 B
-// -> three units per CU (160 KiB / 3 = 54613 B).
+// 20480 + 19456 + 10240 + 2*1280 (counters, offsets) + 16 + 1024 (level table) = 53776 B
+// -> three units per CU by LDS (160 KiB / 3 = 54613 B).
 constexpr size_t kGvLdsBytes = size_t(kGvRowsMax) * kGvHalf * 4 + size_t(kGvQcMax) * kGvHalf * 4 +
-                               size_t(kGvCap) * 8 + size_t(kGvRowsMax) * 8 + 16 + 3 * kGvLevelsMax * 4;
+                               size_t(kGvCap) * 8 + size_t(kGvRowsMax) * 8 + 16 + 4 * kGvLevelsMax * 4;
 
 // Development aid: per-workgroup phase timestamps (s_memtime), written when ablate & 8.
-__device__ unsigned long long g_gv_stamps[4096 * 8];
+__device__ unsigned long long g_gv_stamps[4096 * 16];
 #define VNX_STAMP(k)                                                         \
   do {                                                                       \
     if ((ablate & 8) && tid == 0 && blockIdx.x < 4096)                       \
-      g_gv_stamps[blockIdx.x * 8 + (k)] = __builtin_readcyclecounter();      \
+      g_gv_stamps[blockIdx.x * 16 + (k)] = __builtin_readcyclecounter();     \
   } while (0)
 
-template <typename TV, typename TL>
-__global__ void __launch_bounds__(kGvThreads)
+struct GvGeom {
+  uint32_t mask;  // taps inside the unit's range
+  int row00;      // first tap's row relative to the unit
+  float w[4];
+};
+
+// Bilinear geometry of one sample against the unit's pixel range [r0, r1) of a Hl x Wl level
+// (ms_deform_im2col_cuda.cuh:285-288 range test, :38-78 taps).
+__device__ __forceinline__ GvGeom gv_geometry(float x, float y, float a, int Hl, int Wl, int r0, int r1) {
+  GvGeom g;
+  g.mask = 0; g.row00 = 0;
+  g.w[0] = g.w[1] = g.w[2] = g.w[3] = 0.f;
+  const float Hf = float(Hl), Wf = float(Wl);
+  const float h = y * Hf - 0.5f, w = x * Wf - 0.5f;
+  if (h > -1.f && w > -1.f && h < Hf && w < Wf) {
+    const float hf = floorf(h), wf = floorf(w);
+    const int h0 = int(hf), w0 = int(wf);
+    const float lh = h - hf, lw = w - wf, hh = 1.f - lh, hw = 1.f - lw;
+    const bool top = h0 >= 0, bot = h0 + 1 <= Hl - 1, lef = w0 >= 0, rig = w0 + 1 <= Wl - 1;
+    const int p00 = h0 * Wl + w0;
+    const int pa = p00, pb = p00 + 1, pc = p00 + Wl, pd = p00 + Wl + 1;
+    g.mask = (uint32_t(top && lef && pa >= r0 && pa < r1)) |
+             (uint32_t(top && rig && pb >= r0 && pb < r1) << 1) |
+             (uint32_t(bot && lef && pc >= r0 && pc < r1) << 2) |
+             (uint32_t(bot && rig && pd >= r0 && pd < r1) << 3);
+    g.row00 = p00 - r0;
+    g.w[0] = a * (hh * hw); g.w[1] = a * (hh * lw); g.w[2] = a * (lh * hw); g.w[3] = a * (lh * lw);
+  }
+  return g;
+}
+
+// P_T > 0: points per level known at compile time (index arithmetic without integer division).
+template <typename TV, typename TL, int P_T>
+__global__ void __launch_bounds__(kGvThreads, 4)
 msda_bwd_gv_tile_kernel(const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
                         const TL* __restrict__ loc, const TL* __restrict__ attn,
                         const TV* __restrict__ grad_out, TV* __restrict__ grad_value, MsdaDims d,
@@ -132,8 +165,9 @@ msda_bwd_gv_tile_kernel(const int64_t* __restrict__ shapes, const int64_t* __res
   uint32_t* cnt = reinterpret_cast<uint32_t*>(list + kGvCap);            // [rows] taps per row
   uint32_t* offs = cnt + kGvRowsMax;                                     // [rows] segment starts
   uint32_t* alloc = offs + kGvRowsMax;                                   // [4] running total
-  int* meta = reinterpret_cast<int*>(alloc + 4);                         // [3*L] H, W, start
+  int* meta = reinterpret_cast<int*>(alloc + 4);                         // [4*L] W, start, units, rows/unit
 
+  const int P = P_T > 0 ? P_T : d.P;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   // blockIdx -> (channel half, head, unit, batch); head innermost but one for XCD affinity
@@ -144,56 +178,44 @@ msda_bwd_gv_tile_kernel(const int64_t* __restrict__ shapes, const int64_t* __res
   const int b = rest / units_bound;
   VNX_STAMP(0);
 
-  const int64_t q_stride = int64_t(d.M) * D;  // grad_out elements between queries
-  const TV* go_head = grad_out + (int64_t(b) * d.Lq * d.M + m) * D + half * kGvHalf;
-
-  // this thread's float4 slots of the chunk's [qc][H4] half-rows
-  float4_t pg[kGvSpt];
-  auto prefetch_rows = [&](int chunk) {
-    const int q_base = chunk * qc;
-#pragma unroll
-    for (int j = 0; j < kGvSpt; ++j) {
-      const int slot = tid + j * kGvThreads;
-      const int q = q_base + (slot >> 2);
-      pg[j] = float4_t{0.f, 0.f, 0.f, 0.f};
-      if ((slot >> 2) < qc && q < d.Lq) pg[j] = gv_load4<TV>(go_head + int64_t(q) * q_stride + (slot & 3) * 4);
-    }
-  };
-  // chunk 0's grad_out rows do not depend on the unit: request them before anything else
-  prefetch_rows(0);
-
-  // ---- level table: one round of vector loads, shared through LDS -------------------------
+  // ---- level table: lane l works out level l's unit split; shared through LDS --------------
+  // meta[4l..] = {W_l | H_l << 16, start_l (or -1 when not packed), units_l, rows_per_unit_l}
   if (tid < d.L) {
-    meta[3 * tid] = int(shapes[2 * tid]);
-    meta[3 * tid + 1] = int(shapes[2 * tid + 1]);
-    meta[3 * tid + 2] = int(lsi[tid]);
+    const int H = int(shapes[2 * tid]), W = int(shapes[2 * tid + 1]);
+    const int st = int(lsi[tid]);
+    const int n = H * W;
+    int units = 0, rpu = 1;
+    if (n > 0) {
+      units = (n + kGvRowsMax - 1) / kGvRowsMax;
+      if (units < units_min) units = units_min;
+      if (units > n) units = n;
+      rpu = (n + units - 1) / units;
+      units = (n + rpu - 1) / rpu;
+    }
+    meta[4 * tid] = H; meta[4 * tid + 1] = W; meta[4 * tid + 2] = st;
+    meta[4 * tid + 3] = units | (rpu << 12);  // units <= 2^12 is checked on the host
   }
   for (int i = tid; i < kGvRowsMax; i += kGvThreads) cnt[i] = 0;
   if (tid == 0) alloc[0] = 0;
   __syncthreads();
   VNX_STAMP(1);
 
-  // ---- which (level, pixel range) is this unit? ------------------------------------------------
+  // ---- which (level, pixel range) is this unit? (no divisions here) ---------------------------
   int lvl = -1, r0 = 0, r1 = 0, Hl = 0, Wl = 0, start = 0;
   {
     int running = 0;
     bool packed = true;
     int u = unit;
     for (int l = 0; l < d.L; ++l) {
-      const int H = meta[3 * l], W = meta[3 * l + 1], st = meta[3 * l + 2];
-      const int n = H * W;
+      const int H = meta[4 * l], W = meta[4 * l + 1], st = meta[4 * l + 2], ur = meta[4 * l + 3];
+      const int n = H * W, units = ur & 0xfff, rpu = ur >> 12;
       packed = packed && (st == running);
       running += n;
-      if (lvl < 0 && n > 0) {
-        int units = (n + kGvRowsMax - 1) / kGvRowsMax;
-        if (units < units_min) units = units_min;
-        if (units > n) units = n;
-        const int rows_per_unit = (n + units - 1) / units;
-        units = (n + rows_per_unit - 1) / rows_per_unit;
+      if (lvl < 0) {
         if (u < units) {
           lvl = l; Hl = H; Wl = W; start = st;
-          r0 = u * rows_per_unit;
-          r1 = r0 + rows_per_unit < n ? r0 + rows_per_unit : n;
+          r0 = u * rpu;
+          r1 = r0 + rpu < n ? r0 + rpu : n;
         } else {
           u -= units;
         }
@@ -205,73 +227,73 @@ msda_bwd_gv_tile_kernel(const int64_t* __restrict__ shapes, const int64_t* __res
   const int rows = r1 - r0;
   for (int i = tid; i < rows * H4; i += kGvThreads) slab[i] = float4_t{0.f, 0.f, 0.f, 0.f};
 
-  const int LP = d.L * d.P;
-  const float Hf = float(Hl), Wf = float(Wl);
+  const int LP = d.L * P;
   const int n_chunks = (d.Lq + qc - 1) / qc;
-  const int n_samples = qc * d.P;  // per full chunk, <= kGvSpt * kGvThreads
+  const int n_samples = qc * P;  // per full chunk, <= kGvSpt * kGvThreads
+  const int64_t q_stride = int64_t(d.M) * D;  // grad_out elements between queries
+  const TV* go_head = grad_out + (int64_t(b) * d.Lq * d.M + m) * D + half * kGvHalf;
+  const int64_t loc_head = (int64_t(b) * d.Lq * d.M + m) * LP + lvl * P;  // + q*M*LP + k
 
+  // this thread's slots: float4 pieces of the chunk's [qc][H4] half-rows, and samples
+  float4_t pg[kGvSpt];
   float px[kGvSpt], py[kGvSpt], pa[kGvSpt];
-  auto prefetch_samples = [&](int chunk) {
+  auto prefetch = [&](int chunk) {
+    const int q_base = chunk * qc;
+#pragma unroll
+    for (int j = 0; j < kGvSpt; ++j) {
+      const int slot = tid + j * kGvThreads;
+      const int q = q_base + (slot >> 2);
+      pg[j] = float4_t{0.f, 0.f, 0.f, 0.f};
+      if ((slot >> 2) < qc && q < d.Lq) pg[j] = gv_load4<TV>(go_head + int64_t(q) * q_stride + (slot & 3) * 4);
+    }
 #pragma unroll
     for (int j = 0; j < kGvSpt; ++j) {
       const int e = tid + j * kGvThreads;
-      const int qs = e / d.P;
-      const int q = chunk * qc + qs;
-      px[j] = -4.f; py[j] = -4.f; pa[j] = 0.f;  // fails the range test below
+      const int qs = e / P;
+      const int q = q_base + qs;
+      px[j] = -4.f; py[j] = -4.f; pa[j] = 0.f;  // fails the range test
       if (e < n_samples && q < d.Lq) {
-        const int64_t wi = ((int64_t(b) * d.Lq + q) * d.M + m) * LP + lvl * d.P + (e - qs * d.P);
+        const int64_t wi = loc_head + int64_t(q) * d.M * LP + (e - qs * P);
         px[j] = to_acc(loc[2 * wi]); py[j] = to_acc(loc[2 * wi + 1]); pa[j] = to_acc(attn[wi]);
       }
     }
   };
-  prefetch_samples(0);
+  prefetch(0);
   VNX_STAMP(2);
 
   const int grp = tid >> 2, c4 = tid & 3;
   const int dr[4] = {0, 1, Wl, Wl + 1};
   for (int chunk = 0; chunk < n_chunks; ++chunk) {
-    if (chunk < 3) VNX_STAMP(3 + chunk);
+    if (chunk == 0) VNX_STAMP(3);
     // ---- stage the chunk: grad_out half-rows -> LDS; geometry; rank each tap in its row -------
 #pragma unroll
     for (int j = 0; j < kGvSpt; ++j) {
       const int slot = tid + j * kGvThreads;
       if ((slot >> 2) < qc) grows[slot] = pg[j];
     }
-    uint32_t mask[kGvSpt];
-    int row00[kGvSpt];
-    float wt[kGvSpt][4];
-    uint32_t rank[kGvSpt][4];
+    // kept across the sort: the sample itself (12 B) and 4 x 16-bit ranks; the geometry is
+    // recomputed at scatter time, which is cheaper than carrying it in registers
+    float sx[kGvSpt], sy[kGvSpt], sa[kGvSpt];
+    uint32_t rk01[kGvSpt], rk23[kGvSpt];
 #pragma unroll
     for (int j = 0; j < kGvSpt; ++j) {
-      mask[j] = 0; row00[j] = 0;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) { wt[j][t] = 0.f; rank[j][t] = 0u; }
-      const float h = py[j] * Hf - 0.5f, w = px[j] * Wf - 0.5f;
-      if (h > -1.f && w > -1.f && h < Hf && w < Wf) {
-        const float hf = floorf(h), wf = floorf(w);
-        const int h0 = int(hf), w0i = int(wf);
-        const float lh = h - hf, lw = w - wf, hh = 1.f - lh, hw = 1.f - lw;
-        const bool top = h0 >= 0, bot = h0 + 1 <= Hl - 1, lef = w0i >= 0, rig = w0i + 1 <= Wl - 1;
-        const int p00 = h0 * Wl + w0i;
-        const int pa_ = p00, pb_ = p00 + 1, pc_ = p00 + Wl, pd_ = p00 + Wl + 1;
-        mask[j] = (uint32_t(top && lef && pa_ >= r0 && pa_ < r1)) |
-                  (uint32_t(top && rig && pb_ >= r0 && pb_ < r1) << 1) |
-                  (uint32_t(bot && lef && pc_ >= r0 && pc_ < r1) << 2) |
-                  (uint32_t(bot && rig && pd_ >= r0 && pd_ < r1) << 3);
-        if (ablate & 2) mask[j] = 0;
-        row00[j] = p00 - r0;
-        const float a = pa[j];
-        wt[j][0] = a * (hh * hw); wt[j][1] = a * (hh * lw); wt[j][2] = a * (lh * hw); wt[j][3] = a * (lh * lw);
-      }
+      sx[j] = px[j]; sy[j] = py[j]; sa[j] = pa[j];
+      GvGeom g = gv_geometry(sx[j], sy[j], sa[j], Hl, Wl, r0, r1);
+      if (ablate & 2) g.mask = 0;
+      uint32_t rk[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
       for (int t = 0; t < 4; ++t)
-        if (mask[j] & (1u << t))  // integer LDS atomics are fast (tools/lds_atomic_bench.hip)
-          rank[j][t] = __hip_atomic_fetch_add(cnt + row00[j] + dr[t], 1u, __ATOMIC_RELAXED,
-                                              __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (g.mask & (1u << t))  // integer LDS atomics are fast (tools/lds_atomic_bench.hip)
+          rk[t] = __hip_atomic_fetch_add(cnt + g.row00 + dr[t], 1u, __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_WORKGROUP);
+      rk01[j] = rk[0] | (rk[1] << 16);
+      rk23[j] = rk[2] | (rk[3] << 16);
     }
+    if (chunk == 0) VNX_STAMP(8);
     // the next chunk's loads go out now; they land while this chunk is sorted and applied
-    if (chunk + 1 < n_chunks) { prefetch_rows(chunk + 1); prefetch_samples(chunk + 1); }
+    if (chunk + 1 < n_chunks) prefetch(chunk + 1);
     __syncthreads();
+    if (chunk == 0) VNX_STAMP(9);
 
     // ---- row counts -> segment offsets: wave scan + one allocation per wave --------------------
     {
@@ -290,31 +312,43 @@ msda_bwd_gv_tile_kernel(const int64_t* __restrict__ shapes, const int64_t* __res
       if (tid < rows) offs[tid] = base + incl - my_cnt;
     }
     __syncthreads();
+    if (chunk == 0) VNX_STAMP(10);
     const uint32_t total = alloc[0];
 
     for (uint32_t win = 0; win < total; win += kGvCap) {  // one window unless the chunk is tap-heavy
       // ---- scatter the taps of this window into their row segments ------------------------------
 #pragma unroll
       for (int j = 0; j < kGvSpt; ++j) {
-        const uint32_t qs = uint32_t((tid + j * kGvThreads) / d.P);
+        GvGeom g = gv_geometry(sx[j], sy[j], sa[j], Hl, Wl, r0, r1);
+        if (ablate & 2) g.mask = 0;
+        const uint32_t qs = uint32_t((tid + j * kGvThreads) / P);
+        const uint32_t rk[4] = {rk01[j] & 0xffffu, rk01[j] >> 16, rk23[j] & 0xffffu, rk23[j] >> 16};
 #pragma unroll
         for (int t = 0; t < 4; ++t)
-          if (mask[j] & (1u << t)) {
-            const uint32_t pos = offs[row00[j] + dr[t]] + rank[j][t] - win;
-            if (pos < uint32_t(kGvCap)) list[pos] = uint2_t{qs, __float_as_uint(wt[j][t])};
+          if (g.mask & (1u << t)) {
+            const uint32_t pos = offs[g.row00 + dr[t]] + rk[t] - win;
+            if (pos < uint32_t(kGvCap)) list[pos] = uint2_t{qs, __float_as_uint(g.w[t])};
           }
       }
       __syncthreads();
+      if (chunk == 0 && win == 0) VNX_STAMP(11);
       // ---- 4-lane groups own rows: sum the row's segment in registers, one slab update --------
       if (!(ablate & 1)) {
-        for (int row = grp; row < rows; row += kGvGroups) {
-          const uint32_t n = cnt[row];
-          if (n == 0) continue;
-          const uint32_t o = offs[row];
+        uint32_t rn[kGvRpg], ro[kGvRpg];
+#pragma unroll
+        for (int k = 0; k < kGvRpg; ++k) {  // this group's rows: counts and offsets up front
+          const int row = grp + k * kGvGroups;
+          rn[k] = row < rows ? cnt[row] : 0u;
+          ro[k] = row < rows ? offs[row] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < kGvRpg; ++k) {
+          const int row = grp + k * kGvGroups;
+          const uint32_t n = rn[k], o = ro[k];
           // the part of [o, o+n) inside [win, win+cap)
           const uint32_t lo = o > win ? o : win;
           const uint32_t hi = (o + n) < (win + kGvCap) ? (o + n) : (win + kGvCap);
-          if (lo >= hi) continue;
+          if (n == 0 || lo >= hi) continue;
           const uint2_t* seg = list + (lo - win);
           const uint32_t len = hi - lo;
           const float4_t* g4 = grows + c4;
@@ -336,12 +370,14 @@ msda_bwd_gv_tile_kernel(const int64_t* __restrict__ shapes, const int64_t* __res
         }
       }
       __syncthreads();
+      if (chunk == 0 && win == 0) VNX_STAMP(12);
     }
-    // reset the counters for the next chunk (its rank atomics come after its staging writes,
-    // and the barrier below orders them after these stores)
-    if (tid < rows) cnt[tid] = 0;
-    if (tid == 0) alloc[0] = 0;
-    __syncthreads();
+    if (chunk + 1 < n_chunks) {
+      // reset the counters for the next chunk; the barrier orders its rank atomics after this
+      if (tid < rows) cnt[tid] = 0;
+      if (tid == 0) alloc[0] = 0;
+      __syncthreads();
+    }
   }
   VNX_STAMP(6);
 
@@ -362,6 +398,7 @@ bool msda_d32_gv_supported(int vdt, int ldt, const MsdaDims& d) {
   if (d.D != 32 || vdt == VNX_F64) return false;
   if (vdt == VNX_F32 && ldt != VNX_F32) return false;
   if (d.P > 64 || d.L > kGvLevelsMax) return false;  // >= 8 queries x P samples per chunk; level table in LDS
+  if (d.S > kGvRowsMax * 4000) return false;         // units per level and rows per unit pack into one word
   const int64_t blocks = int64_t(d.B) * d.M * msda_gv_units_bound(d, 16) * 2;
   return blocks < (int64_t(1) << 31);
 }
@@ -374,9 +411,13 @@ static int launch_gv(const int64_t* shapes, const int64_t* lsi, const void* loc,
   const int64_t blocks = int64_t(d.B) * d.M * units_bound * 2;
   int qc = (kGvSpt * kGvThreads) / d.P;
   if (qc > kGvQcMax) qc = kGvQcMax;
-  hipLaunchKernelGGL((msda_bwd_gv_tile_kernel<TV, TL>), dim3(uint32_t(blocks)), dim3(kGvThreads),
-                     kGvLdsBytes, stream, shapes, lsi, (const TL*)loc, (const TL*)attn,
-                     (const TV*)grad_out, (TV*)grad_value, d, units_min, units_bound, qc, ablate);
+#define VNX_LAUNCH(PT)                                                                             \
+  hipLaunchKernelGGL((msda_bwd_gv_tile_kernel<TV, TL, PT>), dim3(uint32_t(blocks)),                \
+                     dim3(kGvThreads), kGvLdsBytes, stream, shapes, lsi, (const TL*)loc,          \
+                     (const TL*)attn, (const TV*)grad_out, (TV*)grad_value, d, units_min,          \
+                     units_bound, qc, ablate)
+  if (d.P == 4) VNX_LAUNCH(4); else VNX_LAUNCH(0);
+#undef VNX_LAUNCH
   return check_launch("msda_bwd_gv_tile");
 }
 
