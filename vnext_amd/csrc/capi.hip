@@ -4,6 +4,8 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <mutex>
+
 #include "vnx_common.h"
 
 namespace vnx {
@@ -47,6 +49,31 @@ int msda_forward_d32(int, int, const void*, const int64_t*, const int64_t*, cons
 int msda_backward_d32(int, int, const void*, const int64_t*, const int64_t*, const void*,
                       const void*, const void*, void*, void*, void*, MsdaDims, int variant,
                       hipStream_t);
+
+// One non-blocking side stream + fork/join events per device, created on first use and kept
+// for the life of the process (the backward forks its two independent kernels onto it).
+struct SideStream {
+  hipStream_t stream = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+  bool ok = false, tried = false;
+};
+
+static SideStream* side_stream_for_current_device() {
+  static SideStream table[64];
+  static std::mutex mu;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  SideStream& s = table[dev];
+  if (!s.tried) {
+    s.tried = true;
+    s.ok = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) == hipSuccess &&
+           hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&s.join, hipEventDisableTiming) == hipSuccess;
+    if (!s.ok) (void)hipGetLastError();
+  }
+  return s.ok ? &s : nullptr;
+}
 
 static int check_common(const char* fn, int vdt, int ldt, const void* value,
                         const int64_t* shapes, const int64_t* lsi, const void* loc,
@@ -184,6 +211,22 @@ int vnx_msda_backward(int value_dtype, int loc_dtype, const void* value,
     //     does nothing on the device when the levels ARE packed.  No host sync either way.
     const bool only_gl = variant >= 100 && variant < 200;  // timing ablations
     const bool only_gv = variant >= 400 && variant < 500;
+    // The two kernels share inputs only, so (2) is forked onto a side stream and joined
+    // back with events; inside a hipGraph capture this records two parallel branches.
+    SideStream* side = (only_gl || only_gv || variant == 500) ? nullptr : side_stream_for_current_device();
+    hipStream_t gv_stream = stream;
+    if (side) {
+      if (hipEventRecord(side->fork, stream) == hipSuccess &&
+          hipStreamWaitEvent(side->stream, side->fork, 0) == hipSuccess)
+        gv_stream = side->stream;
+      else
+        (void)hipGetLastError();  // fall back to one stream
+    }
+    if (!only_gl) {
+      st = msda_backward_gv_d32(value_dtype, loc_dtype, spatial_shapes, level_start_index,
+                                sampling_loc, attn_weight, grad_output, grad_value, d, variant, gv_stream);
+      if (st != VNX_OK) return st;
+    }
     if (!only_gv) {
       st = msda_backward_d32(value_dtype, loc_dtype, value, spatial_shapes, level_start_index,
                              sampling_loc, attn_weight, grad_output, nullptr, grad_sampling_loc,
@@ -191,10 +234,13 @@ int vnx_msda_backward(int value_dtype, int loc_dtype, const void* value,
                              stream);
       if (st != VNX_OK) return st;
     }
-    if (!only_gl) {
-      st = msda_backward_gv_d32(value_dtype, loc_dtype, spatial_shapes, level_start_index,
-                                sampling_loc, attn_weight, grad_output, grad_value, d, variant, stream);
-      if (st != VNX_OK) return st;
+    if (gv_stream != stream) {
+      if (hipEventRecord(side->join, gv_stream) != hipSuccess ||
+          hipStreamWaitEvent(stream, side->join, 0) != hipSuccess) {
+        set_error("vnx_msda_backward: joining the side stream failed: %s",
+                  hipGetErrorString(hipGetLastError()));
+        return VNX_ERR_LAUNCH;
+      }
     }
     if (!(flags & VNX_MSDA_LEVELS_PACKED) && !only_gl && !only_gv) {
       st = zero_if_not_packed(spatial_shapes, level_start_index, num_levels, spatial_size, gv_acc,
