@@ -133,6 +133,19 @@ def event_time_us(graph, launches, reps=15):
     return ts[len(ts) // 2]
 
 
+def latest_pmc_profile():
+    """The newest committed PMC summary (tools/summarize_prof.py), or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_pmc_hbm.json")))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            return {"file": os.path.relpath(files[-1], ROOT), "data": json.load(f)}
+    except (OSError, ValueError):
+        return None
+
+
 def largest_divisor_leq(n, cap):
     for d in range(min(n, cap), 0, -1):
         if n % d == 0:
@@ -170,7 +183,8 @@ def cpu_baseline(B, Lq, res, budget_s=12.0):
             best = (med, nt, len(ts))
     med, nt, n = best
     # the reference's fallback technique (grid_sample + autograd), all host threads
-    torch.set_num_threads(cores)
+    tthreads = min(cores, 16)  # grid_sample does not scale past a few threads; avoid oversubscription
+    torch.set_num_threads(tthreads)
     tv, tl, ta = (torch.from_numpy(x).requires_grad_(True) for x in (value, loc, attn))
     tg = torch.from_numpy(go)
     ts = []
@@ -188,10 +202,10 @@ def cpu_baseline(B, Lq, res, budget_s=12.0):
                   f"oracle/msda_oracle.c, median; host has {cores} cores",
         "ms_per_step": med * 1e3,
         "torch_grid_sample_fallback": {
-            "value": points / gmed / 1e9, "unit": "Gpoints/s", "cores": cores,
+            "value": points / gmed / 1e9, "unit": "Gpoints/s", "cores": tthreads,
             "ms_per_step": gmed * 1e3,
             "note": "grid_sample + autograd statement of the reference's pure-PyTorch path "
-                    "(oracle/msda_torch_fallback.py), torch intra-op threads = host cores"},
+                    "(oracle/msda_torch_fallback.py), torch intra-op threads = min(host cores, 16)"},
     }
 
 
@@ -295,7 +309,20 @@ def main():
         line["roofline"]["warm_us_per_launch"] = us_fwd_warm
         line["roofline"]["warm_frac"] = bytes_fwd / us_fwd_warm / 1e3 / HBM_PEAK_GBS
         line["roofline_bwd"] = roof(bytes_bwd, us_bwd,
-                                    "msda_bwd_d32_kernel + grad_value zero-fill (ms_deform_attn_backward)")
+                                    "msda_bwd_d32_kernel (grad_loc, grad_attn) + msda_bwd_gv_tile_kernel "
+                                    "(grad_value), one ms_deform_attn_backward call")
+        # HBM bytes per launch cannot be counted from inside this process: they come from the
+        # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command
+        # (profiles/rNN_bench_pmc_hbm.json, corrected as MI355X_MICROARCH.md section HBM says).
+        pmc = latest_pmc_profile()
+        if pmc is not None and (B, Lq, res, a.dist) == (5, 300, "360p", "U"):
+            for key, names in (("roofline", ["msda_fwd_d32_kernel"]),
+                               ("roofline_bwd", ["msda_bwd_d32_kernel", "msda_bwd_gv_tile_kernel"])):
+                vals = [v.get("hbm_bytes_per_launch_corrected") for k, v in pmc["data"].items()
+                        if any(n in k for n in names)]
+                if vals and all(v is not None for v in vals):
+                    line[key]["traffic"] = sum(vals)
+                    line[key]["traffic_source"] = pmc["file"]
         line["fwd_gpoints_per_s"] = points / us_fwd / 1e3
         if not a.no_cpu:
             line["cpu_baseline"] = cpu_baseline(B, Lq, res)

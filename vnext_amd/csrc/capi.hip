@@ -211,9 +211,10 @@ int vnx_msda_backward(int value_dtype, int loc_dtype, const void* value,
     //     does nothing on the device when the levels ARE packed.  No host sync either way.
     const bool only_gl = variant >= 100 && variant < 200;  // timing ablations
     const bool only_gv = variant >= 400 && variant < 500;
-    // The two kernels share inputs only, so (2) is forked onto a side stream and joined
-    // back with events; inside a hipGraph capture this records two parallel branches.
-    SideStream* side = (only_gl || only_gv || variant == 500) ? nullptr : side_stream_for_current_device();
+    // The two kernels share inputs only, so (2) CAN be forked onto a side stream and joined
+    // back with events (variant 501).  Measured on MI355X the fork/join costs more than the
+    // overlap returns (52 vs 48 us per backward at the T=5 decoder shape), so it is off.
+    SideStream* side = (variant == 501) ? side_stream_for_current_device() : nullptr;
     hipStream_t gv_stream = stream;
     if (side) {
       if (hipEventRecord(side->fork, stream) == hipSuccess &&
