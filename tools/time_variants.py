@@ -85,10 +85,11 @@ def main():
     ap.add_argument("--bwd", action="store_true")
     ap.add_argument("--bwd-only", action="store_true")
     ap.add_argument("--inner", type=int, default=24)
+    ap.add_argument("--lq", type=int, default=0)
     a = ap.parse_args()
     res = a.shape[3:]
     S = sum(h * w for h, w in SHAPES[res])
-    Lq = 300 if a.shape.startswith("dec") else S
+    Lq = a.lq if a.lq > 0 else (300 if a.shape.startswith("dec") else S)
     dtype = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[a.dtype]
     e = 4 if dtype == torch.float32 else 2
     B = a.B

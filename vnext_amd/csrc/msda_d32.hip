@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(64 * WPB)
 msda_fwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ shapes,
                     const int64_t* __restrict__ lsi, const TL* __restrict__ loc,
                     const TL* __restrict__ attn, TV* __restrict__ out, MsdaDims d,
-                    int tiles_per_batch) {
+                    int tiles_per_batch, int prefetch_rows) {
   constexpr int D = 32;
   constexpr int PG = 8 / QPW;            // sample groups per query
   constexpr int kRowBytes = D * int(sizeof(TV));
@@ -135,6 +135,26 @@ msda_fwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
   float4_t* s_wt = reinterpret_cast<float4_t*>(s_off + ent);
 
   const int pixel_bytes = d.M * kRowBytes;
+
+  const TV* head_base = value + (int64_t(b) * d.S * d.M + m) * D;
+  const uint32_t head_bytes = uint32_t((int64_t(d.S) * d.M - m) * kRowBytes);
+  const __amdgpu_buffer_rsrc_t rsrc = uniform_rsrc(head_base, head_bytes);
+
+  // ---- phase 0 (optional): stream this wave's share of the head's rows towards L2 --------
+  // When the call samples more taps than the head has rows (decoder call on a small map with
+  // scattered locations) nearly every row is read anyway; touching each row's two 64-B halves
+  // in address order here turns the first-touch HBM reads of the random gathers below into a
+  // sequential stream that runs concurrently with the location loads.  The values are unused.
+  float pf_sink = 0.f;
+  if (prefetch_rows > 0) {
+    const int first = ((tile - b * tiles_per_batch) * WPB + wave) * prefetch_rows;
+    for (int r = lane >> 1; r < prefetch_rows; r += 32) {
+      const int row = first + r;
+      const uint32_t off = row < d.S ? uint32_t(row) * uint32_t(pixel_bytes) + uint32_t(lane & 1) * (kRowBytes / 2)
+                                     : kTapOutside;
+      pf_sink += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, int(off), 0, 0));
+    }
+  }
 
   // ---- phase 1: one (query, sample) pair per lane and step --------------------
   const int pairs = QPW * LP;
@@ -177,29 +197,57 @@ msda_fwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
   const int pg = lane / (8 * QPW);
   const int q = q0 + qi;
 
-  const TV* head_base = value + (int64_t(b) * d.S * d.M + m) * D;
-  const uint32_t head_bytes = uint32_t((int64_t(d.S) * d.M - m) * kRowBytes);
-  const __amdgpu_buffer_rsrc_t rsrc = uniform_rsrc(head_base, head_bytes);
-
   const int per_group = LP / PG;  // host guarantees LP % PG == 0
   const uint4_t* g_off = s_off + qi * (LP + 1) + pg * per_group;
   const float4_t* g_wt = s_wt + qi * (LP + 1) + pg * per_group;
   const uint32_t lane_off = uint32_t(ch * kLaneBytes);
 
   float4_t acc = {0.f, 0.f, 0.f, 0.f};
-  constexpr int kUnroll = LP_T > 0 ? LP_T / PG : 1;
+  if constexpr (LP_T > 0 && QPW <= 4) {
+    // The gathers are latency-bound (two dependent HBM round trips per wave: locations, then
+    // taps), so put a whole batch of 4 samples = 16 row loads in flight before the first use.
+    constexpr int kPer = LP_T / PG;
+    constexpr int kBatch = kPer < 4 ? kPer : 4;
+#pragma unroll
+    for (int i0 = 0; i0 < kPer; i0 += kBatch) {
+      uint4_t o[kBatch];
+      float4_t w[kBatch];
+      float4_t v[kBatch][4];
+#pragma unroll
+      for (int j = 0; j < kBatch; ++j) { o[j] = g_off[i0 + j]; w[j] = g_wt[i0 + j]; }
+#pragma unroll
+      for (int j = 0; j < kBatch; ++j) {
+        v[j][0] = load_tap<TV>(rsrc, o[j].x + lane_off);
+        v[j][1] = load_tap<TV>(rsrc, o[j].y + lane_off);
+        v[j][2] = load_tap<TV>(rsrc, o[j].z + lane_off);
+        v[j][3] = load_tap<TV>(rsrc, o[j].w + lane_off);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < kBatch; ++j) {
+        acc += w[j].x * v[j][0];
+        acc += w[j].y * v[j][1];
+        acc += w[j].z * v[j][2];
+        acc += w[j].w * v[j][3];
+      }
+    }
+  } else {
+    // 8 queries per wave: the compiler's own schedule (8 loads in flight, 63 VGPRs, 8 waves per
+    // SIMD) measures better than wider batches on query-rich calls
+    constexpr int kUnroll = LP_T > 0 ? LP_T / PG : 1;
 #pragma unroll kUnroll
-  for (int i = 0; i < per_group; ++i) {
-    const uint4_t o = g_off[i];
-    const float4_t w = g_wt[i];
-    const float4_t v0 = load_tap<TV>(rsrc, o.x + lane_off);
-    const float4_t v1 = load_tap<TV>(rsrc, o.y + lane_off);
-    const float4_t v2 = load_tap<TV>(rsrc, o.z + lane_off);
-    const float4_t v3 = load_tap<TV>(rsrc, o.w + lane_off);
-    acc += w.x * v0;
-    acc += w.y * v1;
-    acc += w.z * v2;
-    acc += w.w * v3;
+    for (int i = 0; i < per_group; ++i) {
+      const uint4_t o = g_off[i];
+      const float4_t w = g_wt[i];
+      const float4_t v0 = load_tap<TV>(rsrc, o.x + lane_off);
+      const float4_t v1 = load_tap<TV>(rsrc, o.y + lane_off);
+      const float4_t v2 = load_tap<TV>(rsrc, o.z + lane_off);
+      const float4_t v3 = load_tap<TV>(rsrc, o.w + lane_off);
+      acc += w.x * v0;
+      acc += w.y * v1;
+      acc += w.z * v2;
+      acc += w.w * v3;
+    }
   }
 
   // sum the sample groups of a query (lanes that differ only in pg)
@@ -214,6 +262,8 @@ msda_fwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
     TV* o = out + ((int64_t(b) * d.Lq + q) * d.M + m) * D + ch * 4;
     store_row4<TV>(o, acc);
   }
+  // keeps the phase-0 loads from being eliminated; the values never reach the output
+  asm volatile("" ::"v"(pf_sink));
 }
 
 struct FwdCfg { int qpw; int wpb; };
@@ -222,13 +272,16 @@ static FwdCfg pick_fwd_cfg(const MsdaDims& d, int variant) {
   // variant: 0 auto; 2..5 force QPW = 8,4,2,1 with 4 waves/block; 12..15 the same with 1 wave/block
   const int LP = d.L * d.P;
   FwdCfg c{8, 4};
+  if (variant >= 20 && variant < 60) variant = (variant - 20) % 20;  // prefetch on/off wrappers
   if (variant >= 2 && variant <= 5) c = FwdCfg{8 >> (variant - 2), 4};
   else if (variant >= 12 && variant <= 15) c = FwdCfg{8 >> (variant - 12), 1};
   else {
+    // measured on MI355X (tools/time_variants.py): 4 queries per wave wins from the T=5 decoder
+    // call (1 500 rows) to the 360p encoder call (25 500 rows); one query per 8-lane group only
+    // pays on very large calls, where occupancy matters more than per-wave parallelism
     const int64_t rows = int64_t(d.B) * d.Lq;
-    // few rows: spread each query over more lanes so all 256 CUs get waves
-    if (rows * d.M <= 256 * 64) c = FwdCfg{2, 1};
-    else if (rows * d.M <= 256 * 256) c = FwdCfg{4, 2};
+    if (rows <= 4096) c = FwdCfg{4, 1};
+    else if (rows <= 262144) c = FwdCfg{4, 4};
     else c = FwdCfg{8, 4};
   }
   while (c.qpw < 8 && (LP % (8 / c.qpw)) != 0) c.qpw <<= 1;
@@ -238,9 +291,17 @@ static FwdCfg pick_fwd_cfg(const MsdaDims& d, int variant) {
 template <typename TV, typename TL, int QPW, int WPB>
 static int launch_fwd_cfg(const void* value, const int64_t* shapes, const int64_t* lsi,
                           const void* loc, const void* attn, void* out, const MsdaDims& d,
-                          hipStream_t stream) {
+                          int variant, hipStream_t stream) {
   const int LP = d.L * d.P;
   const int tiles_per_batch = (d.Lq + QPW * WPB - 1) / (QPW * WPB);
+  // phase 0 pays when the call has at least ~2 taps per row of the map (see the kernel);
+  // variants 20..39 force it on for A/B runs, 40..59 force it off
+  const bool dense = int64_t(d.Lq) * LP * 4 >= 2 * int64_t(d.S);
+  // Measured (tools/time_variants.py, T=5 decoder call): cold 10.5 vs 11.1 us with uniform
+  // locations, but 10.9 vs 9.3 us with model-like ones and 6.7 vs 5.7 us cache-warm -> off by default.
+  (void)dense;
+  const bool want_prefetch = (variant >= 20 && variant < 40);
+  const int prefetch_rows = want_prefetch ? (d.S + tiles_per_batch * WPB - 1) / (tiles_per_batch * WPB) : 0;
   const int64_t blocks = int64_t(d.B) * tiles_per_batch * d.M;
   if (blocks >= (int64_t(1) << 31)) {
     set_error("msda_forward: %lld workgroups exceed the grid limit", (long long)blocks);
@@ -250,11 +311,11 @@ static int launch_fwd_cfg(const void* value, const int64_t* shapes, const int64_
   if (LP == 16)
     hipLaunchKernelGGL((msda_fwd_d32_kernel<TV, TL, QPW, WPB, 16>), dim3(uint32_t(blocks)),
                        dim3(64 * WPB), lds, stream, (const TV*)value, shapes, lsi,
-                       (const TL*)loc, (const TL*)attn, (TV*)out, d, tiles_per_batch);
+                       (const TL*)loc, (const TL*)attn, (TV*)out, d, tiles_per_batch, prefetch_rows);
   else
     hipLaunchKernelGGL((msda_fwd_d32_kernel<TV, TL, QPW, WPB, 0>), dim3(uint32_t(blocks)),
                        dim3(64 * WPB), lds, stream, (const TV*)value, shapes, lsi,
-                       (const TL*)loc, (const TL*)attn, (TV*)out, d, tiles_per_batch);
+                       (const TL*)loc, (const TL*)attn, (TV*)out, d, tiles_per_batch, prefetch_rows);
   return check_launch("msda_fwd_d32");
 }
 
@@ -265,7 +326,7 @@ static int launch_fwd(const void* value, const int64_t* shapes, const int64_t* l
   const FwdCfg c = pick_fwd_cfg(d, variant);
 #define VNX_CASE(Q, W)                                                                       \
   if (c.qpw == Q && c.wpb == W)                                                              \
-    return launch_fwd_cfg<TV, TL, Q, W>(value, shapes, lsi, loc, attn, out, d, stream);
+    return launch_fwd_cfg<TV, TL, Q, W>(value, shapes, lsi, loc, attn, out, d, variant, stream);
   VNX_CASE(8, 4) VNX_CASE(4, 4) VNX_CASE(2, 4) VNX_CASE(1, 4)
   VNX_CASE(8, 1) VNX_CASE(4, 1) VNX_CASE(2, 1) VNX_CASE(1, 1)
   VNX_CASE(4, 2)

@@ -103,6 +103,19 @@ constexpr size_t kGvLdsBytes = size_t(kGvRowsMax) * 128 + size_t(kGvQcMax) * 128
                                size_t(kGvSamplesMax) * 32 + size_t(kGvRowsMax) * 12 + kGvWaves * 4 +
                                3 * kGvLevelsMax * 4;
 
+// Inclusive prefix sum over the 64 lanes of a wave in 6 DPP adds (no LDS round trips):
+// row_shr 1/2/4/8 scan each 16-lane row, row_bcast15 / row_bcast31 carry the row totals.
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+  int x = int(v);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);  // row_shr:1
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);  // row_shr:2
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false);  // row_shr:4
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false);  // row_shr:8
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1, 3
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2, 3
+  return uint32_t(x);
+}
+
 template <typename TV, typename TL>
 __global__ void __launch_bounds__(kGvThreads)
 msda_bwd_gv_tile_kernel(const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
@@ -148,6 +161,7 @@ msda_bwd_gv_tile_kernel(const int64_t* __restrict__ shapes, const int64_t* __res
     meta[3 * tid + 2] = int(lsi[tid]);
   }
   for (int i = tid; i < 2 * kGvRowsMax; i += kGvThreads) cnt2[i] = 0;
+  if (tid == 0) wtot[0] = 0;
   __syncthreads();
 
   // ---- which (level, pixel range) is this unit? ------------------------------------------------
@@ -239,30 +253,17 @@ msda_bwd_gv_tile_kernel(const int64_t* __restrict__ shapes, const int64_t* __res
     if (chunk + 1 < n_chunks) { prefetch_rows(chunk + 1); prefetch_sample(chunk + 1); }
     __syncthreads();
 
-    // ---- exclusive scan of the row counts -> segment offsets (wave 0, 6 rows per lane) -------
-    if (wave == 0) {
-      constexpr int kPer = (kGvRowsMax + 63) / 64;
-      uint32_t c[kPer];
-      uint32_t sum = 0;
-#pragma unroll
-      for (int j = 0; j < kPer; ++j) {
-        const int r = lane * kPer + j;
-        c[j] = r < rows ? cnt[r] : 0u;
-        sum += c[j];
-      }
-      uint32_t incl = sum;
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t up = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += up;
-      }
-      uint32_t run = incl - sum;
-#pragma unroll
-      for (int j = 0; j < kPer; ++j) {
-        const int r = lane * kPer + j;
-        if (r < rows) offs[r] = run;
-        run += c[j];
-      }
+    // ---- row counts -> segment offsets: DPP wave scan + one LDS allocation per wave --------
+    // (segments need not be in row order, only disjoint)
+    {
+      const uint32_t my_cnt = tid < rows ? cnt[tid] : 0u;
+      const uint32_t incl = wave_inclusive_scan(my_cnt);
+      const uint32_t wave_total = uint32_t(__builtin_amdgcn_readlane(int(incl), 63));
+      uint32_t base = 0;
+      if (lane == 0 && wave_total != 0)
+        base = __hip_atomic_fetch_add(wtot, wave_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      base = uint32_t(__builtin_amdgcn_readfirstlane(int(base)));
+      if (tid < rows) offs[tid] = base + incl - my_cnt;
     }
     __syncthreads();
 
@@ -274,11 +275,22 @@ msda_bwd_gv_tile_kernel(const int64_t* __restrict__ shapes, const int64_t* __res
     __syncthreads();
 
     // ---- 8-lane groups own rows: sum the row's segment in registers, one slab update ----------
-    for (int row = grp; row < rows; row += kGvGroups) {
-      const uint32_t n = ablate == 1 ? 0u : cnt[row];
-      cnt_next[row] = 0;  // the other parity's counters are idle during this phase
+    if (tid == 0) wtot[0] = 0;  // the allocator is idle from here to the next chunk's scan
+    constexpr int kRpg = (kGvRowsMax + kGvGroups - 1) / kGvGroups;
+    uint32_t rn[kRpg], ro[kRpg];
+#pragma unroll
+    for (int k = 0; k < kRpg; ++k) {  // this group's rows: counts and offsets in one batch
+      const int row = grp + k * kGvGroups;
+      rn[k] = (row < rows && ablate != 1) ? cnt[row] : 0u;
+      ro[k] = row < rows ? offs[row] : 0u;
+      if (row < rows) cnt_next[row] = 0;  // the other parity's counters are idle during this phase
+    }
+#pragma unroll
+    for (int k = 0; k < kRpg; ++k) {
+      const int row = grp + k * kGvGroups;
+      const uint32_t n = rn[k];
       if (n == 0) continue;
-      const uint2_t* seg = list + offs[row];
+      const uint2_t* seg = list + ro[k];
       const float4_t* g4 = reinterpret_cast<const float4_t*>(grows) + ch4;
       float4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
       uint32_t i = 0;
