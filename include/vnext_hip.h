@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define VNX_ABI_VERSION 2
+#define VNX_ABI_VERSION 3
 
 /* element types */
 enum {
@@ -128,6 +128,27 @@ int vnx_msda_backward(int value_dtype, int loc_dtype,
                       int num_levels, int num_query, int num_point, int flags,
                       void* workspace, size_t workspace_bytes,
                       void* hip_stream);
+
+/*
+ * CondInst-style dynamic mask head, forward (per-instance 1x1 conv stack 10->8->8->1 on
+ * [relative coordinates | 8 mask features], ReLU between, then the x2 "aligned bilinear"
+ * up-sampling), fused into one kernel.  Replaces the op chain
+ *   CondInst_segm.dynamic_mask_with_coords + mask_heads_forward + parse_dynamic_params +
+ *   compute_locations + aligned_bilinear
+ *   (projects/SeqFormer/seqformer/models/segmentation_condInst.py:425-493, 404-422, 614-637,
+ *    665-678, 640-662; same code in projects/IDOL/idol/models/segmentation_condInst.py:398-468).
+ *   mask_feats       [num_images, channels=8, height, width]          (stride-8 mask features)
+ *   reference_points [num_insts, 2]   (x, y) in image pixels
+ *   params           [num_insts, num_params=169]  split [w0(80) w1(64) w2(8) b0(8) b1(8) b2(1)]
+ *   inst_image       [num_insts] int32: the image each instance belongs to (the reference's
+ *                    `num_insts` list, expanded; DEVICE memory)
+ *   out              [num_insts, 2*height, 2*width], fully written
+ * `stride` is mask_feat_stride (8): pixel centres are x*stride + stride/2.
+ */
+int vnx_dynamic_mask_head_forward(int dtype, const void* mask_feats, const void* reference_points,
+                                  const void* params, const int32_t* inst_image, void* out,
+                                  int num_images, int channels, int height, int width,
+                                  int num_insts, int num_params, int stride, void* hip_stream);
 
 /*
  * Kernel selection override for A/B measurements and tests (process-wide):

@@ -1,0 +1,96 @@
+"""Dynamic mask head: the numpy oracle against outputs of the reference's own
+function bodies (CPU), and the fused HIP kernel against both (GPU)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN_DIR
+from oracle import heads_oracle as H
+
+CASES = sorted(os.path.basename(p)[11:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "heads_mask_*.npz")))
+
+
+def load(name):
+    return dict(np.load(os.path.join(GOLDEN_DIR, f"heads_mask_{name}.npz")))
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_matches_reference_functions(name):
+    g = load(name)
+    out = H.dynamic_mask_head(g["feats"], g["ref"], g["params"], list(g["num_insts"]))
+    np.testing.assert_allclose(out, g["out"], rtol=1e-12, atol=1e-12)
+
+
+def test_upsampling_closed_form_is_the_pad_interpolate_crop_chain():
+    x = torch.randn(2, 1, 5, 9, dtype=torch.float64)
+    t = torch.nn.functional.pad(x, (0, 1, 0, 1), mode="replicate")
+    t = torch.nn.functional.interpolate(t, size=(11, 19), mode="bilinear", align_corners=True)
+    t = torch.nn.functional.pad(t, (1, 0, 1, 0), mode="replicate")[:, :, :10, :18]
+    np.testing.assert_allclose(H.aligned_bilinear_x2(x.numpy()), t.numpy(), rtol=1e-13, atol=1e-13)
+
+
+def test_cpu_tensors_are_rejected():
+    from vnext_amd.heads import dynamic_mask_with_coords
+    with pytest.raises(RuntimeError, match="no CPU implementation"):
+        dynamic_mask_with_coords(torch.zeros(1, 8, 2, 2), torch.zeros(1, 1, 2), torch.zeros(1, 1, 169), [1], 8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_kernel_matches_reference_outputs(name):
+    from vnext_amd.heads import dynamic_mask_with_coords
+    g = load(name)
+    dev = "cuda:0"
+    with torch.no_grad():
+        out = dynamic_mask_with_coords(torch.from_numpy(g["feats"]).float().to(dev),
+                                       torch.from_numpy(g["ref"]).float().to(dev)[None],
+                                       torch.from_numpy(g["params"]).float().to(dev)[None],
+                                       [int(n) for n in g["num_insts"]], 8)
+    torch.cuda.synchronize()
+    assert tuple(out.shape) == (1,) + g["out"].shape
+    # fp32 inputs: compare with the oracle run on the same fp32-rounded inputs
+    ref = H.dynamic_mask_head(g["feats"].astype(np.float32).astype(np.float64),
+                              g["ref"].astype(np.float32).astype(np.float64),
+                              g["params"].astype(np.float32).astype(np.float64), list(g["num_insts"]))
+    scale = float(np.abs(ref).max())
+    np.testing.assert_allclose(out[0].double().cpu().numpy(), ref, rtol=0, atol=1e-5 * scale)
+    np.testing.assert_allclose(out[0].double().cpu().numpy(), g["out"], rtol=0, atol=1e-4 * scale)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H_,W_,n", [(48, 80, 300), (92, 160, 37), (1, 130, 3), (17, 1, 2)])
+def test_kernel_at_frame_sizes(H_, W_, n):
+    """360p / 720p frame sizes (BASELINE configs): a sample of instances against the oracle,
+    and linearity in the last layer's bias (adds a constant to every logit)."""
+    from vnext_amd.heads import dynamic_mask_with_coords
+    gen = torch.Generator().manual_seed(H_ * 1000 + W_)
+    feats = torch.randn(2, 8, H_, W_, generator=gen)
+    counts = [n, max(n // 2, 1)]
+    n_all = sum(counts)
+    ref = torch.rand(1, n_all, 2, generator=gen) * torch.tensor([W_ * 8.0, H_ * 8.0])
+    params = 0.3 * torch.randn(1, n_all, 169, generator=gen)
+    with torch.no_grad():
+        out = dynamic_mask_with_coords(feats.cuda(), ref.cuda(), params.cuda(), counts, 8)
+        p2 = params.clone()
+        p2[..., 168] += 1.5
+        out2 = dynamic_mask_with_coords(feats.cuda(), ref.cuda(), p2.cuda(), counts, 8)
+    assert out.shape == (1, n_all, 2 * H_, 2 * W_)
+    assert float((out2 - out - 1.5).abs().max()) <= 1e-4 * max(1.0, float(out.abs().max()))
+    pick = sorted(set([0, n - 1, n, n_all - 1]))
+    img_of = [0] * counts[0] + [1] * counts[1]
+    for j in pick:
+        one = H.dynamic_mask_head(feats[img_of[j]:img_of[j] + 1].double().numpy(), ref[0, j:j + 1].double().numpy(),
+                                  params[0, j:j + 1].double().numpy(), [1])
+        scale = max(1e-6, float(np.abs(one).max()))
+        np.testing.assert_allclose(out[0, j].double().cpu().numpy(), one[0], rtol=0, atol=2e-5 * scale)
+
+
+@pytest.mark.gpu
+def test_gradients_are_refused_loudly():
+    from vnext_amd.heads import dynamic_mask_with_coords
+    p = torch.zeros(1, 1, 169, device="cuda:0", requires_grad=True)
+    with pytest.raises(NotImplementedError, match="backward is not built"):
+        dynamic_mask_with_coords(torch.zeros(1, 8, 2, 2, device="cuda:0"), torch.zeros(1, 1, 2, device="cuda:0"), p, [1], 8)

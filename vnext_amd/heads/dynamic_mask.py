@@ -1,0 +1,67 @@
+"""Dynamic mask head on the fused HIP kernel.
+
+`dynamic_mask_with_coords` keeps the argument meaning of the reference method
+`CondInst_segm.dynamic_mask_with_coords(mask_feats, reference_points, mask_head_params,
+num_insts, mask_feat_stride, rel_coord=True)`
+(projects/SeqFormer/seqformer/models/segmentation_condInst.py:425-493; IDOL :398-468) and
+returns the same `[1, sum(num_insts), H/4, W/4]` logits.  The reference materialises a
+`[1, n*10, H*W]` input and runs three grouped convolutions and two pads + an interpolate;
+here one kernel reads the 8-channel features and the 169 parameters per instance and
+writes the logits -- see vnext_amd/csrc/mask_head.hip.
+
+Forward only for now (the inference path: 300 instances per frame); asking for gradients
+raises instead of silently falling back to a PyTorch op chain.
+"""
+from __future__ import annotations
+
+import torch
+
+from .. import _lib
+
+NUM_PARAMS = 169          # (8+2)*8 + 8*8 + 8 weights, 8 + 8 + 1 biases
+MASK_OUT_STRIDE = 4       # segmentation_condInst.py:40
+
+
+def _instance_image_index(num_insts, device):
+    if len(set(num_insts)) == 1:  # the inference case: no host->device copy at all
+        n = int(num_insts[0])
+        return (torch.arange(n * len(num_insts), device=device, dtype=torch.int32) // max(n, 1)).contiguous()
+    idx = torch.repeat_interleave(torch.arange(len(num_insts), dtype=torch.int32),
+                                  torch.as_tensor(num_insts, dtype=torch.int64))
+    return idx.to(device, non_blocking=True)
+
+
+def dynamic_mask_with_coords(mask_feats, reference_points, mask_head_params, num_insts,
+                             mask_feat_stride, rel_coord=True):
+    """mask_feats [N, 8, H, W]; reference_points [1, sum n, 2] (image pixels);
+    mask_head_params [1, sum n, 169]; num_insts: instances per image.
+    -> [1, sum n, 2H, 2W]"""
+    if not mask_feats.is_cuda:
+        raise RuntimeError("dynamic_mask_with_coords: no CPU implementation (HIP library only)")
+    if not rel_coord:
+        raise NotImplementedError("dynamic mask head is built with rel_coord=True (the reference's setting)")
+    if mask_feat_stride % MASK_OUT_STRIDE != 0 or mask_feat_stride // MASK_OUT_STRIDE != 2:
+        raise NotImplementedError("dynamic mask head is built for mask_feat_stride / mask_out_stride == 2")
+    if any(t.requires_grad for t in (mask_feats, reference_points, mask_head_params)) and torch.is_grad_enabled():
+        raise NotImplementedError("dynamic mask head: backward is not built yet; call under torch.no_grad()")
+    N, C, H, W = mask_feats.shape
+    n_all = reference_points.shape[1]
+    if sum(int(n) for n in num_insts) != n_all or len(num_insts) != N or mask_head_params.shape[1] != n_all:
+        raise RuntimeError("dynamic_mask_with_coords: num_insts does not match the instance tensors")
+    if mask_feats.dtype != torch.float32:
+        raise RuntimeError(f"dynamic mask head: float32 only for now (got {mask_feats.dtype})")
+    feats = mask_feats.contiguous()
+    # the reference rounds the relative coordinates to fp32 (`.float()`, :447)
+    ref = reference_points.reshape(n_all, 2).to(torch.float32).contiguous()
+    params = mask_head_params.reshape(n_all, -1).to(torch.float32).contiguous()
+    out = torch.empty((1, n_all, 2 * H, 2 * W), dtype=torch.float32, device=feats.device)
+    if n_all == 0:
+        return out
+    inst_image = _instance_image_index([int(n) for n in num_insts], feats.device)
+    with torch.cuda.device(feats.device):
+        st = _lib.lib().vnx_dynamic_mask_head_forward(
+            _lib.VNX_F32, feats.data_ptr(), ref.data_ptr(), params.data_ptr(), inst_image.data_ptr(),
+            out.data_ptr(), N, C, H, W, n_all, params.shape[1], int(mask_feat_stride),
+            torch.cuda.current_stream(feats.device).cuda_stream)
+    _lib.check(st)
+    return out

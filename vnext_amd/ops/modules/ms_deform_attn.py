@@ -1,0 +1,189 @@
+"""`MSDeformAttn` modules of both projects, on the MI355X op.
+
+Two classes, because the reference has two (same name, different forward):
+
+* `MSDeformAttnIDOL`  <- projects/IDOL/idol/models/ops/modules/ms_deform_attn.py:30-116
+  `forward(query, reference_points, input_flatten, spatial_shapes, level_start_index,
+  padding_mask) -> (output, sampling_locations, attention_weights)`
+* `MSDeformAttnSeqFormer` <- projects/SeqFormer/seqformer/models/ops/modules/ms_deform_attn.py:32-217
+  `mode='encode'|'decode'`, clip tensors `[N, T, ...]`, extra `output_proj_box`.
+
+Parameter names, shapes and initialisation are the reference's (checkpoints load
+unchanged).  What differs is the mapping onto the machine: the
+reference loops over the T frames of a clip in Python and launches the op once per frame
+(`:107-120, :153-167, :198-211`); here the frame axis is folded into the op's batch axis, so
+a layer is ONE launch whatever T is, and no per-frame `contiguous()` / `cat` copies are made.
+The arithmetic that builds `sampling_locations` keeps the reference's expression order so
+fp32 results match bit for bit up to the op.
+"""
+from __future__ import annotations
+
+import math
+import warnings
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+from torch.nn.init import constant_, xavier_uniform_
+
+from ..functions import MSDeformAttnFunction
+
+
+def _is_power_of_2(n):
+    if (not isinstance(n, int)) or (n < 0):
+        raise ValueError("invalid input for _is_power_of_2: {} (type: {})".format(n, type(n)))
+    return (n & (n - 1) == 0) and n != 0
+
+
+class _MSDeformAttnBase(nn.Module):
+    def __init__(self, d_model=256, n_levels=4, n_heads=8, n_points=4):
+        super().__init__()
+        if d_model % n_heads != 0:
+            raise ValueError("d_model must be divisible by n_heads, but got {} and {}".format(d_model, n_heads))
+        if not _is_power_of_2(d_model // n_heads):
+            warnings.warn("MSDeformAttn: a power-of-two head dimension (32 for the tuned kernels) is faster.")
+        self.im2col_step = 64
+        self.d_model = d_model
+        self.n_levels = n_levels
+        self.n_heads = n_heads
+        self.n_points = n_points
+        self.sampling_offsets = nn.Linear(d_model, n_heads * n_levels * n_points * 2)
+        self.attention_weights = nn.Linear(d_model, n_heads * n_levels * n_points)
+        self.value_proj = nn.Linear(d_model, d_model)
+        self.output_proj = nn.Linear(d_model, d_model)
+
+    def _reset_parameters(self):
+        # reference :62-75 (IDOL) / :65-80 (SeqFormer): zero offset weights, bias = the head's unit
+        # direction (max-norm normalised) times (k+1); uniform attention; xavier projections
+        constant_(self.sampling_offsets.weight.data, 0.)
+        thetas = torch.arange(self.n_heads, dtype=torch.float32) * (2.0 * math.pi / self.n_heads)
+        grid_init = torch.stack([thetas.cos(), thetas.sin()], -1)
+        grid_init = (grid_init / grid_init.abs().max(-1, keepdim=True)[0]).view(
+            self.n_heads, 1, 1, 2).repeat(1, self.n_levels, self.n_points, 1)
+        for i in range(self.n_points):
+            grid_init[:, :, i, :] *= i + 1
+        with torch.no_grad():
+            self.sampling_offsets.bias = nn.Parameter(grid_init.view(-1))
+        constant_(self.attention_weights.weight.data, 0.)
+        constant_(self.attention_weights.bias.data, 0.)
+        xavier_uniform_(self.value_proj.weight.data)
+        constant_(self.value_proj.bias.data, 0.)
+        xavier_uniform_(self.output_proj.weight.data)
+        constant_(self.output_proj.bias.data, 0.)
+
+    # -- shared pieces ------------------------------------------------------------------------
+    def _project_value(self, input_flatten, input_padding_mask):
+        value = self.value_proj(input_flatten)
+        if input_padding_mask is not None:
+            value = value.masked_fill(input_padding_mask[..., None], float(0))
+        return value
+
+    def _offsets_and_weights(self, query):
+        lead = query.shape[:-1]
+        offsets = self.sampling_offsets(query).view(*lead, self.n_heads, self.n_levels, self.n_points, 2)
+        weights = self.attention_weights(query).view(*lead, self.n_heads, self.n_levels * self.n_points)
+        weights = F.softmax(weights, -1).view(*lead, self.n_heads, self.n_levels, self.n_points)
+        return offsets, weights
+
+    def _locations(self, reference_points, offsets, spatial_shapes):
+        """reference_points [..., Lq, L, 2|4] and offsets [..., Lq, M, L, P, 2] broadcast over
+        their leading axes (the reference's expressions, IDOL :102-108)."""
+        if reference_points.shape[-1] == 2:
+            offset_normalizer = torch.stack([spatial_shapes[..., 1], spatial_shapes[..., 0]], -1)
+            return reference_points[..., :, None, :, None, :] + offsets / offset_normalizer[None, None, None, :, None, :]
+        if reference_points.shape[-1] == 4:
+            return reference_points[..., :, None, :, None, :2] \
+                + offsets / self.n_points * reference_points[..., :, None, :, None, 2:] * 0.5
+        raise ValueError("Last dim of reference_points must be 2 or 4, but get {} instead.".format(
+            reference_points.shape[-1]))
+
+
+class MSDeformAttnIDOL(_MSDeformAttnBase):
+    """IDOL's module (no frame axis)."""
+
+    def __init__(self, d_model=256, n_levels=4, n_heads=8, n_points=4):
+        super().__init__(d_model, n_levels, n_heads, n_points)
+        self._reset_parameters()
+
+    def forward(self, query, reference_points, input_flatten, input_spatial_shapes,
+                input_level_start_index, input_padding_mask=None):
+        N, Len_q, _ = query.shape
+        N, Len_in, _ = input_flatten.shape
+        assert (input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum() == Len_in
+        value = self._project_value(input_flatten, input_padding_mask)
+        value = value.view(N, Len_in, self.n_heads, self.d_model // self.n_heads)
+        sampling_offsets, attention_weights = self._offsets_and_weights(query)
+        sampling_locations = self._locations(reference_points, sampling_offsets, input_spatial_shapes)
+        output = MSDeformAttnFunction.apply(value, input_spatial_shapes, input_level_start_index,
+                                            sampling_locations.contiguous(), attention_weights,
+                                            self.im2col_step)
+        return self.output_proj(output), sampling_locations, attention_weights
+
+
+class MSDeformAttnSeqFormer(_MSDeformAttnBase):
+    """SeqFormer's module: clip tensors [N, T, ...]; T is folded into the op batch."""
+
+    def __init__(self, d_model=256, n_levels=4, n_heads=8, n_points=4, mode='encode'):
+        super().__init__(d_model, n_levels, n_heads, n_points)
+        self.mode = mode
+        # present in the reference whatever the mode, and NOT re-initialised by
+        # _reset_parameters (SeqFormer :63,77-80) -- kept so state dicts round-trip
+        self.output_proj_box = nn.Linear(d_model, d_model)
+        self._reset_parameters()
+
+    def forward(self, query, query_box, reference_points, input_flatten, input_spatial_shapes,
+                input_level_start_index, input_padding_mask=None):
+        if self.mode == 'encode':
+            return self.encode_forward(query, reference_points, input_flatten, input_spatial_shapes,
+                                       input_level_start_index, input_padding_mask)
+        elif self.mode == 'decode':
+            return self.decode_forward(query, query_box, reference_points, input_flatten,
+                                       input_spatial_shapes, input_level_start_index, input_padding_mask)
+
+    def _apply_folded(self, value, locations, weights, shapes, level_start_index):
+        """value [N,T,S,M,D], locations [N,T,Lq,M,L,P,2], weights [N,T,Lq,M,L,P] -> [N,T,Lq,C]"""
+        N, T = value.shape[:2]
+        out = MSDeformAttnFunction.apply(
+            value.reshape(N * T, *value.shape[2:]), shapes, level_start_index,
+            locations.reshape(N * T, *locations.shape[2:]).contiguous(),
+            weights.reshape(N * T, *weights.shape[2:]).contiguous(), self.im2col_step)
+        return out.view(N, T, out.shape[1], out.shape[2])
+
+    def encode_forward(self, query, reference_points, input_flatten, input_spatial_shapes,
+                       input_level_start_index, input_padding_mask=None):
+        N, nf, Len_q, _ = query.shape
+        N, nf, Len_in, _ = input_flatten.shape
+        assert (input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum() == Len_in
+        value = self._project_value(input_flatten, input_padding_mask)
+        value = value.view(N, nf, Len_in, self.n_heads, self.d_model // self.n_heads)
+        sampling_offsets, attention_weights = self._offsets_and_weights(query)  # [N,nf,Lq,M,L,P(,2)]
+        if reference_points.shape[-1] != 2:
+            raise ValueError('Last dim of reference_points must be 2 or 4, but get {} instead.'.format(
+                reference_points.shape[-1]))
+        # the encoder's reference points are shared by the frames: [N, Lq, L, 2] (SeqFormer :107-112)
+        locations = self._locations(reference_points[:, None], sampling_offsets, input_spatial_shapes)
+        sampled = self._apply_folded(value, locations, attention_weights, input_spatial_shapes,
+                                     input_level_start_index)
+        return self.output_proj(sampled)
+
+    def decode_forward(self, query, query_box, reference_points, input_flatten, input_spatial_shapes,
+                       input_level_start_index, input_padding_mask=None):
+        N, nf, Len_in, _ = input_flatten.shape
+        assert (input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum() == Len_in
+        value = self._project_value(input_flatten, input_padding_mask)
+        value = value.view(N, nf, Len_in, self.n_heads, self.d_model // self.n_heads)
+        sampling_offsets, attention_weights = self._offsets_and_weights(query_box)
+        if query_box.dim() == 3:
+            # first decoder layer: one set of offsets / weights per query, shared by the frames
+            # (SeqFormer :128-171); reference_points are per frame [N, nf, Lq, L, 2|4]
+            locations = self._locations(reference_points, sampling_offsets[:, None], input_spatial_shapes)
+            weights = attention_weights[:, None].expand(N, nf, *attention_weights.shape[1:])
+        else:
+            assert query_box.dim() == 4  # [N, nf, Lq, C]: per-frame box queries (SeqFormer :172-217)
+            locations = self._locations(reference_points, sampling_offsets, input_spatial_shapes)
+            weights = attention_weights
+        sampled = self._apply_folded(value, locations, weights, input_spatial_shapes, input_level_start_index)
+        output = self.output_proj(sampled)
+        output_box = self.output_proj_box(sampled)
+        # the reference returns the LAST frame's locations (the loop variable, :171,217)
+        return output, output_box, locations[:, -1], attention_weights
