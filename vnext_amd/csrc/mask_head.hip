@@ -9,13 +9,14 @@
 //   :640-662  "aligned bilinear" x2 up-sampling (replicate pad, align_corners interpolate, pad, crop).
 // Here it is one kernel: nothing but the [n, 2H, 2W] logits is ever written.
 //
-// Mapping: one wave per (instance, strip of 63 columns x R rows).  The instance is wave-uniform,
-// so its 169 parameters travel in SGPRs (scalar loads) and the three layers are plain v_fma
-// chains with scalar operands; the 8 features of a pixel are 8 coalesced loads; relative
+// Mapping: one wave per (instance, strip of 63 columns x R rows).  The instance is wave-uniform:
+// its 169 parameters are fetched with three vector loads, kept across the lanes and broadcast
+// into SGPRs with v_readlane as the three layers (v_pk_fma_f32 chains) consume them; the 8 features of a pixel are 8 coalesced loads; relative
 // coordinates are computed, never stored.  The up-sampling needs each pixel's left / upper
-// neighbours: the wave walks its strip row by row keeping the previous row's logit in a register,
-// and takes the left neighbour from the lane below with one DPP move; lane 0 and the first row are
-// a one-pixel halo (computed, not stored), so no LDS and no barrier is used at all.
+// neighbours: the strip's rows (and one halo row above) are all held in registers, the upper
+// neighbour is the previous row's register and the left neighbour comes from the lane below with
+// one DPP move; lane 0 and the first row are a one-pixel halo (computed, not stored), so no LDS
+// and no barrier is used at all.
 // out[2y  ][2x] = (a+b+c+d)/4   out[2y  ][2x+1] = (b+d)/2      a = in[y-1][x-1]  b = in[y-1][x]
 // out[2y+1][2x] = (c+d)/2       out[2y+1][2x+1] = d            c = in[y  ][x-1]  d = in[y  ][x]
 // with indices clamped at 0 -- the closed form of the reference's pad/interpolate/pad/crop.
@@ -28,7 +29,7 @@ constexpr int kMhChannels = 8;    // mask feature channels (hidden_dim / 32)
 constexpr int kMhHidden = 8;      // dynamic_mask_channels
 constexpr int kMhParams = (kMhChannels + 2) * kMhHidden + kMhHidden * kMhHidden + kMhHidden + kMhHidden + kMhHidden + 1;
 constexpr int kMhStripW = 63;     // stored columns per wave (64 lanes - 1 halo lane)
-constexpr int kMhStripH = 8;      // stored rows per wave
+constexpr int kMhStripH = 5;      // stored rows per wave (+1 halo row, all held in registers)
 static_assert(kMhParams == 169, "parameter vector layout");
 
 typedef float float2_t __attribute__((ext_vector_type(2)));
@@ -56,8 +57,15 @@ dynamic_mask_head_kernel(const float* __restrict__ feats, const float* __restric
   const int xc = x < 0 ? 0 : (x > W - 1 ? W - 1 : x);
   const int y0 = sy * kMhStripH;
 
-  const float* P = params + int64_t(j) * kMhParams;  // wave-uniform -> scalar loads
-  const float* W0 = P, *W1 = P + 80, *W2 = P + 144, *B0 = P + 152, *B1 = P + 160, *B2 = P + 168;
+  // The instance's 169 parameters are wave-uniform: scalar loads, SGPR operands of the packed
+  // FMAs.  Alternatives measured on MI355X at 300 instances x 48x80 (tools/mask_head_scaling.py):
+  // lane-parked copy + v_readlane 24.0 us (617 readlanes + 221 s_nops per wave), LDS broadcast
+  // reads 31.6 us (the scheduler hoists all 169 reads: 256 VGPRs or spills), this form 24-26 us.
+  // The kernel is VALU-issue bound (~1300 issued instructions per wave at ~4 clk each), not
+  // memory bound; the HBM roofline (18.4 MB of logits, ~3 us) is 8x away.
+  const float* P = params + int64_t(j) * kMhParams;
+  auto param = [&](int k) -> float { return P[k]; };
+  constexpr int W0 = 0, W1 = 80, W2 = 144, B0 = 152, B1 = 160, B2 = 168;
   const float refx = ref[2 * j], refy = ref[2 * j + 1];
   const int img = inst_image[j];
   const float* F = feats + int64_t(img) * kMhChannels * H * W;
@@ -65,43 +73,88 @@ dynamic_mask_head_kernel(const float* __restrict__ feats, const float* __restric
   const float relx = refx - (float(xc * stride) + half);
 
   float* O = out + int64_t(j) * (2 * H) * (2 * W);
-  float prev = 0.f;
-  for (int r = -1; r < kMhStripH; ++r) {  // r = -1: the halo row above the strip
-    const int y = y0 + r;
-    if (y >= H) break;
-    const int yc = y < 0 ? 0 : y;
-    const float rely = refy - (float(yc * stride) + half);
-    float x0[kMhChannels + 2];
-    x0[0] = relx; x0[1] = rely;
-#pragma unroll
-    for (int c = 0; c < kMhChannels; ++c) x0[2 + c] = F[(int64_t(c) * H + yc) * W + xc];
-    float x1[kMhHidden], x2[kMhHidden];
-#pragma unroll
-    for (int o = 0; o < kMhHidden; ++o) {
-      float a = B0[o];
-#pragma unroll
-      for (int i = 0; i < kMhChannels + 2; ++i) a = fmaf(W0[o * (kMhChannels + 2) + i], x0[i], a);
-      x1[o] = fmaxf(a, 0.f);
-    }
-#pragma unroll
-    for (int o = 0; o < kMhHidden; ++o) {
-      float a = B1[o];
-#pragma unroll
-      for (int i = 0; i < kMhHidden; ++i) a = fmaf(W1[o * kMhHidden + i], x1[i], a);
-      x2[o] = fmaxf(a, 0.f);
-    }
-    float cur = B2[0];
-#pragma unroll
-    for (int i = 0; i < kMhHidden; ++i) cur = fmaf(W2[i], x2[i], cur);
 
+  // All rows of the strip (plus the halo row above it) live in registers, so every one of the
+  // 169 parameters is fetched (scalar load) exactly once per wave and the 8 x (R+1) feature
+  // loads are all in flight together.  Rows are processed in PAIRS held as float2 so the layer
+  // arithmetic compiles to v_pk_fma_f32 (two FMAs per issued instruction): the kernel is
+  // VALU-issue bound (PMC: SQ_ACTIVE_INST_VALU ~ 80 % of the kernel), not memory bound.
+  constexpr int R1 = kMhStripH + 1;        // rows computed
+  static_assert(R1 % 2 == 0, "rows are processed in pairs");
+  constexpr int RP = R1 / 2;
+  float2_t x0[RP][kMhChannels + 2];
+#pragma unroll
+  for (int p = 0; p < RP; ++p) {
+    float v[2][kMhChannels + 2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int y = y0 + 2 * p + h - 1;
+      const int yc = y < 0 ? 0 : (y > H - 1 ? H - 1 : y);
+      v[h][0] = relx;
+      v[h][1] = refy - (float(yc * stride) + half);
+#pragma unroll
+      for (int c = 0; c < kMhChannels; ++c) v[h][2 + c] = F[(int64_t(c) * H + yc) * W + xc];
+    }
+#pragma unroll
+    for (int i = 0; i < kMhChannels + 2; ++i) x0[p][i] = float2_t{v[0][i], v[1][i]};
+  }
+  const float2_t zero2 = {0.f, 0.f};
+  float2_t x1[RP][kMhHidden];
+#pragma unroll
+  for (int o = 0; o < kMhHidden; ++o) {
+    float w[kMhChannels + 2];
+#pragma unroll
+    for (int i = 0; i < kMhChannels + 2; ++i) w[i] = param(W0 + o * (kMhChannels + 2) + i);
+    const float bias = param(B0 + o);
+#pragma unroll
+    for (int p = 0; p < RP; ++p) {
+      float2_t a = {bias, bias};
+#pragma unroll
+      for (int i = 0; i < kMhChannels + 2; ++i) a = __builtin_elementwise_fma(float2_t{w[i], w[i]}, x0[p][i], a);
+      x1[p][o] = __builtin_elementwise_max(a, zero2);
+    }
+  }
+  float2_t x2[RP][kMhHidden];
+#pragma unroll
+  for (int o = 0; o < kMhHidden; ++o) {
+    float w[kMhHidden];
+#pragma unroll
+    for (int i = 0; i < kMhHidden; ++i) w[i] = param(W1 + o * kMhHidden + i);
+    const float bias = param(B1 + o);
+#pragma unroll
+    for (int p = 0; p < RP; ++p) {
+      float2_t a = {bias, bias};
+#pragma unroll
+      for (int i = 0; i < kMhHidden; ++i) a = __builtin_elementwise_fma(float2_t{w[i], w[i]}, x1[p][i], a);
+      x2[p][o] = __builtin_elementwise_max(a, zero2);
+    }
+  }
+  float logit[R1];
+  {
+    float w[kMhHidden];
+#pragma unroll
+    for (int i = 0; i < kMhHidden; ++i) w[i] = param(W2 + i);
+    const float bias = param(B2);
+#pragma unroll
+    for (int p = 0; p < RP; ++p) {
+      float2_t a = {bias, bias};
+#pragma unroll
+      for (int i = 0; i < kMhHidden; ++i) a = __builtin_elementwise_fma(float2_t{w[i], w[i]}, x2[p][i], a);
+      logit[2 * p] = a.x;
+      logit[2 * p + 1] = a.y;
+    }
+  }
+#pragma unroll
+  for (int r = 1; r < R1; ++r) {
+    const int y = y0 + r - 1;
+    const float cur = logit[r], prev = logit[r - 1];
     const float left = lane_below(cur), prev_left = lane_below(prev);
-    if (r >= 0 && lane > 0 && x < W) {
+    if (y < H && lane > 0 && x < W) {
       const float2_t top = {0.25f * ((prev_left + prev) + (left + cur)), 0.5f * (prev + cur)};
       const float2_t bot = {0.5f * (left + cur), cur};
       *reinterpret_cast<float2_t*>(O + int64_t(2 * y) * (2 * W) + 2 * x) = top;
       *reinterpret_cast<float2_t*>(O + int64_t(2 * y + 1) * (2 * W) + 2 * x) = bot;
     }
-    prev = cur;
   }
 }
 

@@ -22,10 +22,20 @@ NUM_PARAMS = 169          # (8+2)*8 + 8*8 + 8 weights, 8 + 8 + 1 biases
 MASK_OUT_STRIDE = 4       # segmentation_condInst.py:40
 
 
+_INDEX_CACHE = {}
+
+
 def _instance_image_index(num_insts, device):
-    if len(set(num_insts)) == 1:  # the inference case: no host->device copy at all
+    if len(set(num_insts)) == 1:  # the inference case: built once per (count, images, device)
         n = int(num_insts[0])
-        return (torch.arange(n * len(num_insts), device=device, dtype=torch.int32) // max(n, 1)).contiguous()
+        key = (n, len(num_insts), str(device))
+        idx = _INDEX_CACHE.get(key)
+        if idx is None:
+            if len(_INDEX_CACHE) > 64:
+                _INDEX_CACHE.clear()
+            idx = (torch.arange(n * len(num_insts), device=device, dtype=torch.int32) // max(n, 1)).contiguous()
+            _INDEX_CACHE[key] = idx
+        return idx
     idx = torch.repeat_interleave(torch.arange(len(num_insts), dtype=torch.int32),
                                   torch.as_tensor(num_insts, dtype=torch.int64))
     return idx.to(device, non_blocking=True)
