@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define VNX_ABI_VERSION 3
+#define VNX_ABI_VERSION 4
 
 /* element types */
 enum {
@@ -149,6 +149,25 @@ int vnx_dynamic_mask_head_forward(int dtype, const void* mask_feats, const void*
                                   const void* params, const int32_t* inst_image, void* out,
                                   int num_images, int channels, int height, int width,
                                   int num_insts, int num_params, int stride, void* hip_stream);
+
+/*
+ * IDOL re-identification head: similarity matrix  out[i, j] = <a_i, b_j>  for a [n, channels]
+ * (row stride lda) and b [k, channels] (row stride ldb), on the matrix cores in exact fp32.
+ * normalize != 0 fuses F.normalize(., p=2, dim=1, eps=1e-12) of both operands (cosine).
+ * Replaces torch.mm(embeds, memo_embeds.t()) / the cosine variant
+ * (projects/IDOL/idol/models/tracker.py:229-244) and the per-instance
+ * einsum('nc,kc->nk') calls of projects/IDOL/idol/models/pos_neg_select.py:47,58-62.
+ * Rows must be 16-byte aligned (lda, ldb multiples of 4).  out [n, k], row stride ldo.
+ */
+int vnx_reid_similarity(int dtype, const void* a, const void* b, void* out, int n, int k,
+                        int channels, int lda, int ldb, int ldo, int normalize, void* hip_stream);
+
+/*
+ * Bi-directional softmax association score (tracker.py:232-235):
+ *   out = (softmax(sim, dim=1) + softmax(sim, dim=0)) / 2      sim, out [n, k], n, k <= 4096
+ */
+int vnx_reid_bisoftmax(int dtype, const void* sim, void* out, int n, int k, int lds, int ldo,
+                       void* hip_stream);
 
 /*
  * Kernel selection override for A/B measurements and tests (process-wide):
