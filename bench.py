@@ -133,6 +133,49 @@ def event_time_us(graph, launches, reps=15):
     return ts[len(ts) // 2]
 
 
+def model_step_leg(rank, local_rank, world, device, steps, warmup=3):
+    """clips/s of the SeqFormer-R50 training step (BASELINE config: T=5 synthetic 360p clip, 300
+    queries): forward + backward + RCCL gradient all-reduce + clipped AdamW step, one clip per
+    rank (weak scaling).  The loss is the surrogate of vnext_amd/models/seqformer.py (matcher and
+    criterion are out of scope); every parameter of the hot path gets a gradient."""
+    import torch.distributed as dist
+    import vnext_amd.models  # noqa: F401
+    from vnext_amd import train as T
+    from vnext_amd.registry import build_model, get_seqformer_cfg
+    torch.manual_seed(0)
+    cfg = get_seqformer_cfg(**{"MODEL.DEVICE": str(device)})
+    model = build_model(cfg).train()
+    ddp = T.wrap_ddp(model, local_rank)
+    opt = T.build_optimizer(model)
+    clips = T.synthetic_clips(1, 5, 360, 640, device, seed=100 + rank)
+    for _ in range(warmup):
+        T.train_step(ddp, opt, clips)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        T.train_step(ddp, opt, clips)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    n_params = sum(p.numel() for p in model.parameters() if p.requires_grad)
+    del ddp, opt, model
+    torch.cuda.empty_cache()
+    return {"clips_per_s": world * steps / dt, "ms_per_step": dt * 1e3 / steps, "steps": steps,
+            "clips_per_rank": 1, "n_gpus": world, "trainable_params": n_params,
+            "grad_allreduce_MB_per_step": round(n_params * 4 / 1e6, 1),
+            "config": "SeqFormer R50 (random init), T=5, 360x640 -> 384x640, 300 queries, 6+6 layers, fp32; "
+                      "surrogate loss; DDP static_graph + gradient_as_bucket_view over RCCL"}
+
+
 def latest_pmc_profile():
     """The newest committed PMC summary (tools/summarize_prof.py), or None."""
     import glob
@@ -219,6 +262,8 @@ def main():
     ap.add_argument("--batch", type=int, default=5)
     ap.add_argument("--dist", default="U", choices=["U", "M"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-model", action="store_true", help="skip the model-level DDP step (clips/s) leg")
+    ap.add_argument("--model-steps", type=int, default=10)
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -287,7 +332,14 @@ def main():
                    "parallelism": f"dp{n_gpus} (clips sharded, no data-path collective)"},
     }
 
+    # ---- model-level leg: SeqFormer-R50 T=5 360p training step under DDP (all ranks) ----------
+    model_leg = None
+    if not a.no_model:
+        model_leg = model_step_leg(rank, local_rank, world, device, a.model_steps)
+
     if rank == 0:
+        if model_leg is not None:
+            line["model_step"] = model_leg
         # ---- per-kernel rooflines, measured live with events on the launch stream -------
         inner = max(nsets, 24)
         g_fwd = capture([(lambda s=sets[i % nsets]: op.fwd(s, B, Lq)) for i in range(inner)])

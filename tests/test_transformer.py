@@ -1,0 +1,68 @@
+"""SeqFormer deformable transformer (callers of rows a4) against a fixture produced
+by the reference's own deformable_transformer.py (oracle/make_golden_transformer.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN_DIR
+from oracle import msda_oracle as O
+from vnext_amd.models.seqformer_transformer import DeformableTransformer
+from vnext_amd.ops.functions import ms_deform_attn_func as func_mod
+
+
+def load():
+    return dict(np.load(os.path.join(GOLDEN_DIR, "transformer_seqformer.npz")))
+
+
+def build(g, device, dtype):
+    C, M, L, P, T, ne, nd, ff = (int(x) for x in g["cfg"])
+    tr = DeformableTransformer(d_model=C, nhead=M, num_encoder_layers=ne, num_decoder_layers=nd,
+                               dim_feedforward=ff, dropout=0.0, return_intermediate_dec=True, num_frames=T,
+                               num_feature_levels=L, dec_n_points=P, enc_n_points=P)
+    tr.decoder.bbox_embed = torch.nn.ModuleList(
+        [torch.nn.Sequential(torch.nn.Linear(C, C), torch.nn.ReLU(), torch.nn.Linear(C, 4)) for _ in range(nd)])
+    sd = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd.")}
+    assert set(sd) == set(tr.state_dict()), "state-dict keys must match the reference transformer"
+    tr = tr.to(torch.float64)
+    tr.load_state_dict(sd)
+    return tr.to(device=device, dtype=dtype).eval(), L
+
+
+def run(tr, L, g, device, dtype):
+    srcs = [torch.from_numpy(g[f"src{i}"]).to(device, dtype) for i in range(L)]
+    poss = [torch.from_numpy(g[f"pos{i}"]).to(device, dtype) for i in range(L)]
+    masks = [torch.from_numpy(g[f"mask{i}"]).to(device) for i in range(L)]
+    with torch.no_grad():
+        return tr(srcs, masks, poss, torch.from_numpy(g["query_embed"]).to(device, dtype))
+
+
+class _OracleOp:
+    @staticmethod
+    def ms_deform_attn_forward(value, shapes, lsi, loc, attn, im2col_step):
+        return torch.from_numpy(O.msda_forward(value.numpy(), shapes.numpy(), lsi.numpy(), loc.numpy(), attn.numpy()))
+
+
+def check(out, g, tol):
+    hs, hs_box, memory, init_ref, inter_refs, _, _, valid_ratios = out
+    for name, t in (("hs", hs), ("hs_box", hs_box), ("memory", memory), ("init_ref", init_ref),
+                    ("inter_refs", inter_refs), ("valid_ratios", valid_ratios)):
+        assert tuple(t.shape) == g[name].shape, name
+        np.testing.assert_allclose(t.double().cpu().numpy(), g[name], rtol=0,
+                                   atol=tol * max(1.0, float(np.abs(g[name]).max())), err_msg=name)
+
+
+def test_transformer_host_logic_matches_reference_cpu(monkeypatch):
+    monkeypatch.setattr(func_mod, "MSDA", _OracleOp)
+    g = load()
+    tr, L = build(g, "cpu", torch.float64)
+    check(run(tr, L, g, "cpu", torch.float64), g, 1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-8), (torch.float32, 2e-4)])
+def test_transformer_on_gpu(dtype, tol):
+    g = load()
+    tr, L = build(g, "cuda:0", dtype)
+    check(run(tr, L, g, "cuda:0", dtype), g, tol)
