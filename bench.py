@@ -73,7 +73,10 @@ def make_set(res, B, Lq, seed, device, dist="U"):
     grad_out = torch.randn(B, Lq, 256, device=device, generator=g)
     out = torch.empty(B, Lq, 256, device=device)
     gv, gl, ga = torch.empty_like(value), torch.empty_like(loc), torch.empty_like(attn)
-    return dict(shapes=shapes, lsi=lsi, value=value, loc=loc, attn=attn.contiguous(),
+    from vnext_amd import _lib
+    ws_bytes = _lib.lib().vnx_msda_backward_workspace_bytes(0, 0, B, S, 8, 32, 4, Lq, 4, 1)
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=device)
+    return dict(ws=ws, ws_bytes=ws_bytes, shapes=shapes, lsi=lsi, value=value, loc=loc, attn=attn.contiguous(),
                 grad_out=grad_out, out=out, gv=gv, gl=gl, ga=ga, S=S)
 
 
@@ -98,7 +101,8 @@ class Op:
             0, 0, s["value"].data_ptr(), s["shapes"].data_ptr(), s["lsi"].data_ptr(),
             s["loc"].data_ptr(), s["attn"].data_ptr(), s["grad_out"].data_ptr(),
             s["gv"].data_ptr(), s["gl"].data_ptr(), s["ga"].data_ptr(),
-            B, s["S"], 8, 32, 4, Lq, 4, 1, None, 0, torch.cuda.current_stream().cuda_stream)
+            B, s["S"], 8, 32, 4, Lq, 4, 1, s["ws"].data_ptr(), s["ws_bytes"],
+            torch.cuda.current_stream().cuda_stream)
         self._lib.check(st)
 
 

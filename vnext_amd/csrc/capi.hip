@@ -48,7 +48,11 @@ int msda_forward_d32(int, int, const void*, const int64_t*, const int64_t*, cons
                      const void*, void*, MsdaDims, int variant, hipStream_t);
 int msda_backward_d32(int, int, const void*, const int64_t*, const int64_t*, const void*,
                       const void*, const void*, void*, void*, void*, MsdaDims, int variant,
-                      hipStream_t);
+                      void* records, hipStream_t);
+bool msda_d32_gvrec_supported(int vdt, int ldt, const MsdaDims& d);
+size_t msda_gvrec_record_bytes(const MsdaDims& d);
+int msda_backward_gvrec_d32(int vdt, const int64_t*, const int64_t*, const void* records, const void*,
+                            void*, MsdaDims, int variant, hipStream_t);
 
 // One non-blocking side stream + fork/join events per device, created on first use and kept
 // for the life of the process (the backward forks its two independent kernels onto it).
@@ -159,15 +163,25 @@ static bool bwd_fast_path(int vdt, int ldt, const MsdaDims& d, int variant) {
          msda_d32_bwd_supported(vdt, ldt, d) && msda_d32_gv_supported(vdt, ldt, d);
 }
 
+// Workspace layout of the backward: [sample records (fast path, 256-B aligned size) | fp32
+// grad_value image (16-bit values whenever the general path may run)].
+static size_t align256(size_t n) { return (n + 255) & ~size_t(255); }
+
+static bool use_records(int vdt, int ldt, const MsdaDims& d, int variant) {
+  return variant != 600 && msda_d32_gvrec_supported(vdt, ldt, d);
+}
+
 size_t vnx_msda_backward_workspace_bytes(int value_dtype, int loc_dtype, int batch,
                                          int spatial_size, int num_heads, int channels,
                                          int num_levels, int num_query, int num_point, int flags) {
-  if (value_dtype != VNX_BF16 && value_dtype != VNX_F16) return 0;
   const MsdaDims d{batch, spatial_size, num_heads, channels, num_levels, num_query, num_point};
-  // packed levels promised + owner-computes kernels available: no fp32 image needed
-  if ((flags & VNX_MSDA_LEVELS_PACKED) && bwd_fast_path(value_dtype, loc_dtype, d, g_kernel_variant))
-    return 0;
-  return sizeof(float) * size_t(batch) * size_t(spatial_size) * size_t(num_heads) * size_t(channels);
+  const int variant = g_kernel_variant;
+  const bool sixteen = (value_dtype == VNX_BF16 || value_dtype == VNX_F16);
+  const size_t image = sixteen ? sizeof(float) * size_t(batch) * size_t(spatial_size) * size_t(num_heads) * size_t(channels) : 0;
+  if (!bwd_fast_path(value_dtype, loc_dtype, d, variant)) return image;
+  const size_t records = use_records(value_dtype, loc_dtype, d, variant) ? align256(msda_gvrec_record_bytes(d)) : 0;
+  // packed levels promised: the general path never runs, no fp32 image
+  return records + ((flags & VNX_MSDA_LEVELS_PACKED) ? 0 : image);
 }
 
 int vnx_msda_backward(int value_dtype, int loc_dtype, const void* value,
@@ -191,30 +205,44 @@ int vnx_msda_backward(int value_dtype, int loc_dtype, const void* value,
     set_error("vnx_msda_backward: null grad_value");
     return VNX_ERR_INVALID_ARGUMENT;
   }
-  if (need > 0 && (!workspace || workspace_bytes < need)) {
-    set_error("vnx_msda_backward: needs %zu workspace bytes, got %zu", need, workspace_bytes);
+  const bool empty = (batch == 0 || num_query == 0);
+  if (need > 0 && !empty && (!workspace || workspace_bytes < need)) {
+    set_error("vnx_msda_backward: needs %zu workspace bytes (vnx_msda_backward_workspace_bytes), got %zu",
+              need, workspace_bytes);
     return VNX_ERR_WORKSPACE;
   }
-  const bool empty = (batch == 0 || num_query == 0);
   if (!empty && (!grad_output || !grad_sampling_loc || !grad_attn_weight)) {
     set_error("vnx_msda_backward: null gradient pointer");
     return VNX_ERR_INVALID_ARGUMENT;
   }
-  void* gv_acc = need > 0 ? workspace : grad_value;
-  const size_t acc_bytes = need > 0 ? need : n_value * size_t(elem_size(value_dtype));
+  const bool sixteen = (value_dtype == VNX_BF16 || value_dtype == VNX_F16);
+  const size_t image_bytes = sixteen ? sizeof(float) * n_value : 0;
+  if (empty) {  // no queries: the gradient of value is all zeros, the other two are empty
+    if (n_value > 0 &&
+        hipMemsetAsync(grad_value, 0, n_value * size_t(elem_size(value_dtype)), stream) != hipSuccess) {
+      set_error("vnx_msda_backward: hipMemsetAsync failed");
+      return VNX_ERR_LAUNCH;
+    }
+    return VNX_OK;
+  }
 
-  if (!empty && bwd_fast_path(value_dtype, loc_dtype, d, variant)) {
-    // (1) grad_loc / grad_attn: per-query gather kernel, no atomics.
-    // (2) grad_value: owner-computes slabs; does nothing on the device unless the levels
-    //     are packed.
+  if (bwd_fast_path(value_dtype, loc_dtype, d, variant)) {
+    // (1) grad_loc / grad_attn: per-query gather kernel, no atomics; it also leaves one 16-B
+    //     geometry record per sample in the workspace.
+    // (2) grad_value: owner-computes slabs fed by those records; does nothing on the device
+    //     unless the levels are packed.
     // (3) unless the caller promised packed levels: the general path, each kernel of which
     //     does nothing on the device when the levels ARE packed.  No host sync either way.
+    const bool with_rec = use_records(value_dtype, loc_dtype, d, variant);
+    const size_t rec_bytes = with_rec ? align256(msda_gvrec_record_bytes(d)) : 0;
+    void* records = with_rec ? workspace : nullptr;
+    void* image = (sixteen && !(flags & VNX_MSDA_LEVELS_PACKED)) ? (void*)((char*)workspace + rec_bytes) : nullptr;
     const bool only_gl = variant >= 100 && variant < 200;  // timing ablations
     const bool only_gv = variant >= 400 && variant < 500;
-    // The two kernels share inputs only, so (2) CAN be forked onto a side stream and joined
-    // back with events (variant 501).  Measured on MI355X the fork/join costs more than the
-    // overlap returns (52 vs 48 us per backward at the T=5 decoder shape), so it is off.
-    SideStream* side = (variant == 501) ? side_stream_for_current_device() : nullptr;
+    // The two kernels of the no-record form share inputs only and CAN be forked onto a side
+    // stream (variant 501).  Measured on MI355X the fork/join costs more than the overlap
+    // returns (52 vs 48 us per backward at the T=5 decoder shape), so it is off.
+    SideStream* side = (variant == 501 && !with_rec) ? side_stream_for_current_device() : nullptr;
     hipStream_t gv_stream = stream;
     if (side) {
       if (hipEventRecord(side->fork, stream) == hipSuccess &&
@@ -223,16 +251,20 @@ int vnx_msda_backward(int value_dtype, int loc_dtype, const void* value,
       else
         (void)hipGetLastError();  // fall back to one stream
     }
-    if (!only_gl) {
-      st = msda_backward_gv_d32(value_dtype, loc_dtype, spatial_shapes, level_start_index,
-                                sampling_loc, attn_weight, grad_output, grad_value, d, variant, gv_stream);
-      if (st != VNX_OK) return st;
-    }
-    if (!only_gv) {
+    if (!only_gv || with_rec) {
       st = msda_backward_d32(value_dtype, loc_dtype, value, spatial_shapes, level_start_index,
                              sampling_loc, attn_weight, grad_output, nullptr, grad_sampling_loc,
                              grad_attn_weight, d, only_gl ? variant : 100 + (variant < 100 ? variant : 0),
-                             stream);
+                             records, stream);
+      if (st != VNX_OK) return st;
+    }
+    if (!only_gl) {
+      if (with_rec)
+        st = msda_backward_gvrec_d32(value_dtype, spatial_shapes, level_start_index, records, grad_output,
+                                     grad_value, d, variant, stream);
+      else
+        st = msda_backward_gv_d32(value_dtype, loc_dtype, spatial_shapes, level_start_index,
+                                  sampling_loc, attn_weight, grad_output, grad_value, d, variant, gv_stream);
       if (st != VNX_OK) return st;
     }
     if (gv_stream != stream) {
@@ -244,6 +276,8 @@ int vnx_msda_backward(int value_dtype, int loc_dtype, const void* value,
       }
     }
     if (!(flags & VNX_MSDA_LEVELS_PACKED) && !only_gl && !only_gv) {
+      void* gv_acc = sixteen ? image : grad_value;
+      const size_t acc_bytes = sixteen ? image_bytes : n_value * size_t(elem_size(value_dtype));
       st = zero_if_not_packed(spatial_shapes, level_start_index, num_levels, spatial_size, gv_acc,
                               acc_bytes, stream);
       if (st != VNX_OK) return st;
@@ -251,13 +285,15 @@ int vnx_msda_backward(int value_dtype, int loc_dtype, const void* value,
                                  sampling_loc, attn_weight, grad_output, gv_acc, grad_sampling_loc,
                                  grad_attn_weight, d, /*only_if_not_packed=*/1, stream);
       if (st != VNX_OK) return st;
-      if (need > 0)
-        return convert_f32_to(value_dtype, workspace, grad_value, int64_t(n_value), spatial_shapes,
+      if (sixteen)
+        return convert_f32_to(value_dtype, image, grad_value, int64_t(n_value), spatial_shapes,
                               level_start_index, num_levels, spatial_size, stream);
     }
     return VNX_OK;
   }
 
+  void* gv_acc = sixteen ? workspace : grad_value;
+  const size_t acc_bytes = sixteen ? image_bytes : n_value * size_t(elem_size(value_dtype));
   // general path: zero-filled image + hardware fp32/fp64 atomics
   if (acc_bytes > 0) {
     const hipError_t e = hipMemsetAsync(gv_acc, 0, acc_bytes, stream);
@@ -266,17 +302,16 @@ int vnx_msda_backward(int value_dtype, int loc_dtype, const void* value,
       return VNX_ERR_LAUNCH;
     }
   }
-  if (empty) return VNX_OK;
   if (variant >= 300 && variant < 400 && msda_d32_bwd_supported(value_dtype, loc_dtype, d))
     st = msda_backward_d32(value_dtype, loc_dtype, value, spatial_shapes, level_start_index,
                            sampling_loc, attn_weight, grad_output, gv_acc, grad_sampling_loc,
-                           grad_attn_weight, d, variant - 300, stream);
+                           grad_attn_weight, d, variant - 300, nullptr, stream);
   else
     st = msda_backward_generic(value_dtype, loc_dtype, value, spatial_shapes, level_start_index,
                                sampling_loc, attn_weight, grad_output, gv_acc, grad_sampling_loc,
                                grad_attn_weight, d, /*only_if_not_packed=*/0, stream);
   if (st != VNX_OK) return st;
-  if (need > 0)
+  if (sixteen)
     return convert_f32_to(value_dtype, workspace, grad_value, int64_t(n_value), nullptr, nullptr, 0, 0,
                           stream);
   return VNX_OK;

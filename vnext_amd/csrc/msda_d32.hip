@@ -414,7 +414,7 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
                     const int64_t* __restrict__ lsi, const TL* __restrict__ loc,
                     const TL* __restrict__ attn, const TV* __restrict__ grad_out,
                     float* __restrict__ gv, TL* __restrict__ grad_loc, TL* __restrict__ grad_attn,
-                    MsdaDims d, int tiles_per_batch) {
+                    MsdaDims d, int tiles_per_batch, uint4_t* __restrict__ sample_records) {
   constexpr int D = 32;
   constexpr int PG = 8 / QPW;
   constexpr int kRowBytes = D * int(sizeof(TV));
@@ -452,6 +452,7 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
       const int H = int(shapes[2 * l]), W = int(shapes[2 * l + 1]);
       const int start = int(lsi[l]);
       const float h = y * float(H) - 0.5f, w = x * float(W) - 0.5f;
+      uint4_t record = {0xffffffffu, 0u, 0u, 0u};  // sample outside the map: no taps
       if (h > -1.f && w > -1.f && h < float(H) && w < float(W)) {
         const float hf = floorf(h), wf = floorf(w);
         const int h0 = int(hf), w0 = int(wf);
@@ -464,7 +465,13 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
         o4.z = (bot && lef) ? o00 + uint32_t(W) * pixel_elems : kTapOutsideElem;
         o4.w = (bot && rig) ? o00 + uint32_t(W + 1) * pixel_elems : kTapOutsideElem;
         g4.x = h - hf; g4.y = w - wf; g4.z = a;
+        record = uint4_t{(uint32_t(h0 + 1) << 16) | uint32_t(w0 + 1), __float_as_uint(g4.x),
+                         __float_as_uint(g4.y), __float_as_uint(a)};
       }
+      // the geometry, kept for the grad_value kernel (msda_d32_gvrec.hip):
+      // [batch][head][level][query*points], 16 B per sample
+      if (sample_records != nullptr)
+        sample_records[((int64_t(b) * d.M + m) * d.L + l) * (int64_t(d.Lq) * d.P) + int64_t(q) * d.P + (p - l * d.P)] = record;
     }
     s_off[qi * (LP + 1) + p] = o4;
     s_geo[qi * (LP + 1) + p] = g4;
@@ -556,7 +563,7 @@ template <typename TV, typename TL, int QPW, int WPB>
 static int launch_bwd_cfg(const void* value, const int64_t* shapes, const int64_t* lsi,
                           const void* loc, const void* attn, const void* grad_out, void* gv,
                           void* grad_loc, void* grad_attn, const MsdaDims& d, bool atomics,
-                          hipStream_t stream) {
+                          void* records, hipStream_t stream) {
   const int LP = d.L * d.P;
   const int tiles_per_batch = (d.Lq + QPW * WPB - 1) / (QPW * WPB);
   const int64_t blocks = int64_t(d.B) * tiles_per_batch * d.M;
@@ -569,7 +576,7 @@ static int launch_bwd_cfg(const void* value, const int64_t* shapes, const int64_
   hipLaunchKernelGGL((msda_bwd_d32_kernel<TV, TL, QPW, WPB, LPT, AT>), dim3(uint32_t(blocks)),   \
                      dim3(64 * WPB), lds, stream, (const TV*)value, shapes, lsi, (const TL*)loc, \
                      (const TL*)attn, (const TV*)grad_out, (float*)gv, (TL*)grad_loc,            \
-                     (TL*)grad_attn, d, tiles_per_batch)
+                     (TL*)grad_attn, d, tiles_per_batch, (uint4_t*)records)
   if (!atomics) { if (LP == 16) VNX_LAUNCH(16, false); else VNX_LAUNCH(0, false); }
   else { if (LP == 16) VNX_LAUNCH(16, true); else VNX_LAUNCH(0, true); }
 #undef VNX_LAUNCH
@@ -579,7 +586,7 @@ static int launch_bwd_cfg(const void* value, const int64_t* shapes, const int64_
 template <typename TV, typename TL>
 static int launch_bwd(const void* value, const int64_t* shapes, const int64_t* lsi,
                       const void* loc, const void* attn, const void* grad_out, void* gv,
-                      void* grad_loc, void* grad_attn, const MsdaDims& d, int variant,
+                      void* grad_loc, void* grad_attn, const MsdaDims& d, int variant, void* records,
                       hipStream_t stream) {
   // variant 100+v: ablation without the grad_value atomics (timing only, wrong grad_value)
   const bool atomics = variant < 100;
@@ -587,7 +594,7 @@ static int launch_bwd(const void* value, const int64_t* shapes, const int64_t* l
 #define VNX_CASE(Q, W)                                                                       \
   if (c.qpw == Q && c.wpb == W)                                                              \
     return launch_bwd_cfg<TV, TL, Q, W>(value, shapes, lsi, loc, attn, grad_out, gv, grad_loc, \
-                                        grad_attn, d, atomics, stream);
+                                        grad_attn, d, atomics, records, stream);
   VNX_CASE(8, 4) VNX_CASE(4, 4) VNX_CASE(2, 4) VNX_CASE(1, 4)
   VNX_CASE(8, 1) VNX_CASE(4, 1) VNX_CASE(2, 1) VNX_CASE(1, 1)
   VNX_CASE(4, 2)
@@ -605,8 +612,9 @@ bool msda_d32_bwd_supported(int vdt, int ldt, const MsdaDims& d) {
 int msda_backward_d32(int vdt, int ldt, const void* value, const int64_t* shapes,
                       const int64_t* lsi, const void* loc, const void* attn,
                       const void* grad_out, void* gv, void* grad_loc, void* grad_attn, MsdaDims d,
-                      int variant, hipStream_t stream) {
-#define VNX_ARGS value, shapes, lsi, loc, attn, grad_out, gv, grad_loc, grad_attn, d, variant, stream
+                      int variant, void* records, hipStream_t stream) {
+  // the 16-bit row limit of the sample records (h0+1, w0+1 packed into one word)
+#define VNX_ARGS value, shapes, lsi, loc, attn, grad_out, gv, grad_loc, grad_attn, d, variant, records, stream
   if (vdt == VNX_F32) return launch_bwd<float, float>(VNX_ARGS);
   if (vdt == VNX_BF16 && ldt == VNX_F32) return launch_bwd<bf16_t, float>(VNX_ARGS);
   if (vdt == VNX_BF16 && ldt == VNX_BF16) return launch_bwd<bf16_t, bf16_t>(VNX_ARGS);

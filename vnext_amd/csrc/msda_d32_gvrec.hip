@@ -1,0 +1,318 @@
+// msda_d32_gvrec.hip -- grad_value, owner-computes, fed by the sample records the
+// grad_loc/grad_attn kernel leaves behind.
+//
+// msda_d32_gv.hip has every unit (a pixel range of one level for one (batch, head)) recompute the
+// bilinear geometry of ALL of its level's samples, 12x redundantly for the finest 360p level, and
+// stage every chunk's grad_out rows in LDS whether or not a tap lands in the unit.  Phase
+// timestamps and PMC counters showed that bookkeeping, not the accumulation, to be two thirds of
+// its time (~400 issued instructions per thread and chunk on 16 waves per CU).
+//
+// Here the per-query kernel (msda_bwd_d32_kernel, which computes every sample's geometry anyway)
+// writes one 16-byte record per sample {(h0+1)<<16 | (w0+1), lh, lw, attn} into a workspace laid
+// out [batch][head][level][query*points] -- contiguous for each unit's scan -- and this kernel
+//   * reads its level's records with coalesced 16-B loads (no location / weight loads, no floor,
+//     no integer division, no range test in floating point),
+//   * ranks the taps that land in its pixel range by destination row (integer LDS atomics),
+//     turns the row counts into segment offsets with a DPP wave scan, scatters {query, weight},
+//   * lets 8-lane groups (16 B per lane = one 32-channel row) sum each row's segment in registers,
+//     reading the grad_out row of each tap straight from L2 (4 independent loads in flight), and
+//     update the LDS slab row once,
+//   * writes the slab with 16-B stores.  No floating-point atomics, no zero-fill pass, no fp32
+//     image for 16-bit tensors; every grad_value row has exactly one owner.
+// Levels must be packed (checked on the device; see msda_d32_gv.hip / capi.hip).
+#include "vnx_common.h"
+
+namespace vnx {
+namespace rec {
+
+typedef float float4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t uint2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t uint4_t __attribute__((ext_vector_type(4)));
+
+template <typename TV> __device__ __forceinline__ float4_t load4(const TV* p);
+template <> __device__ __forceinline__ float4_t load4<float>(const float* p) {
+  return *reinterpret_cast<const float4_t*>(p);
+}
+template <> __device__ __forceinline__ float4_t load4<bf16_t>(const bf16_t* p) {
+  const uint2_t r = *reinterpret_cast<const uint2_t*>(p);
+  float4_t v;
+  v.x = __uint_as_float(r.x << 16); v.y = __uint_as_float(r.x & 0xffff0000u);
+  v.z = __uint_as_float(r.y << 16); v.w = __uint_as_float(r.y & 0xffff0000u);
+  return v;
+}
+template <> __device__ __forceinline__ float4_t load4<f16_t>(const f16_t* p) {
+  const uint2_t r = *reinterpret_cast<const uint2_t*>(p);
+  float4_t v;
+  v.x = float(__builtin_bit_cast(_Float16, uint16_t(r.x & 0xffffu)));
+  v.y = float(__builtin_bit_cast(_Float16, uint16_t(r.x >> 16)));
+  v.z = float(__builtin_bit_cast(_Float16, uint16_t(r.y & 0xffffu)));
+  v.w = float(__builtin_bit_cast(_Float16, uint16_t(r.y >> 16)));
+  return v;
+}
+template <typename TV> __device__ __forceinline__ void store4(TV* p, float4_t v);
+template <> __device__ __forceinline__ void store4<float>(float* p, float4_t v) {
+  *reinterpret_cast<float4_t*>(p) = v;
+}
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, float4_t v) {
+  uint2_t r;
+  r.x = uint32_t(f32_to_bf16_bits(v.x)) | (uint32_t(f32_to_bf16_bits(v.y)) << 16);
+  r.y = uint32_t(f32_to_bf16_bits(v.z)) | (uint32_t(f32_to_bf16_bits(v.w)) << 16);
+  *reinterpret_cast<uint2_t*>(p) = r;
+}
+template <> __device__ __forceinline__ void store4<f16_t>(f16_t* p, float4_t v) {
+  uint2_t r;
+  r.x = uint32_t(__builtin_bit_cast(uint16_t, _Float16(v.x))) | (uint32_t(__builtin_bit_cast(uint16_t, _Float16(v.y))) << 16);
+  r.y = uint32_t(__builtin_bit_cast(uint16_t, _Float16(v.z))) | (uint32_t(__builtin_bit_cast(uint16_t, _Float16(v.w))) << 16);
+  *reinterpret_cast<uint2_t*>(p) = r;
+}
+
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+  int x = int(v);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);  // row_shr:1
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);  // row_shr:2
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false);  // row_shr:4
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false);  // row_shr:8
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1, 3
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2, 3
+  return uint32_t(x);
+}
+
+constexpr int kWaves = 8;                   // 512 threads, one sample per thread per chunk
+constexpr int kThreads = 64 * kWaves;
+constexpr int kGroups = kThreads / 8;       // 8-lane groups
+constexpr int kRowsMax = 448;               // 56 KiB slab
+constexpr int kLevelsMax = 64;
+// slab 56 K + tap list 16 K + 3 x 448 counters/offsets + allocator + level table = 78.9 KiB
+// -> two units per CU.
+constexpr size_t kLdsBytes = size_t(kRowsMax) * 128 + size_t(kThreads) * 32 + size_t(kRowsMax) * 12 + 16 +
+                             4 * kLevelsMax * 4;
+
+template <typename TV, int P_T>
+__global__ void __launch_bounds__(kThreads)
+msda_bwd_gv_rec_kernel(const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
+                       const uint4_t* __restrict__ records, const TV* __restrict__ grad_out,
+                       TV* __restrict__ grad_value, MsdaDims d, int units_min, int units_bound) {
+  constexpr int D = 32;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float4_t* slab = reinterpret_cast<float4_t*>(smem);                        // [rows][8]
+  uint2_t* list = reinterpret_cast<uint2_t*>(slab + kRowsMax * 8);           // [4*threads] taps
+  uint32_t* cnt2 = reinterpret_cast<uint32_t*>(list + 4 * kThreads);         // [2][rows]
+  uint32_t* offs = cnt2 + 2 * kRowsMax;                                      // [rows]
+  uint32_t* alloc = offs + kRowsMax;                                         // [4]
+  int* meta = reinterpret_cast<int*>(alloc + 4);                             // [4*L]
+
+  const int P = P_T > 0 ? P_T : d.P;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int m = blockIdx.x % d.M;
+  const int rest = blockIdx.x / d.M;
+  const int unit = rest % units_bound;
+  const int b = rest / units_bound;
+
+  // level table: lane l works out level l's unit split once (two integer divisions per level)
+  if (tid < d.L) {
+    const int H = int(shapes[2 * tid]), W = int(shapes[2 * tid + 1]);
+    const int n = H * W;
+    int units = 0, rpu = 1;
+    if (n > 0) {
+      units = (n + kRowsMax - 1) / kRowsMax;
+      if (units < units_min) units = units_min;
+      if (units > n) units = n;
+      rpu = (n + units - 1) / units;
+      units = (n + rpu - 1) / rpu;
+    }
+    meta[4 * tid] = H; meta[4 * tid + 1] = W; meta[4 * tid + 2] = int(lsi[tid]);
+    meta[4 * tid + 3] = units | (rpu << 12);
+  }
+  for (int i = tid; i < 2 * kRowsMax; i += kThreads) cnt2[i] = 0;
+  if (tid == 0) alloc[0] = 0;
+  __syncthreads();
+
+  int lvl = -1, r0 = 0, r1 = 0, Hl = 0, Wl = 0, start = 0;
+  {
+    int running = 0;
+    bool packed = true;
+    int u = unit;
+    for (int l = 0; l < d.L; ++l) {
+      const int H = meta[4 * l], W = meta[4 * l + 1], st = meta[4 * l + 2], ur = meta[4 * l + 3];
+      const int n = H * W, units = ur & 0xfff, rpu = ur >> 12;
+      packed = packed && (st == running);
+      running += n;
+      if (lvl < 0) {
+        if (u < units) {
+          lvl = l; Hl = H; Wl = W; start = st;
+          r0 = u * rpu;
+          r1 = r0 + rpu < n ? r0 + rpu : n;
+        } else {
+          u -= units;
+        }
+      }
+    }
+    packed = packed && (running == d.S);
+    if (!packed || lvl < 0) return;  // uniform over the workgroup
+  }
+  const int rows = r1 - r0;
+  for (int i = tid; i < rows * 8; i += kThreads) slab[i] = float4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int n_samples = d.Lq * P;
+  const int n_chunks = (n_samples + kThreads - 1) / kThreads;
+  const uint4_t* my_recs = records + ((int64_t(b) * d.M + m) * d.L + lvl) * n_samples;
+  const TV* go_head = grad_out + (int64_t(b) * d.Lq * d.M + m) * D;
+  const int64_t q_stride = int64_t(d.M) * D;
+  const uint4_t none = {0xffffffffu, 0u, 0u, 0u};
+  uint4_t next = tid < n_samples ? my_recs[tid] : none;
+
+  const int grp = tid >> 3, ch4 = tid & 7;
+  const int dr[4] = {0, 1, Wl, Wl + 1};
+  for (int chunk = 0; chunk < n_chunks; ++chunk) {
+    uint32_t* cnt = cnt2 + (chunk & 1) * kRowsMax;
+    uint32_t* cnt_next = cnt2 + ((chunk + 1) & 1) * kRowsMax;
+    const uint4_t r = next;
+    const int s = chunk * kThreads + tid;
+    {  // the next chunk's record: in flight while this chunk is sorted and applied
+      const int s2 = s + kThreads;
+      next = (chunk + 1 < n_chunks && s2 < n_samples) ? my_recs[s2] : none;
+    }
+    uint32_t mask = 0;
+    int row00 = 0;
+    float wt[4] = {0.f, 0.f, 0.f, 0.f};
+    uint32_t rank[4] = {0u, 0u, 0u, 0u};
+    if (r.x != 0xffffffffu) {
+      const int h0 = int(r.x >> 16) - 1, w0 = int(r.x & 0xffffu) - 1;
+      const float lh = __uint_as_float(r.y), lw = __uint_as_float(r.z), a = __uint_as_float(r.w);
+      const float hh = 1.f - lh, hw = 1.f - lw;
+      const bool top = h0 >= 0, bot = h0 + 1 <= Hl - 1, lef = w0 >= 0, rig = w0 + 1 <= Wl - 1;
+      const int p00 = h0 * Wl + w0;
+      mask = (uint32_t(top && lef && p00 >= r0 && p00 < r1)) |
+             (uint32_t(top && rig && p00 + 1 >= r0 && p00 + 1 < r1) << 1) |
+             (uint32_t(bot && lef && p00 + Wl >= r0 && p00 + Wl < r1) << 2) |
+             (uint32_t(bot && rig && p00 + Wl + 1 >= r0 && p00 + Wl + 1 < r1) << 3);
+      row00 = p00 - r0;
+      wt[0] = a * (hh * hw); wt[1] = a * (hh * lw); wt[2] = a * (lh * hw); wt[3] = a * (lh * lw);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      if (mask & (1u << t))
+        rank[t] = __hip_atomic_fetch_add(cnt + row00 + dr[t], 1u, __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_WORKGROUP);
+    __syncthreads();
+
+    // row counts -> segment offsets: DPP wave scan + one LDS allocation per wave
+    {
+      const uint32_t my_cnt = tid < rows ? cnt[tid] : 0u;
+      const uint32_t incl = wave_inclusive_scan(my_cnt);
+      const uint32_t wave_total = uint32_t(__builtin_amdgcn_readlane(int(incl), 63));
+      uint32_t base = 0;
+      if (lane == 0 && wave_total != 0)
+        base = __hip_atomic_fetch_add(alloc, wave_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      base = uint32_t(__builtin_amdgcn_readfirstlane(int(base)));
+      if (tid < rows) offs[tid] = base + incl - my_cnt;
+    }
+    __syncthreads();
+
+    // scatter {query, weight} into the row segments
+    {
+      const uint32_t q = uint32_t(s) / uint32_t(P);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (mask & (1u << t)) list[offs[row00 + dr[t]] + rank[t]] = uint2_t{q, __float_as_uint(wt[t])};
+    }
+    __syncthreads();
+
+    // 8-lane groups own rows: sum the row's segment in registers, one slab update
+    if (tid == 0) alloc[0] = 0;
+    constexpr int kRpg = (kRowsMax + kGroups - 1) / kGroups;
+    uint32_t rn[kRpg], ro[kRpg];
+#pragma unroll
+    for (int k = 0; k < kRpg; ++k) {
+      const int row = grp + k * kGroups;
+      rn[k] = row < rows ? cnt[row] : 0u;
+      ro[k] = row < rows ? offs[row] : 0u;
+      if (row < rows) cnt_next[row] = 0;
+    }
+#pragma unroll
+    for (int k = 0; k < kRpg; ++k) {
+      const uint32_t n = rn[k];
+      if (n == 0) continue;
+      const int row = grp + k * kGroups;
+      const uint2_t* seg = list + ro[k];
+      const TV* g_lane = go_head + ch4 * 4;
+      float4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+      uint32_t i = 0;
+      for (; i + 4 <= n; i += 4) {  // four independent record -> grad_out row chains in flight
+        const uint2_t e0 = seg[i], e1 = seg[i + 1], e2 = seg[i + 2], e3 = seg[i + 3];
+        const float4_t x0 = load4<TV>(g_lane + int64_t(e0.x) * q_stride);
+        const float4_t x1 = load4<TV>(g_lane + int64_t(e1.x) * q_stride);
+        const float4_t x2 = load4<TV>(g_lane + int64_t(e2.x) * q_stride);
+        const float4_t x3 = load4<TV>(g_lane + int64_t(e3.x) * q_stride);
+        a0 += __uint_as_float(e0.y) * x0;
+        a1 += __uint_as_float(e1.y) * x1;
+        a2 += __uint_as_float(e2.y) * x2;
+        a3 += __uint_as_float(e3.y) * x3;
+      }
+      for (; i < n; ++i) {
+        const uint2_t e = seg[i];
+        a0 += __uint_as_float(e.y) * load4<TV>(g_lane + int64_t(e.x) * q_stride);
+      }
+      slab[row * 8 + ch4] += (a0 + a1) + (a2 + a3);
+    }
+    __syncthreads();
+  }
+
+  TV* out = grad_value + ((int64_t(b) * d.S + start + r0) * d.M + m) * D;
+  for (int i = tid; i < rows * 8; i += kThreads) {
+    const int row = i >> 3, c4 = i & 7;
+    store4<TV>(out + int64_t(row) * d.M * D + c4 * 4, slab[i]);
+  }
+}
+
+}  // namespace rec
+
+int msda_gvrec_units_bound(const MsdaDims& d, int units_min) {
+  return d.L * (units_min + 1) + (d.S + rec::kRowsMax - 1) / rec::kRowsMax;
+}
+
+size_t msda_gvrec_record_bytes(const MsdaDims& d) {
+  return size_t(16) * size_t(d.B) * d.M * d.L * d.Lq * d.P;
+}
+
+bool msda_d32_gvrec_supported(int vdt, int ldt, const MsdaDims& d) {
+  if (d.D != 32 || vdt == VNX_F64) return false;
+  if (vdt == VNX_F32 && ldt != VNX_F32) return false;
+  if (d.L > rec::kLevelsMax) return false;
+  if (d.S > rec::kRowsMax * 4000) return false;     // units and rows/unit share one word
+  if (int64_t(d.Lq) * d.P >= (int64_t(1) << 31)) return false;
+  const int64_t blocks = int64_t(d.B) * d.M * msda_gvrec_units_bound(d, 16);
+  return blocks < (int64_t(1) << 31);
+}
+
+template <typename TV>
+static int launch_gvrec(const int64_t* shapes, const int64_t* lsi, const void* records,
+                        const void* grad_out, void* grad_value, const MsdaDims& d, int units_min,
+                        hipStream_t stream) {
+  const int units_bound = msda_gvrec_units_bound(d, units_min);
+  const int64_t blocks = int64_t(d.B) * d.M * units_bound;
+#define VNX_LAUNCH(PT)                                                                                 \
+  hipLaunchKernelGGL((rec::msda_bwd_gv_rec_kernel<TV, PT>), dim3(uint32_t(blocks)), dim3(rec::kThreads),  \
+                     rec::kLdsBytes, stream, shapes, lsi, (const rec::uint4_t*)records,                \
+                     (const TV*)grad_out, (TV*)grad_value, d, units_min, units_bound)
+  if (d.P == 4) VNX_LAUNCH(4); else VNX_LAUNCH(0);
+#undef VNX_LAUNCH
+  return check_launch("msda_bwd_gv_rec");
+}
+
+// grad_value from the sample records; a no-op on the device when the levels are not packed.
+int msda_backward_gvrec_d32(int vdt, const int64_t* shapes, const int64_t* lsi, const void* records,
+                            const void* grad_out, void* grad_value, MsdaDims d, int variant,
+                            hipStream_t stream) {
+  int units_min = 4;
+  if (variant >= 200 && variant < 300) units_min = variant - 200;
+  if (units_min < 1) units_min = 1;
+  if (units_min > 16) units_min = 16;
+  if (vdt == VNX_F32) return launch_gvrec<float>(shapes, lsi, records, grad_out, grad_value, d, units_min, stream);
+  if (vdt == VNX_BF16) return launch_gvrec<bf16_t>(shapes, lsi, records, grad_out, grad_value, d, units_min, stream);
+  if (vdt == VNX_F16) return launch_gvrec<f16_t>(shapes, lsi, records, grad_out, grad_value, d, units_min, stream);
+  set_error("msda_backward_gvrec_d32: unsupported dtype %d", vdt);
+  return VNX_ERR_INVALID_ARGUMENT;
+}
+
+}  // namespace vnx
