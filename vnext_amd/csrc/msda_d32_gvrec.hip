@@ -14,9 +14,10 @@
 //     no integer division, no range test in floating point),
 //   * ranks the taps that land in its pixel range by destination row (integer LDS atomics),
 //     turns the row counts into segment offsets with a DPP wave scan, scatters {query, weight},
-//   * lets 8-lane groups (16 B per lane = one 32-channel row) sum each row's segment in registers,
-//     reading the grad_out row of each tap straight from L2 (4 independent loads in flight), and
-//     update the LDS slab row once,
+//   * stages the chunk's grad_out rows of this head in LDS (reading them per tap straight from L2
+//     instead measured 19 us for a single round of units: one serialised memory latency per row),
+//   * lets 8-lane groups (16 B per lane = one 32-channel row) sum each row's segment in registers
+//     and update the LDS slab row once,
 //   * writes the slab with 16-B stores.  No floating-point atomics, no zero-fill pass, no fp32
 //     image for 16-bit tensors; every grad_value row has exactly one owner.
 // Levels must be packed (checked on the device; see msda_d32_gv.hip / capi.hip).
@@ -80,22 +81,32 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
 constexpr int kWaves = 8;                   // 512 threads, one sample per thread per chunk
 constexpr int kThreads = 64 * kWaves;
 constexpr int kGroups = kThreads / 8;       // 8-lane groups
-constexpr int kRowsMax = 448;               // 56 KiB slab
+constexpr int kRowsMax = 320;               // 40 KiB slab
+constexpr int kQcMax = 128;                 // queries per chunk (16 KiB of grad_out rows in LDS)
 constexpr int kLevelsMax = 64;
-// slab 56 K + tap list 16 K + 3 x 448 counters/offsets + allocator + level table = 78.9 KiB
-// -> two units per CU.
-constexpr size_t kLdsBytes = size_t(kRowsMax) * 128 + size_t(kThreads) * 32 + size_t(kRowsMax) * 12 + 16 +
-                             4 * kLevelsMax * 4;
+// slab 40 K + grad_out rows 16 K + tap list 16 K + 3 x 320 counters/offsets + allocator + level
+// table = 76.8 KiB -> two units per CU.
+constexpr size_t kLdsBytes = size_t(kRowsMax) * 128 + size_t(kQcMax) * 128 + size_t(kThreads) * 32 +
+                             size_t(kRowsMax) * 12 + 16 + 4 * kLevelsMax * 4;
+
+// Development aid: per-workgroup phase timestamps (s_memtime), written when debug != 0.
+__device__ unsigned long long g_rec_stamps[4096 * 16];
+#define VNX_STAMP(k)                                                              \
+  do {                                                                            \
+    if (debug && tid == 0 && blockIdx.x < 4096)                                   \
+      g_rec_stamps[blockIdx.x * 16 + (k)] = __builtin_readcyclecounter();         \
+  } while (0)
 
 template <typename TV, int P_T>
 __global__ void __launch_bounds__(kThreads)
 msda_bwd_gv_rec_kernel(const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
                        const uint4_t* __restrict__ records, const TV* __restrict__ grad_out,
-                       TV* __restrict__ grad_value, MsdaDims d, int units_min, int units_bound) {
+                       TV* __restrict__ grad_value, MsdaDims d, int units_min, int units_bound, int debug) {
   constexpr int D = 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float4_t* slab = reinterpret_cast<float4_t*>(smem);                        // [rows][8]
-  uint2_t* list = reinterpret_cast<uint2_t*>(slab + kRowsMax * 8);           // [4*threads] taps
+  float4_t* grows = slab + kRowsMax * 8;                                     // [qc][8] grad_out rows
+  uint2_t* list = reinterpret_cast<uint2_t*>(grows + kQcMax * 8);            // [4*threads] taps
   uint32_t* cnt2 = reinterpret_cast<uint32_t*>(list + 4 * kThreads);         // [2][rows]
   uint32_t* offs = cnt2 + 2 * kRowsMax;                                      // [rows]
   uint32_t* alloc = offs + kRowsMax;                                         // [4]
@@ -107,6 +118,7 @@ msda_bwd_gv_rec_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
   const int rest = blockIdx.x / d.M;
   const int unit = rest % units_bound;
   const int b = rest / units_bound;
+  VNX_STAMP(0);
 
   // level table: lane l works out level l's unit split once (two integer divisions per level)
   if (tid < d.L) {
@@ -126,6 +138,7 @@ msda_bwd_gv_rec_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
   for (int i = tid; i < 2 * kRowsMax; i += kThreads) cnt2[i] = 0;
   if (tid == 0) alloc[0] = 0;
   __syncthreads();
+  VNX_STAMP(1);
 
   int lvl = -1, r0 = 0, r1 = 0, Hl = 0, Wl = 0, start = 0;
   {
@@ -154,29 +167,46 @@ msda_bwd_gv_rec_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
   for (int i = tid; i < rows * 8; i += kThreads) slab[i] = float4_t{0.f, 0.f, 0.f, 0.f};
 
   const int n_samples = d.Lq * P;
-  const int n_chunks = (n_samples + kThreads - 1) / kThreads;
+  const int qc_ = kThreads / P < kQcMax ? kThreads / P : kQcMax;
+  const int n_chunks = (d.Lq + qc_ - 1) / qc_;
   const uint4_t* my_recs = records + ((int64_t(b) * d.M + m) * d.L + lvl) * n_samples;
   const TV* go_head = grad_out + (int64_t(b) * d.Lq * d.M + m) * D;
   const int64_t q_stride = int64_t(d.M) * D;
   const uint4_t none = {0xffffffffu, 0u, 0u, 0u};
-  uint4_t next = tid < n_samples ? my_recs[tid] : none;
+  uint4_t next = (tid < qc_ * P && tid < n_samples) ? my_recs[tid] : none;
+  // a chunk = qc queries = qc*P <= 512 samples; its grad_out rows are staged in LDS (two 16-B
+  // pieces per thread), loaded one chunk ahead like the records
+  const int qc = kThreads / P < kQcMax ? kThreads / P : kQcMax;
+  const int g0 = tid, g1 = tid + kThreads;
+  float4_t pg0 = {0.f, 0.f, 0.f, 0.f}, pg1 = pg0;
+  auto prefetch_rows = [&](int chunk) {
+    const int qa = chunk * qc + (g0 >> 3), qb = chunk * qc + (g1 >> 3);
+    if ((g0 >> 3) < qc && qa < d.Lq) pg0 = load4<TV>(go_head + int64_t(qa) * q_stride + (g0 & 7) * 4);
+    if ((g1 >> 3) < qc && qb < d.Lq) pg1 = load4<TV>(go_head + int64_t(qb) * q_stride + (g1 & 7) * 4);
+  };
+  prefetch_rows(0);
+  VNX_STAMP(2);
 
   const int grp = tid >> 3, ch4 = tid & 7;
   const int dr[4] = {0, 1, Wl, Wl + 1};
   for (int chunk = 0; chunk < n_chunks; ++chunk) {
     uint32_t* cnt = cnt2 + (chunk & 1) * kRowsMax;
     uint32_t* cnt_next = cnt2 + ((chunk + 1) & 1) * kRowsMax;
+    if (chunk == 0) VNX_STAMP(3);
     const uint4_t r = next;
-    const int s = chunk * kThreads + tid;
-    {  // the next chunk's record: in flight while this chunk is sorted and applied
-      const int s2 = s + kThreads;
-      next = (chunk + 1 < n_chunks && s2 < n_samples) ? my_recs[s2] : none;
+    const int s = chunk * qc * P + tid;               // sample index within (b, m, level)
+    if ((g0 >> 3) < qc) grows[g0] = pg0;
+    if ((g1 >> 3) < qc) grows[g1] = pg1;
+    if (chunk + 1 < n_chunks) {  // the next chunk's loads: in flight while this one is sorted and applied
+      const int s2 = s + qc * P;
+      next = (tid < qc * P && s2 < n_samples) ? my_recs[s2] : none;
+      prefetch_rows(chunk + 1);
     }
     uint32_t mask = 0;
     int row00 = 0;
     float wt[4] = {0.f, 0.f, 0.f, 0.f};
     uint32_t rank[4] = {0u, 0u, 0u, 0u};
-    if (r.x != 0xffffffffu) {
+    if (r.x != 0xffffffffu && tid < qc * P) {
       const int h0 = int(r.x >> 16) - 1, w0 = int(r.x & 0xffffu) - 1;
       const float lh = __uint_as_float(r.y), lw = __uint_as_float(r.z), a = __uint_as_float(r.w);
       const float hh = 1.f - lh, hw = 1.f - lw;
@@ -194,7 +224,9 @@ msda_bwd_gv_rec_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
       if (mask & (1u << t))
         rank[t] = __hip_atomic_fetch_add(cnt + row00 + dr[t], 1u, __ATOMIC_RELAXED,
                                          __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (chunk == 0) VNX_STAMP(4);
     __syncthreads();
+    if (chunk == 0) VNX_STAMP(5);
 
     // row counts -> segment offsets: DPP wave scan + one LDS allocation per wave
     {
@@ -208,15 +240,17 @@ msda_bwd_gv_rec_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
       if (tid < rows) offs[tid] = base + incl - my_cnt;
     }
     __syncthreads();
+    if (chunk == 0) VNX_STAMP(6);
 
     // scatter {query, weight} into the row segments
     {
-      const uint32_t q = uint32_t(s) / uint32_t(P);
+      const uint32_t slot = uint32_t(tid) / uint32_t(P);  // query slot inside the chunk
 #pragma unroll
       for (int t = 0; t < 4; ++t)
-        if (mask & (1u << t)) list[offs[row00 + dr[t]] + rank[t]] = uint2_t{q, __float_as_uint(wt[t])};
+        if (mask & (1u << t)) list[offs[row00 + dr[t]] + rank[t]] = uint2_t{slot, __float_as_uint(wt[t])};
     }
     __syncthreads();
+    if (chunk == 0) VNX_STAMP(7);
 
     // 8-lane groups own rows: sum the row's segment in registers, one slab update
     if (tid == 0) alloc[0] = 0;
@@ -229,21 +263,21 @@ msda_bwd_gv_rec_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
       ro[k] = row < rows ? offs[row] : 0u;
       if (row < rows) cnt_next[row] = 0;
     }
+    // One row at a time, four taps in flight within the row.  (Walking the group's rows
+    // side by side -- one tap of each row per step -- was measured slower: 70 us total backward
+    // against 42 us, because every group then iterates to the longest row of the wave.)
+    const float4_t* g4 = grows + ch4;
 #pragma unroll
     for (int k = 0; k < kRpg; ++k) {
       const uint32_t n = rn[k];
       if (n == 0) continue;
       const int row = grp + k * kGroups;
       const uint2_t* seg = list + ro[k];
-      const TV* g_lane = go_head + ch4 * 4;
       float4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
       uint32_t i = 0;
-      for (; i + 4 <= n; i += 4) {  // four independent record -> grad_out row chains in flight
+      for (; i + 4 <= n; i += 4) {
         const uint2_t e0 = seg[i], e1 = seg[i + 1], e2 = seg[i + 2], e3 = seg[i + 3];
-        const float4_t x0 = load4<TV>(g_lane + int64_t(e0.x) * q_stride);
-        const float4_t x1 = load4<TV>(g_lane + int64_t(e1.x) * q_stride);
-        const float4_t x2 = load4<TV>(g_lane + int64_t(e2.x) * q_stride);
-        const float4_t x3 = load4<TV>(g_lane + int64_t(e3.x) * q_stride);
+        const float4_t x0 = g4[e0.x * 8], x1 = g4[e1.x * 8], x2 = g4[e2.x * 8], x3 = g4[e3.x * 8];
         a0 += __uint_as_float(e0.y) * x0;
         a1 += __uint_as_float(e1.y) * x1;
         a2 += __uint_as_float(e2.y) * x2;
@@ -251,18 +285,23 @@ msda_bwd_gv_rec_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
       }
       for (; i < n; ++i) {
         const uint2_t e = seg[i];
-        a0 += __uint_as_float(e.y) * load4<TV>(g_lane + int64_t(e.x) * q_stride);
+        a0 += __uint_as_float(e.y) * g4[e.x * 8];
       }
       slab[row * 8 + ch4] += (a0 + a1) + (a2 + a3);
     }
+    if (chunk == 0) VNX_STAMP(8);
     __syncthreads();
+    if (chunk == 0) VNX_STAMP(9);
+    if (chunk == 1) VNX_STAMP(10);
   }
+  VNX_STAMP(11);
 
   TV* out = grad_value + ((int64_t(b) * d.S + start + r0) * d.M + m) * D;
   for (int i = tid; i < rows * 8; i += kThreads) {
     const int row = i >> 3, c4 = i & 7;
     store4<TV>(out + int64_t(row) * d.M * D + c4 * 4, slab[i]);
   }
+  VNX_STAMP(12);
 }
 
 }  // namespace rec
@@ -288,13 +327,13 @@ bool msda_d32_gvrec_supported(int vdt, int ldt, const MsdaDims& d) {
 template <typename TV>
 static int launch_gvrec(const int64_t* shapes, const int64_t* lsi, const void* records,
                         const void* grad_out, void* grad_value, const MsdaDims& d, int units_min,
-                        hipStream_t stream) {
+                        int debug, hipStream_t stream) {
   const int units_bound = msda_gvrec_units_bound(d, units_min);
   const int64_t blocks = int64_t(d.B) * d.M * units_bound;
 #define VNX_LAUNCH(PT)                                                                                 \
   hipLaunchKernelGGL((rec::msda_bwd_gv_rec_kernel<TV, PT>), dim3(uint32_t(blocks)), dim3(rec::kThreads),  \
                      rec::kLdsBytes, stream, shapes, lsi, (const rec::uint4_t*)records,                \
-                     (const TV*)grad_out, (TV*)grad_value, d, units_min, units_bound)
+                     (const TV*)grad_out, (TV*)grad_value, d, units_min, units_bound, debug)
   if (d.P == 4) VNX_LAUNCH(4); else VNX_LAUNCH(0);
 #undef VNX_LAUNCH
   return check_launch("msda_bwd_gv_rec");
@@ -308,11 +347,16 @@ int msda_backward_gvrec_d32(int vdt, const int64_t* shapes, const int64_t* lsi, 
   if (variant >= 200 && variant < 300) units_min = variant - 200;
   if (units_min < 1) units_min = 1;
   if (units_min > 16) units_min = 16;
-  if (vdt == VNX_F32) return launch_gvrec<float>(shapes, lsi, records, grad_out, grad_value, d, units_min, stream);
-  if (vdt == VNX_BF16) return launch_gvrec<bf16_t>(shapes, lsi, records, grad_out, grad_value, d, units_min, stream);
-  if (vdt == VNX_F16) return launch_gvrec<f16_t>(shapes, lsi, records, grad_out, grad_value, d, units_min, stream);
+  if (vdt == VNX_F32) return launch_gvrec<float>(shapes, lsi, records, grad_out, grad_value, d, units_min, variant == 408 ? 1 : 0, stream);
+  if (vdt == VNX_BF16) return launch_gvrec<bf16_t>(shapes, lsi, records, grad_out, grad_value, d, units_min, variant == 408 ? 1 : 0, stream);
+  if (vdt == VNX_F16) return launch_gvrec<f16_t>(shapes, lsi, records, grad_out, grad_value, d, units_min, variant == 408 ? 1 : 0, stream);
   set_error("msda_backward_gvrec_d32: unsupported dtype %d", vdt);
   return VNX_ERR_INVALID_ARGUMENT;
+}
+
+// development aid, not part of the public header
+extern "C" int vnx_debug_read_rec_stamps(unsigned long long* host, int n) {
+  return int(hipMemcpyFromSymbol(host, HIP_SYMBOL(rec::g_rec_stamps), sizeof(unsigned long long) * size_t(n)));
 }
 
 }  // namespace vnx
