@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define VNX_ABI_VERSION 4
+#define VNX_ABI_VERSION 5
 
 /* element types */
 enum {
@@ -149,6 +149,28 @@ int vnx_dynamic_mask_head_forward(int dtype, const void* mask_feats, const void*
                                   const void* params, const int32_t* inst_image, void* out,
                                   int num_images, int channels, int height, int width,
                                   int num_insts, int num_params, int stride, void* hip_stream);
+
+/*
+ * Dynamic mask head, backward (the training path, forward_mask_head_train,
+ * segmentation_condInst.py:354-401): gradients of the chain above with respect to the mask
+ * features, the reference points and the per-instance parameters, contracted with grad_out.
+ * Replaces what autograd runs for the reference: the transposes of pad/interpolate/pad, three
+ * grouped-conv backward-data + three backward-weight launches (groups = num_insts), the ReLU
+ * masks and the reduction over the `repeat`ed feature map (:452-456).  Nothing is saved by
+ * the forward; the hidden layers are recomputed.
+ *   grad_out    [num_insts, 2*height, 2*width]
+ *   grad_feats  [num_images, 8, height, width]   sum over the instances of each image
+ *   grad_ref    [num_insts, 2]
+ *   grad_params [num_insts, 169]
+ * All three outputs are fully defined on return (zero-filled inside, then accumulated with
+ * fp32 atomics: the order of the sums over pixels / instances is not fixed, as in the
+ * reference's cuDNN/MIOpen weight-gradient kernels).
+ */
+int vnx_dynamic_mask_head_backward(int dtype, const void* mask_feats, const void* reference_points,
+                                   const void* params, const int32_t* inst_image, const void* grad_out,
+                                   void* grad_feats, void* grad_ref, void* grad_params,
+                                   int num_images, int channels, int height, int width,
+                                   int num_insts, int num_params, int stride, void* hip_stream);
 
 /*
  * IDOL re-identification head: similarity matrix  out[i, j] = <a_i, b_j>  for a [n, channels]

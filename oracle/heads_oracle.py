@@ -74,6 +74,57 @@ def dynamic_mask_head(mask_feats, reference_points, params, num_insts, stride=8,
     return aligned_bilinear_x2(logits) if upsample else logits
 
 
+def aligned_bilinear_x2_adjoint(g):
+    """Transpose of aligned_bilinear_x2: [..., 2h, 2w] -> [..., h, w]."""
+    def down1d(a, axis):
+        a = np.moveaxis(a, axis, -1)
+        out = a[..., 1::2].copy()                            # Y = 2k+1 <- in[k]
+        out[..., 0] += a[..., 0]                             # Y = 0    <- in[0]
+        out[..., :-1] += 0.5 * a[..., 2::2]                  # Y = 2k   <- (in[k-1] + in[k]) / 2
+        out[..., 1:] += 0.5 * a[..., 2::2]
+        return np.moveaxis(out, -1, axis)
+    return down1d(down1d(g, -2), -1)
+
+
+def dynamic_mask_head_backward(mask_feats, reference_points, params, num_insts, grad_out, stride=8):
+    """Gradients of dynamic_mask_head(...) contracted with grad_out [sum n, 2H, 2W]:
+    -> (grad_feats [N, 8, H, W], grad_ref [sum n, 2], grad_params [sum n, 169]).
+    What autograd derives for the reference chain (grouped 1x1 convs + ReLU,
+    segmentation_condInst.py:404-422; the `.float()` on the relative coordinates passes the
+    gradient through); ReLU gradient is 0 at 0 like F.relu's."""
+    mask_feats = np.asarray(mask_feats)
+    dt = mask_feats.dtype
+    N, C, H, W = mask_feats.shape
+    params = np.asarray(params, dtype=dt)
+    W0, W1, W2, b0, b1, b2 = split_params(params, C)
+    ref = np.asarray(reference_points, dtype=dt)
+    xs = (np.arange(W, dtype=np.float32) * stride + stride // 2).astype(dt)
+    ys = (np.arange(H, dtype=np.float32) * stride + stride // 2).astype(dt)
+    gl_all = aligned_bilinear_x2_adjoint(np.asarray(grad_out, dtype=dt)).reshape(-1, 1, H * W)
+    gfeats = np.zeros_like(mask_feats)
+    gref = np.zeros_like(ref)
+    gparams = np.zeros_like(params)
+    j = 0
+    for i, n in enumerate(num_insts):
+        feats = mask_feats[i].reshape(C, H * W)
+        for _ in range(n):
+            relx = np.broadcast_to((ref[j, 0] - xs[None, :]).astype(np.float32).astype(dt), (H, W)).reshape(1, H * W)
+            rely = np.broadcast_to((ref[j, 1] - ys[:, None]).astype(np.float32).astype(dt), (H, W)).reshape(1, H * W)
+            x0 = np.concatenate([relx, rely, feats], 0)
+            x1 = np.maximum(W0[j] @ x0 + b0[j][:, None], 0)
+            x2 = np.maximum(W1[j] @ x1 + b1[j][:, None], 0)
+            gl = gl_all[j]                                    # [1, HW]
+            g2 = (W2[j].T @ gl) * (x2 > 0)                    # [8, HW]
+            g1 = (W1[j].T @ g2) * (x1 > 0)
+            g0 = W0[j].T @ g1                                 # [10, HW]
+            gparams[j] = np.concatenate([(g1 @ x0.T).ravel(), (g2 @ x1.T).ravel(), (gl @ x2.T).ravel(),
+                                         g1.sum(1), g2.sum(1), gl.sum(1)])
+            gref[j] = g0[:2].sum(1)
+            gfeats[i] += g0[2:].reshape(C, H, W)
+            j += 1
+    return gfeats, gref, gparams
+
+
 # ------------------------------------------------------------------------ reid head
 def bisoftmax(sim):
     """(softmax over tracks + softmax over detections) / 2   (tracker.py:232-235)"""

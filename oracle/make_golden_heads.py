@@ -40,11 +40,17 @@ def main():
         n_all = sum(num_insts)
         ref = torch.rand(1, n_all, 2, generator=gen) * torch.tensor([W * 8.0, H * 8.0])
         params = 0.3 * torch.randn(1, n_all, 169, generator=gen)
+        feats.requires_grad_(True); ref.requires_grad_(True); params.requires_grad_(True)
         out = fns["dynamic_mask_with_coords"](me, feats, ref, params, num_insts=num_insts,
                                               mask_feat_stride=8, rel_coord=True)
+        # gradients of the reference chain (autograd) for a seeded upstream gradient
+        gout = torch.randn(out.shape, generator=gen)
+        gfeats, gref, gparams = torch.autograd.grad(out, (feats, ref, params), gout)
+        feats, ref, params, out = feats.detach(), ref.detach(), params.detach(), out.detach()
         path = os.path.join(OUT_DIR, f"heads_mask_{name}.npz")
         np.savez_compressed(path, feats=feats.numpy(), ref=ref[0].numpy(), params=params[0].numpy(),
-                            num_insts=np.array(num_insts), out=out[0].numpy())
+                            num_insts=np.array(num_insts), out=out[0].numpy(), grad_out=gout[0].numpy(),
+                            grad_feats=gfeats.numpy(), grad_ref=gref[0].numpy(), grad_params=gparams[0].numpy())
         print(f"{name:16s} {tuple(out.shape)} {os.path.getsize(path)/1024:7.1f} KiB")
 
     run("small", 1, 5, 7, [3], 1)

@@ -24,6 +24,23 @@ def test_oracle_matches_reference_functions(name):
     np.testing.assert_allclose(out, g["out"], rtol=1e-12, atol=1e-12)
 
 
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_backward_matches_reference_autograd(name):
+    g = load(name)
+    gf, gr, gp = H.dynamic_mask_head_backward(g["feats"], g["ref"], g["params"], list(g["num_insts"]), g["grad_out"])
+    np.testing.assert_allclose(gf, g["grad_feats"], rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(gp, g["grad_params"], rtol=1e-11, atol=1e-9)
+    # the reference's `.float()` on the relative coordinates rounds this one gradient to fp32
+    np.testing.assert_allclose(gr, g["grad_ref"], rtol=1e-6, atol=1e-6)
+
+
+def test_upsampling_adjoint_is_the_transpose():
+    rng = np.random.default_rng(0)
+    x, g = rng.standard_normal((3, 4, 7)), rng.standard_normal((3, 8, 14))
+    np.testing.assert_allclose((H.aligned_bilinear_x2(x) * g).sum(), (x * H.aligned_bilinear_x2_adjoint(g)).sum(),
+                               rtol=1e-12)
+
+
 def test_upsampling_closed_form_is_the_pad_interpolate_crop_chain():
     x = torch.randn(2, 1, 5, 9, dtype=torch.float64)
     t = torch.nn.functional.pad(x, (0, 1, 0, 1), mode="replicate")
@@ -88,9 +105,65 @@ def test_kernel_at_frame_sizes(H_, W_, n):
         np.testing.assert_allclose(out[0, j].double().cpu().numpy(), one[0], rtol=0, atol=2e-5 * scale)
 
 
-@pytest.mark.gpu
-def test_gradients_are_refused_loudly():
+def _grads_on_gpu(feats, ref, params, counts, gout):
     from vnext_amd.heads import dynamic_mask_with_coords
-    p = torch.zeros(1, 1, 169, device="cuda:0", requires_grad=True)
-    with pytest.raises(NotImplementedError, match="backward is not built"):
-        dynamic_mask_with_coords(torch.zeros(1, 8, 2, 2, device="cuda:0"), torch.zeros(1, 1, 2, device="cuda:0"), p, [1], 8)
+    dev = "cuda:0"
+    f = feats.float().to(dev).requires_grad_(True)
+    r = ref.float().to(dev)[None].requires_grad_(True)
+    p = params.float().to(dev)[None].requires_grad_(True)
+    out = dynamic_mask_with_coords(f, r, p, counts, 8)
+    gf, gr, gp = torch.autograd.grad(out, (f, r, p), gout.float().to(dev)[None])
+    torch.cuda.synchronize()
+    return gf.double().cpu().numpy(), gr[0].double().cpu().numpy(), gp[0].double().cpu().numpy()
+
+
+def _close(got, want, tol):
+    scale = max(1e-9, float(np.abs(want).max()))
+    np.testing.assert_allclose(got, want, rtol=0, atol=tol * scale)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_backward_kernel_matches_reference_autograd(name):
+    g = load(name)
+    counts = [int(n) for n in g["num_insts"]]
+    gf, gr, gp = _grads_on_gpu(torch.from_numpy(g["feats"]), torch.from_numpy(g["ref"]),
+                               torch.from_numpy(g["params"]), counts, torch.from_numpy(g["grad_out"]))
+    # against the oracle on the same fp32-rounded inputs (tight), then the reference's fp64 run
+    f32 = lambda a: a.astype(np.float32).astype(np.float64)
+    of, orf, op = H.dynamic_mask_head_backward(f32(g["feats"]), f32(g["ref"]), f32(g["params"]), counts, f32(g["grad_out"]))
+    for got, want, ref64 in ((gf, of, g["grad_feats"]), (gr, orf, g["grad_ref"]), (gp, op, g["grad_params"])):
+        _close(got, want, 2e-5)
+        _close(got, ref64, 1e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H_,W_,counts", [(48, 80, [7, 0, 12]), (92, 160, [3, 5]), (1, 130, [2]), (17, 1, [2, 1]),
+                                          (9, 63, [1]), (8, 64, [2])])
+def test_backward_kernel_at_frame_sizes(H_, W_, counts):
+    """Training-like instance counts at the 360p / 720p mask-feature sizes plus strip-edge shapes,
+    against the fp64 oracle; and linearity in grad_out."""
+    gen = torch.Generator().manual_seed(H_ * 977 + W_)
+    n_all = sum(counts)
+    feats = torch.randn(len(counts), 8, H_, W_, generator=gen)
+    ref = torch.rand(n_all, 2, generator=gen) * torch.tensor([W_ * 8.0, H_ * 8.0])
+    params = 0.3 * torch.randn(n_all, 169, generator=gen)
+    gout = torch.randn(n_all, 2 * H_, 2 * W_, generator=gen)
+    gf, gr, gp = _grads_on_gpu(feats, ref, params, counts, gout)
+    of, orf, op = H.dynamic_mask_head_backward(feats.double().numpy(), ref.double().numpy(), params.double().numpy(),
+                                               counts, gout.double().numpy())
+    _close(gf, of, 2e-5)
+    _close(gr, orf, 2e-5)
+    _close(gp, op, 2e-5)
+    gf2, gr2, gp2 = _grads_on_gpu(feats, ref, params, counts, -2.0 * gout)
+    _close(gf2, -2.0 * gf, 1e-5)
+    _close(gp2, -2.0 * gp, 1e-5)
+    assert gf.shape == feats.shape and not np.any(gf[1]) if counts[1:2] == [0] else True
+
+
+@pytest.mark.gpu
+def test_no_instances_gives_empty_output_and_zero_feature_gradient():
+    from vnext_amd.heads import dynamic_mask_with_coords
+    f = torch.randn(1, 8, 4, 6, device="cuda:0", requires_grad=True)
+    out = dynamic_mask_with_coords(f, torch.zeros(1, 0, 2, device="cuda:0"), torch.zeros(1, 0, 169, device="cuda:0"), [0], 8)
+    assert out.shape == (1, 0, 8, 12)

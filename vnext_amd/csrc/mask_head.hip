@@ -158,6 +158,209 @@ dynamic_mask_head_kernel(const float* __restrict__ feats, const float* __restric
   }
 }
 
+
+// ------------------------------------------------------------------------------ backward
+// Training path (forward_mask_head_train, segmentation_condInst.py:354-401: the matched
+// instances of every frame, for each of the 6 decoder layers).  Autograd's chain for the
+// reference is: transpose of the x2 up-sampling, three grouped-conv backward-data and three
+// backward-weight launches with groups = n, the ReLU masks, and the sum over the repeated
+// feature map.  Here one kernel: a wave owns (instance, 63 columns x kMbRows rows), recomputes
+// the two hidden layers of its pixels from the 8 features (nothing was saved by the forward),
+// back-propagates, keeps the 169 parameter gradients + 2 reference-point gradients as
+// lane-local sums over its rows, reduces them across the wave with DPP once, and adds them to
+// grad_params / grad_ref; the feature gradients of all instances of a frame meet in grad_feats
+// through coalesced fp32 atomics.  Outputs are zero-filled by the C entry point (memset nodes,
+// graph-capturable).  Lane 63 is a one-pixel halo on the right: the transpose of the
+// up-sampling needs the upstream gradient around pixel (y, x+1) and (y+1, x+1).
+constexpr int kMbRows = 8;
+
+struct UpAdj { float d, c, b, a; };  // what a pixel's 2x2 output block sends to in[y][x], in[y][x-1], in[y-1][x], in[y-1][x-1]
+
+__device__ __forceinline__ float lane_above(float v) {
+  // lane l receives lane l+1 (wave_shl:1); lane 63's result is never used
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v),
+                                                                0x130, 0xF, 0xF, false));
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_fold(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+
+// sum over the 64 lanes; valid in lane 63
+__device__ __forceinline__ float wave_sum_to_last(float v) {
+  v = dpp_fold<0x111, 0xF>(v);  // row_shr:1
+  v = dpp_fold<0x112, 0xF>(v);  // row_shr:2
+  v = dpp_fold<0x114, 0xF>(v);  // row_shr:4
+  v = dpp_fold<0x118, 0xF>(v);  // row_shr:8   -> lane 15 of each row holds the row's sum
+  v = dpp_fold<0x142, 0xA>(v);  // row_bcast:15 -> rows 1, 3
+  v = dpp_fold<0x143, 0xC>(v);  // row_bcast:31 -> rows 2, 3
+  return v;
+}
+
+__global__ void __launch_bounds__(64)
+dynamic_mask_head_bwd_kernel(const float* __restrict__ feats, const float* __restrict__ ref,
+                             const float* __restrict__ params, const int* __restrict__ inst_image,
+                             const float* __restrict__ grad_out, float* __restrict__ grad_feats,
+                             float* __restrict__ grad_ref, float* __restrict__ grad_params,
+                             int H, int W, int n_inst, int stride, int strips_x, int strips_y) {
+  const int lane = threadIdx.x;
+  const int strips = strips_x * strips_y;
+  const int j = int(blockIdx.x) / strips;  // instance
+  if (j >= n_inst) return;
+  const int s = int(blockIdx.x) - j * strips;
+  const int sy = s / strips_x, sx = s - sy * strips_x;
+  const int x = sx * kMhStripW + lane;               // lane 63 is the right halo
+  const int xc = x > W - 1 ? W - 1 : x;
+  const int y0 = sy * kMbRows;
+  const bool col_ok = x < W;
+  const bool owner = col_ok && lane < kMhStripW;
+
+  const float* P = params + int64_t(j) * kMhParams;
+  constexpr int W0 = 0, W1 = 80, W2 = 144, B0 = 152, B1 = 160;
+  const float refx = ref[2 * j], refy = ref[2 * j + 1];
+  const int img = inst_image[j];
+  const float* F = feats + int64_t(img) * kMhChannels * H * W;
+  float* GF = grad_feats + int64_t(img) * kMhChannels * H * W;
+  const float* G = grad_out + int64_t(j) * (2 * H) * (2 * W);
+  const float half = float(stride / 2);
+  const float relx = refx - (float(xc * stride) + half);
+
+  auto up_adj = [&](int y) -> UpAdj {
+    float2_t top = {0.f, 0.f}, bot = {0.f, 0.f};
+    if (y < H && col_ok) {
+      top = *reinterpret_cast<const float2_t*>(G + int64_t(2 * y) * (2 * W) + 2 * x);
+      bot = *reinterpret_cast<const float2_t*>(G + int64_t(2 * y + 1) * (2 * W) + 2 * x);
+    }
+    const float q = 0.25f * top.x;
+    return UpAdj{q + 0.5f * (top.y + bot.x) + bot.y, q + 0.5f * bot.x, q + 0.5f * top.y, q};
+  };
+
+  float acc_w0[kMhHidden][kMhChannels + 2], acc_w1[kMhHidden][kMhHidden], acc_w2[kMhHidden];
+  float acc_b0[kMhHidden], acc_b1[kMhHidden], acc_b2 = 0.f, acc_rx = 0.f, acc_ry = 0.f;
+#pragma unroll
+  for (int o = 0; o < kMhHidden; ++o) {
+#pragma unroll
+    for (int i = 0; i < kMhChannels + 2; ++i) acc_w0[o][i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMhHidden; ++i) acc_w1[o][i] = 0.f;
+    acc_w2[o] = 0.f; acc_b0[o] = 0.f; acc_b1[o] = 0.f;
+  }
+
+  UpAdj cur = up_adj(y0);
+#pragma unroll 1
+  for (int r = 0; r < kMbRows; ++r) {
+    const int y = y0 + r;
+    if (y >= H) break;
+    const UpAdj nxt = up_adj(y + 1);  // zeros below the map
+    // d(loss)/d(logit[y][x]) before up-sampling: the transpose of
+    //   out[2y][2x] = (a+b+c+d)/4, out[2y][2x+1] = (b+d)/2, out[2y+1][2x] = (c+d)/2, out[2y+1][2x+1] = d
+    // with a, b, c the clamped upper-left / upper / left neighbours (clamping folds the
+    // first row's b, a and the first column's c, a back onto the pixel itself)
+    float gl = cur.d + lane_above(cur.c) + nxt.b + lane_above(nxt.a);
+    if (x == 0) gl += cur.c + nxt.a;
+    if (y == 0) gl += cur.b + lane_above(cur.a);
+    if (x == 0 && y == 0) gl += cur.a;
+    if (!owner) gl = 0.f;   // halo lane / columns past the map contribute nothing
+    cur = nxt;
+
+    float x0[kMhChannels + 2];
+    x0[0] = relx;
+    x0[1] = refy - (float(y * stride) + half);
+#pragma unroll
+    for (int c = 0; c < kMhChannels; ++c) x0[2 + c] = F[(int64_t(c) * H + y) * W + xc];
+    float x1[kMhHidden], x2[kMhHidden];
+#pragma unroll
+    for (int o = 0; o < kMhHidden; ++o) {
+      float a = P[B0 + o];
+#pragma unroll
+      for (int i = 0; i < kMhChannels + 2; ++i) a = fmaf(P[W0 + o * (kMhChannels + 2) + i], x0[i], a);
+      x1[o] = fmaxf(a, 0.f);
+    }
+#pragma unroll
+    for (int o = 0; o < kMhHidden; ++o) {
+      float a = P[B1 + o];
+#pragma unroll
+      for (int i = 0; i < kMhHidden; ++i) a = fmaf(P[W1 + o * kMhHidden + i], x1[i], a);
+      x2[o] = fmaxf(a, 0.f);
+    }
+    // layer 3: logit = w2 . x2 + b2
+    float g2[kMhHidden];
+    acc_b2 += gl;
+#pragma unroll
+    for (int o = 0; o < kMhHidden; ++o) {
+      acc_w2[o] = fmaf(gl, x2[o], acc_w2[o]);
+      g2[o] = x2[o] > 0.f ? P[W2 + o] * gl : 0.f;
+    }
+    // layer 2
+    float g1[kMhHidden];
+#pragma unroll
+    for (int i = 0; i < kMhHidden; ++i) g1[i] = 0.f;
+#pragma unroll
+    for (int o = 0; o < kMhHidden; ++o) {
+      acc_b1[o] += g2[o];
+#pragma unroll
+      for (int i = 0; i < kMhHidden; ++i) {
+        acc_w1[o][i] = fmaf(g2[o], x1[i], acc_w1[o][i]);
+        g1[i] = fmaf(P[W1 + o * kMhHidden + i], g2[o], g1[i]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < kMhHidden; ++i) g1[i] = x1[i] > 0.f ? g1[i] : 0.f;
+    // layer 1
+    float g0[kMhChannels + 2];
+#pragma unroll
+    for (int i = 0; i < kMhChannels + 2; ++i) g0[i] = 0.f;
+#pragma unroll
+    for (int o = 0; o < kMhHidden; ++o) {
+      acc_b0[o] += g1[o];
+#pragma unroll
+      for (int i = 0; i < kMhChannels + 2; ++i) {
+        acc_w0[o][i] = fmaf(g1[o], x0[i], acc_w0[o][i]);
+        g0[i] = fmaf(P[W0 + o * (kMhChannels + 2) + i], g1[o], g0[i]);
+      }
+    }
+    acc_rx += g0[0];   // rel = ref - pixel centre
+    acc_ry += g0[1];
+    if (owner) {
+#pragma unroll
+      for (int c = 0; c < kMhChannels; ++c) atomic_add(GF + (int64_t(c) * H + y) * W + x, g0[2 + c]);
+    }
+  }
+
+  // 171 wave reductions; total k lands in lane k % 64 of word k / 64, then three coalesced atomics
+  float res[3] = {0.f, 0.f, 0.f};
+  auto put = [&](int k, float v) {
+    const float t = wave_sum_to_last(v);
+    const int tot = __builtin_amdgcn_readlane(__builtin_bit_cast(int, t), 63);
+    if (lane == (k & 63)) res[k >> 6] = __builtin_bit_cast(float, tot);
+  };
+#pragma unroll
+  for (int o = 0; o < kMhHidden; ++o) {
+#pragma unroll
+    for (int i = 0; i < kMhChannels + 2; ++i) put(W0 + o * (kMhChannels + 2) + i, acc_w0[o][i]);
+  }
+#pragma unroll
+  for (int o = 0; o < kMhHidden; ++o) {
+#pragma unroll
+    for (int i = 0; i < kMhHidden; ++i) put(W1 + o * kMhHidden + i, acc_w1[o][i]);
+  }
+#pragma unroll
+  for (int o = 0; o < kMhHidden; ++o) {
+    put(W2 + o, acc_w2[o]);
+    put(B0 + o, acc_b0[o]);
+    put(B1 + o, acc_b1[o]);
+  }
+  put(168, acc_b2);
+  put(169, acc_rx);   // slots 169, 170 of word 2: the reference point
+  put(170, acc_ry);
+  float* GP = grad_params + int64_t(j) * kMhParams;
+  atomic_add(GP + lane, res[0]);
+  atomic_add(GP + 64 + lane, res[1]);
+  if (lane < kMhParams - 128) atomic_add(GP + 128 + lane, res[2]);
+  else if (lane < kMhParams - 128 + 2) atomic_add(grad_ref + 2 * j + (lane - (kMhParams - 128)), res[2]);
+}
+
 }  // namespace vnx
 
 using namespace vnx;
@@ -199,4 +402,55 @@ extern "C" int vnx_dynamic_mask_head_forward(int dtype, const void* mask_feats,
                      (const float*)params, (const int*)inst_image, (float*)out, height, width,
                      num_insts, stride, strips_x, strips_y);
   return check_launch("dynamic_mask_head");
+}
+
+extern "C" int vnx_dynamic_mask_head_backward(int dtype, const void* mask_feats, const void* reference_points,
+                                              const void* params, const int32_t* inst_image,
+                                              const void* grad_out, void* grad_feats, void* grad_ref,
+                                              void* grad_params, int num_images, int channels, int height,
+                                              int width, int num_insts, int num_params, int stride,
+                                              void* hip_stream) {
+  if (dtype != VNX_F32) {
+    set_error("vnx_dynamic_mask_head_backward: only f32 is built (got dtype %d)", dtype);
+    return VNX_ERR_UNSUPPORTED;
+  }
+  if (channels != kMhChannels || num_params != kMhParams) {
+    set_error("vnx_dynamic_mask_head_backward: built for %d feature channels / %d parameters; got %d / %d",
+              kMhChannels, kMhParams, channels, num_params);
+    return VNX_ERR_UNSUPPORTED;
+  }
+  if (num_images < 0 || height < 0 || width < 0 || num_insts < 0 || stride <= 0) {
+    set_error("vnx_dynamic_mask_head_backward: bad sizes");
+    return VNX_ERR_INVALID_ARGUMENT;
+  }
+  hipStream_t stream = (hipStream_t)hip_stream;
+  const size_t feat_bytes = size_t(num_images) * kMhChannels * height * width * sizeof(float);
+  if ((feat_bytes && !grad_feats) || (num_insts && (!grad_ref || !grad_params))) {
+    set_error("vnx_dynamic_mask_head_backward: null output pointer");
+    return VNX_ERR_INVALID_ARGUMENT;
+  }
+  // every output element is defined on return: zero-fill, then accumulate
+  if (feat_bytes && hipMemsetAsync(grad_feats, 0, feat_bytes, stream) != hipSuccess) return check_launch("mask_head_bwd memset");
+  if (num_insts) {
+    if (hipMemsetAsync(grad_ref, 0, size_t(num_insts) * 2 * sizeof(float), stream) != hipSuccess ||
+        hipMemsetAsync(grad_params, 0, size_t(num_insts) * kMhParams * sizeof(float), stream) != hipSuccess)
+      return check_launch("mask_head_bwd memset");
+  }
+  if (num_insts == 0 || height == 0 || width == 0) return VNX_OK;
+  if (!mask_feats || !reference_points || !params || !inst_image || !grad_out) {
+    set_error("vnx_dynamic_mask_head_backward: null pointer argument");
+    return VNX_ERR_INVALID_ARGUMENT;
+  }
+  const int strips_x = (width + kMhStripW - 1) / kMhStripW;
+  const int strips_y = (height + kMbRows - 1) / kMbRows;
+  const int64_t blocks = int64_t(num_insts) * strips_x * strips_y;
+  if (blocks >= (int64_t(1) << 31)) {
+    set_error("vnx_dynamic_mask_head_backward: %lld workgroups exceed the grid limit", (long long)blocks);
+    return VNX_ERR_UNSUPPORTED;
+  }
+  hipLaunchKernelGGL(dynamic_mask_head_bwd_kernel, dim3(uint32_t(blocks)), dim3(64), 0, stream,
+                     (const float*)mask_feats, (const float*)reference_points, (const float*)params,
+                     (const int*)inst_image, (const float*)grad_out, (float*)grad_feats, (float*)grad_ref,
+                     (float*)grad_params, height, width, num_insts, stride, strips_x, strips_y);
+  return check_launch("dynamic_mask_head_bwd");
 }

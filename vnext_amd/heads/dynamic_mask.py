@@ -9,8 +9,10 @@ returns the same `[1, sum(num_insts), H/4, W/4]` logits.  The reference material
 here one kernel reads the 8-channel features and the 169 parameters per instance and
 writes the logits -- see vnext_amd/csrc/mask_head.hip.
 
-Forward only for now (the inference path: 300 instances per frame); asking for gradients
-raises instead of silently falling back to a PyTorch op chain.
+Differentiable: the backward (training path, `forward_mask_head_train`, :354-401) is a second
+fused kernel that recomputes the hidden layers and returns the gradients of the mask
+features, the reference points and the parameters (`vnx_dynamic_mask_head_backward`).
+No double backward (the reference's loss never needs one).
 """
 from __future__ import annotations
 
@@ -41,6 +43,44 @@ def _instance_image_index(num_insts, device):
     return idx.to(device, non_blocking=True)
 
 
+class _DynamicMaskHead(torch.autograd.Function):
+    """feats [N,8,H,W], ref [n,2], params [n,169] (fp32, contiguous), inst_image [n] int32 -> [n,2H,2W]"""
+
+    @staticmethod
+    def forward(ctx, feats, ref, params, inst_image, stride):
+        N, C, H, W = feats.shape
+        n_all = ref.shape[0]
+        out = torch.empty((n_all, 2 * H, 2 * W), dtype=torch.float32, device=feats.device)
+        with torch.cuda.device(feats.device):
+            st = _lib.lib().vnx_dynamic_mask_head_forward(
+                _lib.VNX_F32, feats.data_ptr(), ref.data_ptr(), params.data_ptr(), inst_image.data_ptr(),
+                out.data_ptr(), N, C, H, W, n_all, params.shape[1], int(stride),
+                torch.cuda.current_stream(feats.device).cuda_stream)
+        _lib.check(st)
+        ctx.save_for_backward(feats, ref, params, inst_image)
+        ctx.stride = int(stride)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_out):
+        feats, ref, params, inst_image = ctx.saved_tensors
+        N, C, H, W = feats.shape
+        n_all = ref.shape[0]
+        grad_out = grad_out.to(torch.float32).contiguous()
+        gfeats = torch.empty_like(feats)
+        gref = torch.empty_like(ref)
+        gparams = torch.empty_like(params)
+        with torch.cuda.device(feats.device):
+            st = _lib.lib().vnx_dynamic_mask_head_backward(
+                _lib.VNX_F32, feats.data_ptr(), ref.data_ptr(), params.data_ptr(), inst_image.data_ptr(),
+                grad_out.data_ptr(), gfeats.data_ptr(), gref.data_ptr(), gparams.data_ptr(),
+                N, C, H, W, n_all, params.shape[1], ctx.stride,
+                torch.cuda.current_stream(feats.device).cuda_stream)
+        _lib.check(st)
+        return gfeats, gref, gparams, None, None
+
+
 def dynamic_mask_with_coords(mask_feats, reference_points, mask_head_params, num_insts,
                              mask_feat_stride, rel_coord=True):
     """mask_feats [N, 8, H, W]; reference_points [1, sum n, 2] (image pixels);
@@ -52,8 +92,6 @@ def dynamic_mask_with_coords(mask_feats, reference_points, mask_head_params, num
         raise NotImplementedError("dynamic mask head is built with rel_coord=True (the reference's setting)")
     if mask_feat_stride % MASK_OUT_STRIDE != 0 or mask_feat_stride // MASK_OUT_STRIDE != 2:
         raise NotImplementedError("dynamic mask head is built for mask_feat_stride / mask_out_stride == 2")
-    if any(t.requires_grad for t in (mask_feats, reference_points, mask_head_params)) and torch.is_grad_enabled():
-        raise NotImplementedError("dynamic mask head: backward is not built yet; call under torch.no_grad()")
     N, C, H, W = mask_feats.shape
     n_all = reference_points.shape[1]
     if sum(int(n) for n in num_insts) != n_all or len(num_insts) != N or mask_head_params.shape[1] != n_all:
@@ -63,15 +101,8 @@ def dynamic_mask_with_coords(mask_feats, reference_points, mask_head_params, num
     feats = mask_feats.contiguous()
     # the reference rounds the relative coordinates to fp32 (`.float()`, :447)
     ref = reference_points.reshape(n_all, 2).to(torch.float32).contiguous()
-    params = mask_head_params.reshape(n_all, -1).to(torch.float32).contiguous()
-    out = torch.empty((1, n_all, 2 * H, 2 * W), dtype=torch.float32, device=feats.device)
+    params = mask_head_params.reshape(n_all, mask_head_params.shape[-1]).to(torch.float32).contiguous()
     if n_all == 0:
-        return out
+        return torch.empty((1, 0, 2 * H, 2 * W), dtype=torch.float32, device=feats.device)
     inst_image = _instance_image_index([int(n) for n in num_insts], feats.device)
-    with torch.cuda.device(feats.device):
-        st = _lib.lib().vnx_dynamic_mask_head_forward(
-            _lib.VNX_F32, feats.data_ptr(), ref.data_ptr(), params.data_ptr(), inst_image.data_ptr(),
-            out.data_ptr(), N, C, H, W, n_all, params.shape[1], int(mask_feat_stride),
-            torch.cuda.current_stream(feats.device).cuda_stream)
-    _lib.check(st)
-    return out
+    return _DynamicMaskHead.apply(feats, ref, params, inst_image, int(mask_feat_stride))[None]
