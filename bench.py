@@ -140,8 +140,9 @@ def event_time_us(graph, launches, reps=15):
 def model_step_leg(rank, local_rank, world, device, steps, warmup=3):
     """clips/s of the SeqFormer-R50 training step (BASELINE config: T=5 synthetic 360p clip, 300
     queries): forward + backward + RCCL gradient all-reduce + clipped AdamW step, one clip per
-    rank (weak scaling).  The loss is the surrogate of vnext_amd/models/seqformer.py (matcher and
-    criterion are out of scope); every parameter of the hot path gets a gradient."""
+    rank (weak scaling).  The loss is the reference's objective (clip-level Hungarian matching,
+    focal / L1 / GIoU / mask focal + dice over the 6 decoder layers, vnext_amd/models/criterion.py)
+    on 4 synthetic tracks per clip, with the fused dynamic mask head forward and backward."""
     import torch.distributed as dist
     import vnext_amd.models  # noqa: F401
     from vnext_amd import train as T
@@ -151,7 +152,7 @@ def model_step_leg(rank, local_rank, world, device, steps, warmup=3):
     model = build_model(cfg).train()
     ddp = T.wrap_ddp(model, local_rank)
     opt = T.build_optimizer(model)
-    clips = T.synthetic_clips(1, 5, 360, 640, device, seed=100 + rank)
+    clips = T.synthetic_clips(1, 5, 360, 640, device, seed=100 + rank, num_instances=4)
     for _ in range(warmup):
         T.train_step(ddp, opt, clips)
     torch.cuda.synchronize()
@@ -177,7 +178,7 @@ def model_step_leg(rank, local_rank, world, device, steps, warmup=3):
             "clips_per_rank": 1, "n_gpus": world, "trainable_params": n_params,
             "grad_allreduce_MB_per_step": round(n_params * 4 / 1e6, 1),
             "config": "SeqFormer R50 (random init), T=5, 360x640 -> 384x640, 300 queries, 6+6 layers, fp32; "
-                      "surrogate loss; DDP static_graph + gradient_as_bucket_view over RCCL"}
+                      "SetCriterion on 4 synthetic tracks per clip (matcher + focal/L1/GIoU/mask losses, deep supervision); DDP static_graph + gradient_as_bucket_view over RCCL"}
 
 
 def latest_pmc_profile():

@@ -1,0 +1,57 @@
+"""Time the SeqFormer-R50 training step (and optionally inference) on one GPU.
+    python tools/time_model.py [--steps 10] [--infer] [--instances 4]
+Under rocprofv3 --kernel-trace --stats this gives the per-kernel breakdown of a step."""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import vnext_amd.models  # noqa: F401,E402
+from vnext_amd import train as T  # noqa: E402
+from vnext_amd.registry import build_model, get_seqformer_cfg  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--steps", type=int, default=10)
+ap.add_argument("--warmup", type=int, default=3)
+ap.add_argument("--instances", type=int, default=4)
+ap.add_argument("--infer", action="store_true")
+ap.add_argument("--phases", action="store_true", help="time forward / backward / optimizer separately")
+a = ap.parse_args()
+dev = "cuda:0"
+torch.manual_seed(0)
+model = build_model(get_seqformer_cfg(**{"MODEL.DEVICE": dev})).train()
+opt = T.build_optimizer(model)
+clips = T.synthetic_clips(1, 5, 360, 640, dev, seed=100, num_instances=a.instances)
+
+
+def timed(fn, n):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) * 1e3 / n
+
+
+for _ in range(a.warmup):
+    T.train_step(model, opt, clips)
+print(f"train step: {timed(lambda: T.train_step(model, opt, clips), a.steps):.2f} ms/step")
+if a.phases:
+    fw = timed(lambda: model(clips), a.steps)
+    def fb():
+        opt.zero_grad(set_to_none=True)
+        sum(model(clips).values()).backward()
+    fwbw = timed(fb, a.steps)
+    print(f"forward (with matching + losses): {fw:.2f} ms   forward+backward: {fwbw:.2f} ms")
+    with torch.no_grad():
+        x, mask = model._preprocess(clips)
+        t_bb = timed(lambda: model._features(x, mask), a.steps)
+        print(f"backbone + input_proj forward (no grad): {t_bb:.2f} ms")
+if a.infer:
+    model.eval()
+    for _ in range(2):
+        model(clips[:1])
+    print(f"inference: {timed(lambda: model(clips[:1]), a.steps):.2f} ms/clip (5 frames)")

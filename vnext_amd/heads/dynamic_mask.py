@@ -81,6 +81,27 @@ class _DynamicMaskHead(torch.autograd.Function):
         return gfeats, gref, gparams, None, None
 
 
+def dynamic_mask_head(mask_feats, points, params, inst_image, mask_feat_stride=8):
+    """Lower-level surface for callers that already hold a flat instance list:
+    mask_feats [N, 8, H, W]; points [n, 2] (x, y image pixels); params [n, 169];
+    inst_image [n] int32 (any order, any image) -> logits [n, 2H, 2W].  Differentiable."""
+    if not mask_feats.is_cuda:
+        raise RuntimeError("dynamic_mask_head: no CPU implementation (HIP library only)")
+    if mask_feats.dtype != torch.float32:
+        raise RuntimeError(f"dynamic mask head: float32 only for now (got {mask_feats.dtype})")
+    if mask_feat_stride // MASK_OUT_STRIDE != 2 or mask_feat_stride % MASK_OUT_STRIDE:
+        raise NotImplementedError("dynamic mask head is built for mask_feat_stride / mask_out_stride == 2")
+    n = points.shape[0]
+    if params.shape[0] != n or inst_image.shape[0] != n:
+        raise RuntimeError("dynamic_mask_head: points, params and inst_image disagree on the instance count")
+    H, W = mask_feats.shape[-2:]
+    if n == 0:
+        return torch.empty((0, 2 * H, 2 * W), dtype=torch.float32, device=mask_feats.device)
+    return _DynamicMaskHead.apply(mask_feats.contiguous(), points.to(torch.float32).contiguous(),
+                                  params.to(torch.float32).contiguous(),
+                                  inst_image.to(torch.int32).contiguous(), int(mask_feat_stride))
+
+
 def dynamic_mask_with_coords(mask_feats, reference_points, mask_head_params, num_insts,
                              mask_feat_stride, rel_coord=True):
     """mask_feats [N, 8, H, W]; reference_points [1, sum n, 2] (image pixels);

@@ -44,11 +44,35 @@ def shard_indices(num_items: int, rank: int, world: int):
     return list(range(rank, num_items, world))
 
 
-def synthetic_clips(num_clips: int, num_frames: int, height: int, width: int, device, seed: int = 0):
+def synthetic_clips(num_clips: int, num_frames: int, height: int, width: int, device, seed: int = 0,
+                    num_instances: int = 3, num_classes: int = 40):
+    """Random frames plus `num_instances` synthetic tracks per clip in the dataset mapper's layout
+    (per frame: gt_classes, gt_boxes xyxy pixels, gt_masks, gt_ids, image_size): a rectangle that
+    drifts from frame to frame, its mask the filled rectangle."""
     g = torch.Generator(device=device).manual_seed(seed)
-    return [{"image": [torch.rand(3, height, width, device=device, generator=g) * 255.0
-                       for _ in range(num_frames)], "height": height, "width": width}
-            for _ in range(num_clips)]
+    clips = []
+    for _ in range(num_clips):
+        frames = [torch.rand(3, height, width, device=device, generator=g) * 255.0 for _ in range(num_frames)]
+        clip = {"image": frames, "height": height, "width": width}
+        if num_instances > 0:
+            n = num_instances
+            ctr = 0.25 + 0.5 * torch.rand(n, 2, device=device, generator=g)
+            size = 0.1 + 0.25 * torch.rand(n, 2, device=device, generator=g)
+            cls = torch.randint(0, num_classes, (n,), device=device, generator=g)
+            wh = torch.tensor([width, height], device=device, dtype=torch.float32)
+            ys = torch.arange(height, device=device)[None, :, None]
+            xs = torch.arange(width, device=device)[None, None, :]
+            inst = []
+            for t in range(num_frames):
+                c = (ctr + 0.02 * t).clamp(0.05, 0.95)
+                lo, hi = ((c - size / 2).clamp(0, 1) * wh), ((c + size / 2).clamp(0, 1) * wh)
+                masks = (xs >= lo[:, 0, None, None]) & (xs < hi[:, 0, None, None]) & \
+                        (ys >= lo[:, 1, None, None]) & (ys < hi[:, 1, None, None])
+                inst.append({"gt_classes": cls, "gt_boxes": torch.cat([lo, hi], 1), "gt_masks": masks,
+                             "gt_ids": torch.arange(n, device=device), "image_size": (height, width)})
+            clip["instances"] = inst
+        clips.append(clip)
+    return clips
 
 
 def wrap_ddp(model, local_rank: int | None = None):
