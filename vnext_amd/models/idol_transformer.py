@@ -1,0 +1,199 @@
+"""IDOL's per-frame deformable transformer on the MI355X op (SURVEY.md section 8 row a5 callers).
+
+Module tree and parameter names are those of
+projects/IDOL/idol/models/deformable_transformer.py (encoder.layers.N.self_attn,
+decoder.layers.N.{cross_attn,self_attn,...}, level_embed, reference_points) so reference
+checkpoints load unchanged; `two_stage` is never enabled by IDOL's configs and is not built.
+Frames are independent here (no clip axis): the op batch is the number of frames in the call
+-- key + reference frames in training, up to BATCH_INFER_LEN frames in inference.
+
+Not reproduced: the decoder's top-30 sample keeper (:352-358).  Its output (`inter_samples`)
+is returned by the reference transformer and dropped by every caller
+(segmentation_condInst.py:142-143, :281); computing it costs a 128-wide top-k per query per
+layer.  `return_samples=True` brings it back for callers that want it.
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+from torch.nn.init import constant_, normal_, xavier_uniform_
+
+from ..ops.functions import mark_levels_packed
+from ..ops.modules import MSDeformAttnIDOL
+from .seqformer_transformer import DeformableTransformerEncoder as _ClipEncoder
+from .seqformer_transformer import _get_activation_fn, _get_clones, inverse_sigmoid
+
+
+class DeformableTransformerEncoderLayer(nn.Module):
+    def __init__(self, d_model=256, d_ffn=1024, dropout=0.1, activation="relu", n_levels=4, n_heads=8, n_points=4):
+        super().__init__()
+        self.self_attn = MSDeformAttnIDOL(d_model, n_levels, n_heads, n_points)
+        self.dropout1 = nn.Dropout(dropout)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.linear1 = nn.Linear(d_model, d_ffn)
+        self.activation = _get_activation_fn(activation)
+        self.dropout2 = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(d_ffn, d_model)
+        self.dropout3 = nn.Dropout(dropout)
+        self.norm2 = nn.LayerNorm(d_model)
+
+    def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None):
+        q = src if pos is None else src + pos
+        src2 = self.self_attn(q, reference_points, src, spatial_shapes, level_start_index, padding_mask)[0]
+        src = self.norm1(src + self.dropout1(src2))
+        src2 = self.linear2(self.dropout2(self.activation(self.linear1(src))))
+        return self.norm2(src + self.dropout3(src2))
+
+
+class DeformableTransformerEncoder(nn.Module):
+    def __init__(self, encoder_layer, num_layers):
+        super().__init__()
+        self.layers = _get_clones(encoder_layer, num_layers)
+        self.num_layers = num_layers
+
+    get_reference_points = staticmethod(_ClipEncoder.get_reference_points)   # same construction (:249-261)
+
+    def forward(self, src, spatial_shapes, level_start_index, valid_ratios, pos=None, padding_mask=None,
+                spatial_shapes_list=None):
+        shapes = spatial_shapes_list if spatial_shapes_list is not None else spatial_shapes.tolist()
+        reference_points = self.get_reference_points(shapes, valid_ratios, device=src.device)
+        for layer in self.layers:
+            src = layer(src, pos, reference_points, spatial_shapes, level_start_index, padding_mask)
+        return src
+
+
+class DeformableTransformerDecoderLayer(nn.Module):
+    def __init__(self, d_model=256, d_ffn=1024, dropout=0.1, activation="relu", n_levels=4, n_heads=8, n_points=4):
+        super().__init__()
+        self.cross_attn = MSDeformAttnIDOL(d_model, n_levels, n_heads, n_points)
+        self.dropout1 = nn.Dropout(dropout)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.self_attn = nn.MultiheadAttention(d_model, n_heads, dropout=dropout)
+        self.dropout2 = nn.Dropout(dropout)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.linear1 = nn.Linear(d_model, d_ffn)
+        self.activation = _get_activation_fn(activation)
+        self.dropout3 = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(d_ffn, d_model)
+        self.dropout4 = nn.Dropout(dropout)
+        self.norm3 = nn.LayerNorm(d_model)
+
+    def forward(self, tgt, query_pos, reference_points, src, src_spatial_shapes, level_start_index,
+                src_padding_mask=None):
+        q = k = tgt if query_pos is None else tgt + query_pos
+        tgt2 = self.self_attn(q.transpose(0, 1), k.transpose(0, 1), tgt.transpose(0, 1))[0].transpose(0, 1)
+        tgt = self.norm2(tgt + self.dropout2(tgt2))
+        tgt2, loc, w = self.cross_attn(tgt if query_pos is None else tgt + query_pos, reference_points, src,
+                                       src_spatial_shapes, level_start_index, src_padding_mask)
+        tgt = self.norm1(tgt + self.dropout1(tgt2))
+        tgt2 = self.linear2(self.dropout3(self.activation(self.linear1(tgt))))
+        return self.norm3(tgt + self.dropout4(tgt2)), loc, w
+
+
+class DeformableTransformerDecoder(nn.Module):
+    def __init__(self, decoder_layer, num_layers, return_intermediate=False, return_samples=False):
+        super().__init__()
+        self.layers = _get_clones(decoder_layer, num_layers)
+        self.num_layers = num_layers
+        self.return_intermediate = return_intermediate
+        self.return_samples = return_samples
+        self.bbox_embed = None      # installed by the detector for iterative box refinement
+        self.class_embed = None
+
+    def forward(self, tgt, reference_points, src, src_spatial_shapes, src_level_start_index, src_valid_ratios,
+                query_pos=None, src_padding_mask=None):
+        output = tgt
+        inter, inter_refs, inter_samples = [], [], []
+        for lid, layer in enumerate(self.layers):
+            if reference_points.shape[-1] == 4:
+                ref_in = reference_points[:, :, None] * torch.cat([src_valid_ratios, src_valid_ratios], -1)[:, None]
+            else:
+                assert reference_points.shape[-1] == 2
+                ref_in = reference_points[:, :, None] * src_valid_ratios[:, None]
+            output, loc, w = layer(output, query_pos, ref_in, src, src_spatial_shapes, src_level_start_index,
+                                   src_padding_mask)
+            if self.return_samples:   # the 30 heaviest sampling points of every query (:352-358)
+                N, Lq = loc.shape[:2]
+                loc = (loc / src_valid_ratios[:, None, None, None, :, :]).view(N, Lq, -1, 2)
+                top = w.view(N, Lq, -1).topk(30, dim=2)[1]
+                inter_samples.append(torch.gather(loc, 2, top.unsqueeze(-1).expand(-1, -1, -1, 2)))
+            if self.bbox_embed is not None:
+                tmp = self.bbox_embed[lid](output)
+                if reference_points.shape[-1] == 4:
+                    new_ref = (tmp + inverse_sigmoid(reference_points)).sigmoid()
+                else:
+                    new_ref = tmp
+                    new_ref[..., :2] = tmp[..., :2] + inverse_sigmoid(reference_points)
+                    new_ref = new_ref.sigmoid()
+                reference_points = new_ref.detach()
+            if self.return_intermediate:
+                inter.append(output)
+                inter_refs.append(reference_points)
+        if self.return_intermediate:
+            return torch.stack(inter), torch.stack(inter_refs), (torch.stack(inter_samples) if inter_samples else None)
+        return output, reference_points
+
+
+class DeformableTransformer(nn.Module):
+    def __init__(self, d_model=256, nhead=8, num_encoder_layers=6, num_decoder_layers=6, dim_feedforward=1024,
+                 dropout=0.1, activation="relu", return_intermediate_dec=False, num_frames=1,
+                 num_feature_levels=4, dec_n_points=4, enc_n_points=4, two_stage=False, return_samples=False):
+        super().__init__()
+        if two_stage:
+            raise NotImplementedError("two_stage is never enabled by IDOL's configs")
+        self.d_model, self.nhead, self.two_stage = d_model, nhead, False
+        self.num_frames = 1
+        self.num_feature_levels = num_feature_levels
+        enc = DeformableTransformerEncoderLayer(d_model, dim_feedforward, dropout, activation, num_feature_levels,
+                                                nhead, enc_n_points)
+        self.encoder = DeformableTransformerEncoder(enc, num_encoder_layers)
+        dec = DeformableTransformerDecoderLayer(d_model, dim_feedforward, dropout, activation, num_feature_levels,
+                                                nhead, dec_n_points)
+        self.decoder = DeformableTransformerDecoder(dec, num_decoder_layers, return_intermediate_dec, return_samples)
+        self.level_embed = nn.Parameter(torch.Tensor(num_feature_levels, d_model))
+        self.reference_points = nn.Linear(d_model, 2)
+        self._reset_parameters()
+
+    def _reset_parameters(self):
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+        for m in self.modules():
+            if isinstance(m, MSDeformAttnIDOL):
+                m._reset_parameters()
+        xavier_uniform_(self.reference_points.weight.data, gain=1.0)
+        constant_(self.reference_points.bias.data, 0.)
+        normal_(self.level_embed)
+
+    @staticmethod
+    def get_valid_ratio(mask):
+        _, H, W = mask.shape
+        valid_H = torch.sum(~mask[:, :, 0], 1)
+        valid_W = torch.sum(~mask[:, 0, :], 1)
+        return torch.stack([valid_W.float() / W, valid_H.float() / H], -1)
+
+    def forward(self, srcs, masks, pos_embeds, query_embed=None):
+        """srcs: per level [N, C, H_l, W_l]; -> (hs [Ld, N, Q, C], memory [N, S, C], init_reference
+        [N, Q, 2], inter_references [Ld, N, Q, 4], inter_samples | None, None, None)  (:135-198)"""
+        assert query_embed is not None
+        src_flatten, mask_flatten, pos_flatten, shapes = [], [], [], []
+        for lvl, (src, mask, pos) in enumerate(zip(srcs, masks, pos_embeds)):
+            shapes.append(tuple(src.shape[-2:]))
+            src_flatten.append(src.flatten(2).transpose(1, 2))
+            mask_flatten.append(mask.flatten(1))
+            pos_flatten.append(pos.flatten(2).transpose(1, 2) + self.level_embed[lvl].view(1, 1, -1))
+        src_flatten, mask_flatten, pos_flatten = torch.cat(src_flatten, 1), torch.cat(mask_flatten, 1), torch.cat(pos_flatten, 1)
+        spatial_shapes = torch.as_tensor(shapes, dtype=torch.long, device=src_flatten.device)
+        level_start_index = mark_levels_packed(
+            torch.cat((spatial_shapes.new_zeros((1,)), spatial_shapes.prod(1).cumsum(0)[:-1])))
+        valid_ratios = torch.stack([self.get_valid_ratio(m) for m in masks], 1)
+        memory = self.encoder(src_flatten, spatial_shapes, level_start_index, valid_ratios, pos_flatten,
+                              mask_flatten, spatial_shapes_list=shapes)
+        bs, _, c = memory.shape
+        query_embed, tgt = torch.split(query_embed, c, dim=1)
+        query_embed = query_embed.unsqueeze(0).expand(bs, -1, -1)
+        tgt = tgt.unsqueeze(0).expand(bs, -1, -1)
+        reference_points = self.reference_points(query_embed).sigmoid()
+        hs, inter_references, inter_samples = self.decoder(tgt, reference_points, memory, spatial_shapes,
+                                                           level_start_index, valid_ratios, query_embed, mask_flatten)
+        return hs, memory, reference_points, inter_references, inter_samples, None, None
