@@ -1,0 +1,147 @@
+"""IDOL meta-architecture (b): registry surface, training branch, and the
+video-level inference post-processing against the reference's `IDOL.inference` + IDOL_Tracker
+(oracle/make_golden_idol_inference.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import vnext_amd.models  # noqa: F401
+from conftest import GOLDEN_DIR
+from vnext_amd import train as T
+from vnext_amd.models import idol as idol_mod
+from vnext_amd.models import tracker as trk
+from vnext_amd.registry import META_ARCH_REGISTRY, build_model, get_idol_cfg
+
+TINY = {"MODEL.IDOL.ENC_LAYERS": 1, "MODEL.IDOL.DEC_LAYERS": 2, "MODEL.IDOL.NUM_OBJECT_QUERIES": 110,
+        "MODEL.IDOL.DIM_FEEDFORWARD": 64, "MODEL.IDOL.DROPOUT": 0.0}
+
+
+def _loss_reid_torch(ref, key, pos, neg, aux):
+    dot = ref @ key.t()
+    cos = torch.nn.functional.normalize(ref, dim=1) @ torch.nn.functional.normalize(key, dim=1).t()
+    lse_neg = torch.logsumexp(dot.masked_fill(~neg, float("-inf")), dim=0)
+    lse_pos = torch.logsumexp((-dot).masked_fill(~pos, float("-inf")), dim=0)
+    contrast = torch.nn.functional.softplus((lse_neg + lse_pos).clamp_min(torch.finfo(dot.dtype).min))
+    return contrast.sum(), ((((cos - pos.to(cos.dtype)) ** 2) * aux).sum(0) / aux.sum(0).clamp_min(1)).sum()
+
+
+def _torch_scores(embeds, memo, metric):
+    feats = embeds @ memo.t()
+    return (feats.softmax(1) + feats.softmax(0)) / 2 if metric == "bisoftmax" else feats.softmax(1)
+
+
+@pytest.fixture
+def cpu_stand_ins(monkeypatch):
+    """PyTorch restatements (oracle/, tests only) for the HIP entry points so the model steps on CPU."""
+    from oracle.heads_torch_fallback import dynamic_mask_head_torch
+    from oracle.msda_torch_fallback import msda_grid_sample
+    from vnext_amd.ops.modules import ms_deform_attn as mod
+
+    class Fn:
+        @staticmethod
+        def apply(value, shapes, lsi, loc, attn, step):
+            return msda_grid_sample(value, shapes, loc, attn)
+    monkeypatch.setattr(mod, "MSDeformAttnFunction", Fn)
+    monkeypatch.setattr(idol_mod, "dynamic_mask_head", dynamic_mask_head_torch)
+    monkeypatch.setattr(idol_mod, "loss_reid", _loss_reid_torch)
+    monkeypatch.setattr(trk, "_pairwise_dot", lambda a, b: a @ b.t())
+    monkeypatch.setattr(trk, "_match_scores", _torch_scores)
+
+
+def test_registry_and_state_dict_names():
+    assert "IDOL" in META_ARCH_REGISTRY
+    model = build_model(get_idol_cfg(**{"MODEL.DEVICE": "cpu", **TINY}))
+    keys = set(model.state_dict())
+    for k in ("detr.detr.transformer.encoder.layers.0.self_attn.sampling_offsets.weight",
+              "detr.detr.transformer.decoder.layers.1.cross_attn.output_proj.weight",
+              "detr.detr.transformer.decoder.layers.0.self_attn.in_proj_weight",
+              "detr.detr.transformer.level_embed", "detr.detr.transformer.reference_points.weight",
+              "detr.detr.class_embed.1.weight", "detr.detr.bbox_embed.0.layers.2.bias", "detr.detr.query_embed.weight",
+              "detr.controller.layers.2.weight", "detr.mask_head.lay1.weight", "detr.reid_embed_head.layers.1.weight"):
+        assert k in keys, k
+    assert not any("output_proj_box" in k or "self_attn_box" in k for k in keys)      # SeqFormer-only modules
+
+
+def test_training_branch_loss_names_and_gradients(cpu_stand_ins):
+    torch.manual_seed(2)
+    model = build_model(get_idol_cfg(**{"MODEL.DEVICE": "cpu", **TINY})).train()
+    pairs = T.synthetic_clips(2, 2, 64, 96, "cpu", seed=9, num_instances=2)
+    pairs[1]["instances"][1]["gt_ids"] = torch.tensor([0, -1])       # an object missing from a reference frame
+    losses = model(pairs)
+    names = {"loss_ce", "loss_bbox", "loss_giou", "loss_mask", "loss_dice"}
+    assert set(losses) == names | {"loss_reid", "loss_reid_aux"} | {f"{k}_0" for k in names}
+    assert all(torch.isfinite(v) for v in losses.values())
+    sum(losses.values()).backward()
+    missing = [n for n, p in model.named_parameters() if p.requires_grad and p.grad is None]
+    assert not missing, missing
+
+
+def test_inference_output_format(cpu_stand_ins):
+    torch.manual_seed(3)
+    model = build_model(get_idol_cfg(**{"MODEL.DEVICE": "cpu", "MODEL.IDOL.BATCH_INFER_LEN": 2, **TINY})).eval()
+    g = torch.Generator().manual_seed(0)
+    video = [{"image": [torch.rand(3, 64, 96, generator=g) * 255 for _ in range(3)], "height": 70, "width": 100}]
+    res = model(video)
+    assert set(res) == {"image_size", "pred_scores", "pred_labels", "pred_masks"}       # idol.py:466-471
+    assert res["image_size"] == (70, 100) and len(res["pred_masks"]) == len(res["pred_scores"]) == len(res["pred_labels"])
+    for track in res["pred_masks"]:
+        assert len(track) == 3 and all(m is None or (tuple(m.shape) == (70, 100) and m.dtype == torch.bool) for m in track)
+
+
+def _associate_from_golden(g, v, device):
+    model = build_model(get_idol_cfg(**{"MODEL.DEVICE": device, **TINY})).eval()
+    logits = torch.from_numpy(g[f"v{v}.pred_logits"]).to(device)
+    boxes = torch.from_numpy(g[f"v{v}.pred_boxes"]).to(device)
+    masks = torch.from_numpy(g[f"v{v}.pred_masks"]).to(device)
+    embeds = torch.from_numpy(g[f"v{v}.pred_inst_embed"]).to(device)
+    picks = model.select_candidates(logits, boxes)
+    per_frame = []
+    for f, c in enumerate(picks):
+        q = torch.from_numpy(c).to(device)
+        per_frame.append({"indices": c.tolist(), "logits": logits[f, q], "boxes": boxes[f, q], "embeds": embeds[f, q],
+                          "masks": masks[f, q]})
+    oh, ow, ih, iw = (int(x) for x in g[f"v{v}.sizes"])
+    tracker = trk.IDOL_Tracker(init_score_thr=0.2, obj_score_thr=0.1, nms_thr_pre=0.5, nms_thr_post=0.05,
+                               addnew_score_thr=0.2, memo_tracklet_frames=10, memo_momentum=0.8, long_match=True,
+                               frame_weight=True, temporal_weight=True, memory_len=3)
+    res = model.associate(per_frame, tracker, (oh, ow), (ih, iw))
+    np.testing.assert_array_equal(np.array(res["pred_labels"]), g[f"v{v}.labels"])
+    np.testing.assert_allclose(np.array(res["pred_scores"]), g[f"v{v}.scores"], rtol=1e-5)
+    present = g[f"v{v}.present"]
+    want = np.unpackbits(g[f"v{v}.masks"], axis=-1)[..., :ow].astype(bool)
+    assert len(res["pred_masks"]) == present.shape[0]
+    for i, track in enumerate(res["pred_masks"]):
+        assert [m is not None for m in track] == present[i].tolist()
+        for t, m in enumerate(track):
+            if m is not None:
+                assert float((m.numpy() != want[i, t]).mean()) < 2e-3, (i, t)
+
+
+@pytest.mark.parametrize("v", [0, 1])
+def test_video_postprocessing_equals_reference_cpu(v, cpu_stand_ins):
+    _associate_from_golden(dict(np.load(os.path.join(GOLDEN_DIR, "inference_idol.npz"))), v, "cpu")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("v", [0, 1])
+def test_video_postprocessing_equals_reference_on_gpu(v):
+    _associate_from_golden(dict(np.load(os.path.join(GOLDEN_DIR, "inference_idol.npz"))), v, "cuda:0")
+
+
+@pytest.mark.gpu
+def test_idol_train_step_and_inference_on_gpu():
+    cfg = get_idol_cfg(**{"MODEL.DEVICE": "cuda:0", "MODEL.IDOL.BATCH_INFER_LEN": 2, **TINY})
+    model = build_model(cfg).train()
+    opt = T.build_optimizer(model, base_lr=1e-4)
+    pairs = T.synthetic_clips(2, 2, 96, 160, "cuda:0", seed=3, num_instances=3)
+    before = model.detr.reid_embed_head.layers[0].weight.detach().clone()
+    l0 = T.train_step(model, opt, pairs)
+    l1 = T.train_step(model, opt, pairs)
+    assert torch.isfinite(l0) and torch.isfinite(l1)
+    assert not torch.equal(before, model.detr.reid_embed_head.layers[0].weight), "reid losses must reach the head"
+    model.eval()
+    res = model([{"image": pairs[0]["image"] + pairs[1]["image"], "height": 96, "width": 160}])
+    assert set(res) == {"image_size", "pred_scores", "pred_labels", "pred_masks"}
+    assert all(len(track) == 4 for track in res["pred_masks"])

@@ -18,13 +18,14 @@ ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--instances", type=int, default=4)
 ap.add_argument("--infer", action="store_true")
+ap.add_argument("--idol", action="store_true", help="IDOL-R50: key/reference pair training step and video inference")
+ap.add_argument("--size", default="360x640")
+ap.add_argument("--frames", type=int, default=36)
 ap.add_argument("--phases", action="store_true", help="time forward / backward / optimizer separately")
 a = ap.parse_args()
 dev = "cuda:0"
 torch.manual_seed(0)
-model = build_model(get_seqformer_cfg(**{"MODEL.DEVICE": dev})).train()
-opt = T.build_optimizer(model)
-clips = T.synthetic_clips(1, 5, 360, 640, dev, seed=100, num_instances=a.instances)
+H_, W_ = (int(v) for v in a.size.split("x"))
 
 
 def timed(fn, n):
@@ -34,6 +35,31 @@ def timed(fn, n):
         fn()
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) * 1e3 / n
+
+
+if a.idol:
+    from vnext_amd.registry import get_idol_cfg
+    model = build_model(get_idol_cfg(**{"MODEL.DEVICE": dev})).train()
+    opt = T.build_optimizer(model, base_lr=1e-4)
+    pairs = T.synthetic_clips(1, 2, H_, W_, dev, seed=100, num_instances=8)
+    for _ in range(a.warmup):
+        T.train_step(model, opt, pairs)
+    print(f"IDOL train step (1 key/ref pair {H_}x{W_}, 8 objects): {timed(lambda: T.train_step(model, opt, pairs), a.steps):.2f} ms/step")
+    if a.infer:
+        model.eval()
+        g = torch.Generator(device=dev).manual_seed(1)
+        video = [{"image": [torch.rand(3, H_, W_, device=dev, generator=g) * 255 for _ in range(a.frames)],
+                  "height": H_, "width": W_}]
+        model(video)
+        ms = timed(lambda: model(video), 3)
+        print(f"IDOL video inference: {ms:.1f} ms for {a.frames} frames = {a.frames / ms * 1e3:.1f} frames/s")
+        with torch.no_grad():
+            ms_net = timed(lambda: [model.inference_forward(video[0]["image"][s:s + 10]) for s in range(0, a.frames, 10)], 3)
+        print(f"  network + candidate selection + mask head: {ms_net:.1f} ms; tracker + post-processing: {ms - ms_net:.1f} ms")
+    sys.exit(0)
+model = build_model(get_seqformer_cfg(**{"MODEL.DEVICE": dev})).train()
+opt = T.build_optimizer(model)
+clips = T.synthetic_clips(1, 5, H_, W_, dev, seed=100, num_instances=a.instances)
 
 
 for _ in range(a.warmup):
