@@ -9,7 +9,7 @@ os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
 
 
 def short(name):
-    m = re.search(r"vnx::(\w+)(<[^(]*>)?", name)
+    m = re.search(r"vnx::((?:\w+::)*\w+)(<[^(]*>)?", name)
     if m:
         return "vnx::" + m.group(1) + (m.group(2) or "")
     return name[:60]

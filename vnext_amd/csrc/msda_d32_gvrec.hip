@@ -168,7 +168,8 @@ msda_bwd_gv_rec_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
 
   const int n_samples = d.Lq * P;
   const int qc_ = kThreads / P < kQcMax ? kThreads / P : kQcMax;
-  const int n_chunks = (d.Lq + qc_ - 1) / qc_;
+  int n_chunks = (d.Lq + qc_ - 1) / qc_;
+  if (debug == 2 || (debug == 3 && lvl == 0) || (debug == 4 && lvl <= 1)) n_chunks = 1;  // timing experiments only (wrong results)
   const uint4_t* my_recs = records + ((int64_t(b) * d.M + m) * d.L + lvl) * n_samples;
   const TV* go_head = grad_out + (int64_t(b) * d.Lq * d.M + m) * D;
   const int64_t q_stride = int64_t(d.M) * D;
@@ -347,9 +348,9 @@ int msda_backward_gvrec_d32(int vdt, const int64_t* shapes, const int64_t* lsi, 
   if (variant >= 200 && variant < 300) units_min = variant - 200;
   if (units_min < 1) units_min = 1;
   if (units_min > 16) units_min = 16;
-  if (vdt == VNX_F32) return launch_gvrec<float>(shapes, lsi, records, grad_out, grad_value, d, units_min, variant == 408 ? 1 : 0, stream);
-  if (vdt == VNX_BF16) return launch_gvrec<bf16_t>(shapes, lsi, records, grad_out, grad_value, d, units_min, variant == 408 ? 1 : 0, stream);
-  if (vdt == VNX_F16) return launch_gvrec<f16_t>(shapes, lsi, records, grad_out, grad_value, d, units_min, variant == 408 ? 1 : 0, stream);
+  if (vdt == VNX_F32) return launch_gvrec<float>(shapes, lsi, records, grad_out, grad_value, d, units_min, (variant >= 408 && variant <= 411 ? variant - 407 : 0), stream);
+  if (vdt == VNX_BF16) return launch_gvrec<bf16_t>(shapes, lsi, records, grad_out, grad_value, d, units_min, (variant >= 408 && variant <= 411 ? variant - 407 : 0), stream);
+  if (vdt == VNX_F16) return launch_gvrec<f16_t>(shapes, lsi, records, grad_out, grad_value, d, units_min, (variant >= 408 && variant <= 411 ? variant - 407 : 0), stream);
   set_error("msda_backward_gvrec_d32: unsupported dtype %d", vdt);
   return VNX_ERR_INVALID_ARGUMENT;
 }
