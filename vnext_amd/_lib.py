@@ -45,14 +45,15 @@ class VnextHipError(RuntimeError):
 def lib() -> ctypes.CDLL:
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        path = os.environ.get("VNX_HIP_LIB") or LIB_PATH    # override: experiment builds (tools/wpe_sweep.py)
+        if not os.path.exists(path):
             raise VnextHipError(
-                f"{LIB_PATH} is missing: the HIP library is the only implementation of this "
+                f"{path} is missing: the HIP library is the only implementation of this "
                 "path (no CPU fallback). Build it with `python -m vnext_amd.build`.")
         # torch ships its own libamdhip64.so.7; import it first so this library binds to
         # the HIP runtime torch's allocator and streams live in.
         import torch  # noqa: F401
-        cdll = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+        cdll = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(cdll, name)
             fn.restype = res

@@ -37,18 +37,21 @@ def _stale() -> bool:
     return any(os.path.getmtime(p) > t for p in deps)
 
 
-def build_hip(force: bool = False, verbose: bool = False) -> str:
-    if not force and not _stale():
+def build_hip(force: bool = False, verbose: bool = False, out: str | None = None, defines=()) -> str:
+    """`out` / `defines` build an experiment copy (e.g. -DVNX_FWD_WPE=4) beside the product library;
+    `VNX_HIP_LIB=<path>` makes vnext_amd._lib load it (development aid, tools/wpe_sweep.py)."""
+    target = out or LIB_PATH
+    if out is None and not force and not _stale():
         return LIB_PATH
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    os.makedirs(LIB_DIR, exist_ok=True)
-    tmp = LIB_PATH + ".tmp"
-    cmd = [hipcc] + HIPCC_FLAGS + ["-o", tmp] + sources()
+    os.makedirs(os.path.dirname(target), exist_ok=True)
+    tmp = target + ".tmp"
+    cmd = [hipcc] + HIPCC_FLAGS + [f"-D{d}" for d in defines] + ["-o", tmp] + sources()
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
-    os.replace(tmp, LIB_PATH)
-    return LIB_PATH
+    os.replace(tmp, target)
+    return target
 
 
 if __name__ == "__main__":

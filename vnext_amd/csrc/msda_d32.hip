@@ -109,8 +109,26 @@ __device__ __forceinline__ void store_row4<f16_t>(f16_t* p, float4_t v) {
 // forward
 // -----------------------------------------------------------------------------
 // LP = levels*points (template value 0 = use the runtime value, no unrolling).
+// VNX_FWD_WPE / VNX_K1_WPE: amdgpu_waves_per_eu hint (second __launch_bounds__ argument); the
+// register-allocation and scheduling heuristics follow it, and the measured best is built in.
+#ifndef VNX_FWD_WPE
+#define VNX_FWD_WPE 0
+#endif
+#ifndef VNX_K1_WPE
+#define VNX_K1_WPE 0
+#endif
+#if VNX_FWD_WPE > 0
+#define VNX_FWD_BOUNDS(n) __launch_bounds__(n, VNX_FWD_WPE)
+#else
+#define VNX_FWD_BOUNDS(n) __launch_bounds__(n)
+#endif
+#if VNX_K1_WPE > 0
+#define VNX_K1_BOUNDS(n) __launch_bounds__(n, VNX_K1_WPE)
+#else
+#define VNX_K1_BOUNDS(n) __launch_bounds__(n)
+#endif
 template <typename TV, typename TL, int QPW, int WPB, int LP_T>
-__global__ void __launch_bounds__(64 * WPB)
+__global__ void VNX_FWD_BOUNDS(64 * WPB)
 msda_fwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ shapes,
                     const int64_t* __restrict__ lsi, const TL* __restrict__ loc,
                     const TL* __restrict__ attn, TV* __restrict__ out, MsdaDims d,
@@ -409,7 +427,7 @@ __device__ __forceinline__ void store_loc(TL* p, float v) { *p = from_acc<TL>(v)
 // grad_value accumulates in fp32 (`gv`: grad_value itself for fp32, the workspace
 // image for 16-bit values), laid out [B,S,M,32] fp32.
 template <typename TV, typename TL, int QPW, int WPB, int LP_T, bool ATOMICS>
-__global__ void __launch_bounds__(64 * WPB)
+__global__ void VNX_K1_BOUNDS(64 * WPB)
 msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ shapes,
                     const int64_t* __restrict__ lsi, const TL* __restrict__ loc,
                     const TL* __restrict__ attn, const TV* __restrict__ grad_out,
