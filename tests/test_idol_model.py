@@ -145,3 +145,26 @@ def test_idol_train_step_and_inference_on_gpu():
     res = model([{"image": pairs[0]["image"] + pairs[1]["image"], "height": 96, "width": 160}])
     assert set(res) == {"image_size", "pred_scores", "pred_labels", "pred_masks"}
     assert all(len(track) == 4 for track in res["pred_masks"])
+
+
+def test_config_c1_single_480x640_frame_on_cpu_with_the_oracle_op(monkeypatch):
+    """one 480x640 frame, random-init R50 + the 4-level, 6-layer encoder on CPU
+    with the op served by the C oracle -> memory [1, 6380, 256] (level shapes 60x80, 30x40, 15x20, 8x10)."""
+    from oracle import msda_oracle as O
+    from vnext_amd.ops.functions import ms_deform_attn_func as func_mod
+
+    class OracleOp:
+        @staticmethod
+        def ms_deform_attn_forward(value, shapes, lsi, loc, attn, im2col_step):
+            return torch.from_numpy(O.msda_forward(value.numpy(), shapes.numpy(), lsi.numpy(), loc.numpy(),
+                                                   attn.numpy())).to(value.dtype)
+    monkeypatch.setattr(func_mod, "MSDA", OracleOp)
+    torch.manual_seed(0)
+    model = build_model(get_idol_cfg(**{"MODEL.DEVICE": "cpu", "MODEL.IDOL.DEC_LAYERS": 1,
+                                        "MODEL.IDOL.NUM_OBJECT_QUERIES": 20, "MODEL.IDOL.DROPOUT": 0.0})).eval()
+    with torch.no_grad():
+        x, mask = model._preprocess([torch.rand(3, 480, 640) * 255])
+        srcs, hs, memory, refs, inter_refs = model._encode_decode(x, mask)
+    assert [tuple(s.shape[-2:]) for s in srcs] == [(60, 80), (30, 40), (15, 20), (8, 10)]
+    assert tuple(memory.shape) == (1, 6380, 256) and tuple(hs.shape) == (1, 1, 20, 256)
+    assert torch.isfinite(memory).all() and torch.isfinite(hs).all()

@@ -159,3 +159,19 @@ def test_train_step_and_inference_on_gpu():
     assert set(res) == {"image_size", "pred_scores", "pred_labels", "pred_masks"}   # seqformer.py:403-408
     assert len(res["pred_masks"]) == len(res["pred_scores"]) == len(res["pred_labels"]) >= 10
     assert tuple(res["pred_masks"][0].shape) == (2, 96, 160) and res["pred_masks"][0].dtype == torch.bool
+
+
+@pytest.mark.gpu
+def test_train_step_under_bf16_autocast_on_gpu():
+    """bf16 I/O: GEMMs and the op's `value` / output in bf16, locations and
+    attention weights fp32 (softmax autocasts up) -- the mixed signature the C ABI accepts."""
+    cfg = get_seqformer_cfg(**{"MODEL.DEVICE": "cuda:0", **TINY})
+    model = build_model(cfg).train()
+    clips = T.synthetic_clips(1, 2, 96, 160, "cuda:0", seed=4)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        losses = model(clips)
+    total = sum(losses.values())
+    assert torch.isfinite(total)
+    total.backward()
+    g = model.detr.detr.transformer.encoder.layers[0].self_attn.value_proj.weight.grad
+    assert g is not None and torch.isfinite(g).all() and float(g.abs().sum()) > 0

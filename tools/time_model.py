@@ -21,10 +21,13 @@ ap.add_argument("--infer", action="store_true")
 ap.add_argument("--idol", action="store_true", help="IDOL-R50: key/reference pair training step and video inference")
 ap.add_argument("--size", default="360x640")
 ap.add_argument("--frames", type=int, default=36)
+ap.add_argument("--bf16", action="store_true", help="run the model under torch.autocast(bfloat16)")
 ap.add_argument("--phases", action="store_true", help="time forward / backward / optimizer separately")
 a = ap.parse_args()
 dev = "cuda:0"
 torch.manual_seed(0)
+if a.bf16:
+    torch.autocast("cuda", dtype=torch.bfloat16).__enter__()   # for the whole script
 H_, W_ = (int(v) for v in a.size.split("x"))
 
 
