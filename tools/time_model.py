@@ -21,6 +21,7 @@ ap.add_argument("--infer", action="store_true")
 ap.add_argument("--idol", action="store_true", help="IDOL-R50: key/reference pair training step and video inference")
 ap.add_argument("--size", default="360x640")
 ap.add_argument("--frames", type=int, default=36)
+ap.add_argument("--graph", action="store_true", help="SeqFormer: capture the training trunk (forward + backward hipGraphs)")
 ap.add_argument("--bf16", action="store_true", help="run the model under torch.autocast(bfloat16)")
 ap.add_argument("--phases", action="store_true", help="time forward / backward / optimizer separately")
 a = ap.parse_args()
@@ -61,6 +62,7 @@ if a.idol:
         print(f"  network + candidate selection + mask head: {ms_net:.1f} ms; tracker + post-processing: {ms - ms_net:.1f} ms")
     sys.exit(0)
 model = build_model(get_seqformer_cfg(**{"MODEL.DEVICE": dev})).train()
+model.graph_training = a.graph
 opt = T.build_optimizer(model)
 clips = T.synthetic_clips(1, 5, H_, W_, dev, seed=100, num_instances=a.instances)
 
@@ -83,4 +85,8 @@ if a.infer:
     model.eval()
     for _ in range(2):
         model(clips[:1])
-    print(f"inference: {timed(lambda: model(clips[:1]), a.steps):.2f} ms/clip (5 frames)")
+    print(f"inference, trunk replayed from a hipGraph: {timed(lambda: model(clips[:1]), a.steps):.2f} ms/clip (5 frames)")
+    model.graph_inference = False
+    for _ in range(2):
+        model(clips[:1])
+    print(f"inference, eager: {timed(lambda: model(clips[:1]), a.steps):.2f} ms/clip")

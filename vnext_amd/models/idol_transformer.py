@@ -18,7 +18,7 @@ import torch
 from torch import nn
 from torch.nn.init import constant_, normal_, xavier_uniform_
 
-from ..ops.functions import mark_levels_packed
+from ..ops.functions import level_tensors
 from ..ops.modules import MSDeformAttnIDOL
 from .seqformer_transformer import DeformableTransformerEncoder as _ClipEncoder
 from .seqformer_transformer import _get_activation_fn, _get_clones, inverse_sigmoid
@@ -183,9 +183,7 @@ class DeformableTransformer(nn.Module):
             mask_flatten.append(mask.flatten(1))
             pos_flatten.append(pos.flatten(2).transpose(1, 2) + self.level_embed[lvl].view(1, 1, -1))
         src_flatten, mask_flatten, pos_flatten = torch.cat(src_flatten, 1), torch.cat(mask_flatten, 1), torch.cat(pos_flatten, 1)
-        spatial_shapes = torch.as_tensor(shapes, dtype=torch.long, device=src_flatten.device)
-        level_start_index = mark_levels_packed(
-            torch.cat((spatial_shapes.new_zeros((1,)), spatial_shapes.prod(1).cumsum(0)[:-1])))
+        spatial_shapes, level_start_index = level_tensors(shapes, src_flatten.device)
         valid_ratios = torch.stack([self.get_valid_ratio(m) for m in masks], 1)
         memory = self.encoder(src_flatten, spatial_shapes, level_start_index, valid_ratios, pos_flatten,
                               mask_flatten, spatial_shapes_list=shapes)

@@ -171,6 +171,33 @@ class CondInstSegm(nn.Module):
         self.mask_head = MaskHeadSmallConv(hidden)
 
 
+class _TrainTrunk(nn.Module):
+    """The shape-static, sync-free part of a training step -- normalise + pad, backbone, input
+    projections, 6+6 transformer layers, class / box heads, mask-feature convs -- as one module, so
+    that `torch.cuda.make_graphed_callables` can capture its forward AND its backward into two
+    hipGraphs.  Shares the owner's parameters; not registered on the owner."""
+
+    def __init__(self, owner):
+        super().__init__()
+        self.detr = owner.detr
+        object.__setattr__(self, "_owner", owner)
+
+    def forward(self, stack):
+        o = self._owner
+        h, w = stack.shape[-2:]
+        H, W = (h + 31) // 32 * 32, (w + 31) // 32 * 32
+        x = stack.new_zeros(stack.shape[0], 3, H, W)
+        x[:, :, :h, :w] = (stack - o.pixel_mean) / o.pixel_std
+        mask = torch.ones(stack.shape[0], H, W, dtype=torch.bool, device=stack.device)
+        mask[:, :h, :w] = False
+        srcs, masks, poss = o._features(x, mask)
+        d = self.detr.detr
+        hs, hs_box, memory, init_ref, inter_refs, _, _, _ = d.transformer(srcs, masks, poss, d.query_embed.weight)
+        logits, boxes = o._heads(hs, hs_box, init_ref, inter_refs)
+        return (hs, logits, boxes, inverse_sigmoid(init_ref), inverse_sigmoid(inter_refs),
+                o._mask_features(srcs, memory))
+
+
 @META_ARCH_REGISTRY.register()
 class SeqFormer(nn.Module):
     def __init__(self, cfg):
@@ -200,6 +227,10 @@ class SeqFormer(nn.Module):
                                       num_frames=self.num_frames)
         self.deep_supervision = m.DEEP_SUPERVISION
         self.multi_cls, self.cls_thres = m.MULTI_CLS_ON, m.APPLY_CLS_THRES
+        self.graph_inference = True     # replay the inference trunk from a hipGraph (per clip shape)
+        self.graph_training = False     # capture the training trunk's forward and backward (opt-in)
+        self._graphs = {}
+        self._train_trunks = {}
         self.register_buffer("pixel_mean", torch.tensor(cfg.MODEL.PIXEL_MEAN).view(3, 1, 1), persistent=False)
         self.register_buffer("pixel_std", torch.tensor(cfg.MODEL.PIXEL_STD).view(3, 1, 1), persistent=False)
         self.to(self.device)
@@ -306,13 +337,32 @@ class SeqFormer(nn.Module):
             start += h * w
         return self.detr.mask_head(mem).float().contiguous()
 
+    def _graphed_train_trunk(self, stack):
+        """Forward + backward hipGraphs of the training trunk for this clip batch shape, captured
+        on first use (3 eager warm-up iterations on a side stream, then capture -- what
+        make_graphed_callables does)."""
+        key = tuple(stack.shape)
+        fn = self._train_trunks.get(key)
+        if fn is None:
+            if len(self._train_trunks) >= 2:
+                self._train_trunks.pop(next(iter(self._train_trunks)))
+            fn = self._train_trunks[key] = torch.cuda.make_graphed_callables(
+                _TrainTrunk(self).train(), (stack.clone(),), allow_unused_input=True)
+        return fn(stack)
+
     def losses(self, batched_inputs):
         """CondInst_segm.forward (segmentation_condInst.py:69-207) + SetCriterion."""
         targets = self.prepare_targets(batched_inputs)
-        x, srcs, hs, memory, logits, boxes, refs = self._run(batched_inputs, want_refs=True)
+        frames = [f for clip in batched_inputs for f in clip["image"]]
+        if self.graph_training and frames[0].is_cuda and all(f.shape == frames[0].shape for f in frames):
+            hs, logits, boxes, ref0, ref_rest, feats = self._graphed_train_trunk(
+                torch.stack([f.to(self.device, torch.float32) for f in frames]))
+            refs = [ref0] + list(ref_rest[:hs.shape[0] - 1])
+        else:
+            x, srcs, hs, memory, logits, boxes, refs = self._run(batched_inputs, want_refs=True)
+            feats = self._mask_features(srcs, memory)
         Ld, N, T = boxes.shape[:3]
         indices_list = self.criterion.matcher.match_all_layers(logits, boxes, targets)
-        feats = self._mask_features(srcs, memory)
         # the matched instances of every decoder layer, on every frame of their clip, in one launch
         params, points, image = [], [], []
         frame = torch.arange(T, device=self.device)
@@ -349,6 +399,51 @@ class SeqFormer(nn.Module):
             return self.losses(batched_inputs)
         return self.inference(batched_inputs)
 
+    # ---- inference --------------------------------------------------------------------------
+    def _clip_trunk(self, stack):
+        """[T, 3, h, w] raw frames of ONE clip -> what `inference` needs from the network: class
+        logits and (pre-sigmoid) reference of the last decoder layer, its query states and the
+        stride-8 mask features.  Shape-static and free of host synchronisation, so it can be
+        captured into a hipGraph; boxes of the other layers are not computed (whole-video
+        inference never reads them, seqformer.py:351-410)."""
+        h, w = stack.shape[-2:]
+        H, W = (h + 31) // 32 * 32, (w + 31) // 32 * 32
+        x = stack.new_zeros(stack.shape[0], 3, H, W)
+        x[:, :, :h, :w] = (stack - self.pixel_mean) / self.pixel_std
+        mask = torch.ones(stack.shape[0], H, W, dtype=torch.bool, device=stack.device)
+        mask[:, :h, :w] = False
+        srcs, masks, poss = self._features(x, mask)
+        d = self.detr.detr
+        hs, _, memory, init_ref, inter_refs, _, _, _ = d.transformer(srcs, masks, poss, d.query_embed.weight)
+        last = hs.shape[0] - 1
+        ref = inverse_sigmoid(init_ref if last == 0 else inter_refs[last - 1])
+        return d.class_embed[last](hs[last]), ref, hs[last], self._mask_features(srcs, memory)
+
+    def _clip_trunk_graphed(self, stack):
+        """`_clip_trunk` replayed from a hipGraph captured per (T, h, w): the ~1 500 launches of
+        backbone + 6+6 transformer layers + mask-feature convs become one graph launch
+        (SURVEY section 8(f) rank 2).  Outputs live in the graph's static buffers until the next call."""
+        key = tuple(stack.shape)
+        entry = self._graphs.get(key)
+        if entry is None:
+            static_in = stack.clone()
+            side = torch.cuda.Stream(device=stack.device)
+            side.wait_stream(torch.cuda.current_stream(stack.device))
+            with torch.cuda.stream(side):           # warm-up outside capture: lazy inits, cached level tensors
+                for _ in range(2):
+                    self._clip_trunk(static_in)
+            torch.cuda.current_stream(stack.device).wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_out = self._clip_trunk(static_in)
+            if len(self._graphs) >= 4:              # a few resolutions at most; drop the oldest
+                self._graphs.pop(next(iter(self._graphs)))
+            entry = self._graphs[key] = (graph, static_in, static_out)
+        graph, static_in, static_out = entry
+        static_in.copy_(stack)
+        graph.replay()
+        return static_out
+
     @torch.no_grad()
     def inference(self, batched_inputs):
         """Whole clip at once (seqformer.py:231-238, 351-410; CondInst_segm.inference,
@@ -357,20 +452,28 @@ class SeqFormer(nn.Module):
         runs the mask head for all 300 queries of all 6 decoder layers and keeps 10 of the last."""
         assert len(batched_inputs) == 1
         clip = batched_inputs[0]
-        x, srcs, hs, memory, logits, boxes, refs = self._run(batched_inputs, want_refs=True)
+        frames = [f.to(self.device, torch.float32) for f in clip["image"]]
+        same = all(f.shape == frames[0].shape for f in frames)
+        if same:
+            stack = torch.stack(frames)
+            trunk = self._clip_trunk_graphed if (self.graph_inference and stack.is_cuda) else self._clip_trunk
+            logits, ref_last, hs_last, feats = trunk(stack)
+            H, W = feats.shape[-2] * 8, feats.shape[-1] * 8
+        else:   # frames of different sizes: the general (eager, padded-batch) path
+            x, srcs, hs, memory, logits_all, _, refs = self._run(batched_inputs, want_refs=True)
+            logits, ref_last, hs_last, feats = logits_all[-1], refs[-1], hs[-1], self._mask_features(srcs, memory)
+            H, W = x.shape[-2:]
         T = self.num_frames
         ih, iw = clip["image"][0].shape[-2:]                                  # size fed to the network
-        prob = logits[-1][0].sigmoid()                                        # [Q, classes]
+        prob = logits[0].sigmoid()                                            # [Q, classes]
         query = prob.max(1)[0].topk(min(10, prob.shape[0]))[1]
         prob = prob[query]
-        params = self.detr.controller(hs[-1][0, query])                      # [10, 169]
-        feats = self._mask_features(srcs, memory)                             # [T, 8, H/8, W/8]
+        params = self.detr.controller(hs_last[0, query])                     # [10, 169]
         scale = torch.tensor([iw, ih], device=self.device, dtype=torch.float32)
-        ref = refs[-1][0][:, query, :2].sigmoid() * scale                     # [T, 10, 2] image pixels
+        ref = ref_last[0][:, query, :2].sigmoid() * scale                     # [T, 10, 2] image pixels
         n = len(query)
         logits_m = dynamic_mask_with_coords(feats, ref.reshape(1, T * n, 2).float(),
                                             params.float().repeat(T, 1)[None], [n] * T, 8)
-        H, W = x.shape[-2:]
         masks = logits_m.view(T, n, H // 4, W // 4).transpose(0, 1)          # [10, T, H/4, W/4]
         masks = F.interpolate(masks, size=(H, W), mode="bilinear", align_corners=False).sigmoid()
         if self.multi_cls:

@@ -19,7 +19,7 @@ import torch.nn.functional as F
 from torch import nn
 from torch.nn.init import constant_, normal_, xavier_uniform_
 
-from ..ops.functions import mark_levels_packed
+from ..ops.functions import level_tensors
 from ..ops.modules import MSDeformAttnSeqFormer
 
 
@@ -275,10 +275,9 @@ class DeformableTransformer(nn.Module):
         mask_flatten = torch.cat(mask_flatten, 2)
         lvl_pos_embed_flatten = torch.cat(lvl_pos_embed_flatten, 2)
         shapes_list = spatial_shapes
-        spatial_shapes = torch.as_tensor(spatial_shapes, dtype=torch.long, device=src_flatten.device)
-        # packed by construction: tell the op so its backward skips the general-path launches
-        level_start_index = mark_levels_packed(
-            torch.cat((spatial_shapes.new_zeros((1,)), spatial_shapes.prod(1).cumsum(0)[:-1])))
+        # cached device tensors, tagged as packed (the op's backward then skips the general-path
+        # launches) and with their host-side sizes (no device read for the length checks)
+        spatial_shapes, level_start_index = level_tensors(shapes_list, src_flatten.device)
         valid_ratios = torch.stack([self.get_valid_ratio(m[:, 0]) for m in masks], 1)
 
         memory = self.encoder(src_flatten, spatial_shapes, level_start_index, valid_ratios, lvl_pos_embed_flatten,

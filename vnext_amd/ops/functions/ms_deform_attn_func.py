@@ -57,3 +57,35 @@ def ms_deform_attn(value, value_spatial_shapes, value_level_start_index, samplin
     """Functional spelling of MSDeformAttnFunction.apply."""
     return MSDeformAttnFunction.apply(value, value_spatial_shapes, value_level_start_index,
                                       sampling_locations, attention_weights, im2col_step)
+
+
+_LEVEL_TENSORS = {}
+
+
+def level_tensors(shapes, device):
+    """(spatial_shapes [L,2] int64, level_start_index [L] int64) on `device` for a tuple of
+    (H, W) pairs, built once per (shapes, device) and reused: no host->device copy and no
+    allocation on later calls (which also keeps callers hipGraph-capturable).  The tensors carry
+    their host-side meaning -- `_vnx_hw` (the pairs) and `_vnx_levels_packed` -- so that callers
+    can check lengths without reading the device."""
+    key = (tuple((int(h), int(w)) for h, w in shapes), str(device))
+    hit = _LEVEL_TENSORS.get(key)
+    if hit is None:
+        if len(_LEVEL_TENSORS) > 256:
+            _LEVEL_TENSORS.clear()
+        sizes = torch.as_tensor(key[0], dtype=torch.long, device=device)
+        starts = torch.cat((sizes.new_zeros((1,)), sizes.prod(1).cumsum(0)[:-1]))
+        sizes._vnx_hw = key[0]
+        hit = _LEVEL_TENSORS[key] = (sizes, mark_levels_packed(starts))
+    return hit
+
+
+def check_flattened_length(spatial_shapes, length):
+    """The reference's `assert (shapes[:,0] * shapes[:,1]).sum() == Len_in`
+    (ops/modules/ms_deform_attn.py:91): on the host when the tensor came from `level_tensors`,
+    else on the device like the reference (a synchronisation per call)."""
+    hw = getattr(spatial_shapes, "_vnx_hw", None)
+    if hw is not None:
+        assert sum(h * w for h, w in hw) == length
+    else:
+        assert (spatial_shapes[:, 0] * spatial_shapes[:, 1]).sum() == length

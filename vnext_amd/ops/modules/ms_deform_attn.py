@@ -26,7 +26,7 @@ import torch.nn.functional as F
 from torch import nn
 from torch.nn.init import constant_, xavier_uniform_
 
-from ..functions import MSDeformAttnFunction
+from ..functions import MSDeformAttnFunction, check_flattened_length
 
 
 def _is_power_of_2(n):
@@ -109,7 +109,7 @@ class MSDeformAttnIDOL(_MSDeformAttnBase):
                 input_level_start_index, input_padding_mask=None):
         N, Len_q, _ = query.shape
         N, Len_in, _ = input_flatten.shape
-        assert (input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum() == Len_in
+        check_flattened_length(input_spatial_shapes, Len_in)
         value = self._project_value(input_flatten, input_padding_mask)
         value = value.view(N, Len_in, self.n_heads, self.d_model // self.n_heads)
         sampling_offsets, attention_weights = self._offsets_and_weights(query)
@@ -153,7 +153,7 @@ class MSDeformAttnSeqFormer(_MSDeformAttnBase):
                        input_level_start_index, input_padding_mask=None):
         N, nf, Len_q, _ = query.shape
         N, nf, Len_in, _ = input_flatten.shape
-        assert (input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum() == Len_in
+        check_flattened_length(input_spatial_shapes, Len_in)
         value = self._project_value(input_flatten, input_padding_mask)
         value = value.view(N, nf, Len_in, self.n_heads, self.d_model // self.n_heads)
         sampling_offsets, attention_weights = self._offsets_and_weights(query)  # [N,nf,Lq,M,L,P(,2)]
@@ -169,7 +169,7 @@ class MSDeformAttnSeqFormer(_MSDeformAttnBase):
     def decode_forward(self, query, query_box, reference_points, input_flatten, input_spatial_shapes,
                        input_level_start_index, input_padding_mask=None):
         N, nf, Len_in, _ = input_flatten.shape
-        assert (input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum() == Len_in
+        check_flattened_length(input_spatial_shapes, Len_in)
         value = self._project_value(input_flatten, input_padding_mask)
         value = value.view(N, nf, Len_in, self.n_heads, self.d_model // self.n_heads)
         sampling_offsets, attention_weights = self._offsets_and_weights(query_box)
