@@ -181,6 +181,55 @@ def model_step_leg(rank, local_rank, world, device, steps, warmup=3):
                       "SetCriterion on 4 synthetic tracks per clip (matcher + focal/L1/GIoU/mask losses, deep supervision); DDP static_graph + gradient_as_bucket_view over RCCL"}
 
 
+def extra_model_legs(device):
+    """Single-GPU legs for the other SURVEY section 8d configs (rank 0, N=1 only; a few seconds each):
+    C2 SeqFormer-R50 whole-clip inference, C3-like IDOL-R50 key/reference training step, C5 IDOL-R50
+    video inference with the tracker.  Random-init weights, synthetic frames / annotations, fp32."""
+    import vnext_amd.models  # noqa: F401
+    from vnext_amd import train as T
+    from vnext_amd.registry import build_model, get_idol_cfg, get_seqformer_cfg
+
+    def timed(fn, n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) * 1e3 / n
+    out = {}
+    torch.manual_seed(0)
+    model = build_model(get_seqformer_cfg(**{"MODEL.DEVICE": str(device)})).eval()
+    clip = T.synthetic_clips(1, 5, 360, 640, device, seed=7, num_instances=0)
+    for _ in range(2):
+        model(clip)
+    ms = timed(lambda: model(clip), 10)
+    out["seqformer_inference"] = {"ms_per_clip": ms, "clips_per_s": 1e3 / ms, "frames_per_s": 5e3 / ms,
+                                  "config": "SeqFormer R50, T=5, 360x640, 300 queries, trunk replayed from a hipGraph, "
+                                            "top-10 masks at input resolution"}
+    del model
+    model = build_model(get_idol_cfg(**{"MODEL.DEVICE": str(device)})).train()
+    opt = T.build_optimizer(model, base_lr=1e-4)
+    pair = T.synthetic_clips(1, 2, 360, 640, device, seed=8, num_instances=8)
+    for _ in range(3):
+        T.train_step(model, opt, pair)
+    ms = timed(lambda: T.train_step(model, opt, pair), 5)
+    out["idol_train_step"] = {"ms_per_step": ms, "pairs_per_s": 1e3 / ms,
+                              "config": "IDOL R50, one key/reference pair 360x640, 8 objects, simOTA + reid losses, AdamW"}
+    del opt
+    model.eval()
+    g = torch.Generator(device=device).manual_seed(1)
+    for name, (h, w) in (("360p", (360, 640)), ("720p", (720, 1280))):
+        video = [{"image": [torch.rand(3, h, w, device=device, generator=g) * 255 for _ in range(36)],
+                  "height": h, "width": w}]
+        model(video)
+        ms = timed(lambda: model(video), 3)
+        out[f"idol_video_inference_{name}"] = {"ms_per_video": ms, "frames_per_s": 36e3 / ms,
+                                               "config": f"IDOL R50, 36 frames {h}x{w} in chunks of 10, tracker on"}
+    del model
+    torch.cuda.empty_cache()
+    return out
+
+
 def latest_pmc_profile():
     """The newest committed PMC summary (tools/summarize_prof.py), or None."""
     import glob
@@ -345,6 +394,8 @@ def main():
     if rank == 0:
         if model_leg is not None:
             line["model_step"] = model_leg
+            if world == 1:
+                line["other_configs"] = extra_model_legs(device)
         # ---- per-kernel rooflines, measured live with events on the launch stream -------
         inner = max(nsets, 24)
         g_fwd = capture([(lambda s=sets[i % nsets]: op.fwd(s, B, Lq)) for i in range(inner)])

@@ -142,9 +142,14 @@ def test_idol_train_step_and_inference_on_gpu():
     assert torch.isfinite(l0) and torch.isfinite(l1)
     assert not torch.equal(before, model.detr.reid_embed_head.layers[0].weight), "reid losses must reach the head"
     model.eval()
-    res = model([{"image": pairs[0]["image"] + pairs[1]["image"], "height": 96, "width": 160}])
+    video = [{"image": pairs[0]["image"] + pairs[1]["image"] + pairs[0]["image"][:1], "height": 96, "width": 160}]
+    res = model(video)                      # chunks of 2, 2 and 1 frames: two graphs captured, one replayed
     assert set(res) == {"image_size", "pred_scores", "pred_labels", "pred_masks"}
-    assert all(len(track) == 4 for track in res["pred_masks"])
+    assert all(len(track) == 5 for track in res["pred_masks"]) and len(model._graphs) == 2
+    model.graph_inference = False
+    eager = model(video)
+    assert res["pred_labels"] == eager["pred_labels"]
+    np.testing.assert_allclose(res["pred_scores"], eager["pred_scores"], rtol=1e-5)
 
 
 def test_config_c1_single_480x640_frame_on_cpu_with_the_oracle_op(monkeypatch):

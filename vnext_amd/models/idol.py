@@ -104,6 +104,8 @@ class IDOL(nn.Module):
                                        mask_out_stride=m.MASK_STRIDE, focal_alpha=m.FOCAL_ALPHA,
                                        num_frames=self.num_frames)
         self.deep_supervision = m.DEEP_SUPERVISION
+        self.graph_inference = True      # replay the per-chunk inference trunk from a hipGraph
+        self._graphs = {}
         self.register_buffer("pixel_mean", torch.tensor(cfg.MODEL.PIXEL_MEAN).view(3, 1, 1), persistent=False)
         self.register_buffer("pixel_std", torch.tensor(cfg.MODEL.PIXEL_STD).view(3, 1, 1), persistent=False)
         self.to(self.device)
@@ -245,26 +247,67 @@ class IDOL(nn.Module):
             picks.append(cand)
         return picks
 
+    def _chunk_trunk(self, x, mask):
+        """Padded frames -> (logits [F,Q,K], boxes [F,Q,4], query states, pre-sigmoid reference of the
+        last decoder layer, stride-8 mask features): the shape-static, sync-free part of inference."""
+        srcs, hs, memory, refs, _ = self._encode_decode(x, mask)
+        last = hs.shape[0] - 1
+        logits, boxes = self._box_heads(hs, refs, [last])
+        return logits[0], boxes[0], hs[last], refs[last], self._mask_features(srcs, memory)
+
+    def _chunk_trunk_graphed(self, stack):
+        """`_chunk_trunk` of same-sized frames replayed from a hipGraph captured per chunk shape
+        (a video is chunks of BATCH_INFER_LEN frames + one shorter tail: two graphs)."""
+        key = tuple(stack.shape)
+        entry = self._graphs.get(key)
+        if entry is None:
+            static_in = stack.clone()
+
+            def run():
+                h, w = static_in.shape[-2:]
+                H, W = (h + 31) // 32 * 32, (w + 31) // 32 * 32
+                x = static_in.new_zeros(static_in.shape[0], 3, H, W)
+                x[:, :, :h, :w] = (static_in - self.pixel_mean) / self.pixel_std
+                mask = torch.ones(static_in.shape[0], H, W, dtype=torch.bool, device=static_in.device)
+                mask[:, :h, :w] = False
+                return self._chunk_trunk(x, mask)
+            side = torch.cuda.Stream(device=stack.device)
+            side.wait_stream(torch.cuda.current_stream(stack.device))
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    run()
+            torch.cuda.current_stream(stack.device).wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_out = run()
+            if len(self._graphs) >= 4:
+                self._graphs.pop(next(iter(self._graphs)))
+            entry = self._graphs[key] = (graph, static_in, static_out)
+        graph, static_in, static_out = entry
+        static_in.copy_(stack)
+        graph.replay()
+        return static_out
+
     @torch.no_grad()
     def inference_forward(self, frames):
         """One chunk of frames -> per-frame candidates (inference_forward :234-321 + the selection of
         idol.py:331-349): list over frames of dicts {indices, logits [n,K], boxes [n,4], embeds
         [n,C], masks [n,1,H/4,W/4]} for the queries that survive the score threshold and the
         class-aware box NMS (0.9)."""
-        x, mask = self._preprocess(frames)
-        srcs, hs, memory, refs, inter_refs = self._encode_decode(x, mask)
-        last = hs.shape[0] - 1
-        logits, boxes = self._box_heads(hs, refs, [last])
-        logits, boxes = logits[0], boxes[0]
+        frames = [f.to(self.device, torch.float32) for f in frames]
+        if self.graph_inference and frames[0].is_cuda and all(f.shape == frames[0].shape for f in frames):
+            logits, boxes, hs_last, ref_last, feats = self._chunk_trunk_graphed(torch.stack(frames))
+        else:
+            logits, boxes, hs_last, ref_last, feats = self._chunk_trunk(*self._preprocess(frames))
         picks = self.select_candidates(logits, boxes)
         frame_of = torch.from_numpy(np.concatenate([np.full(len(c), f) for f, c in enumerate(picks)])).to(self.device)
         query = torch.from_numpy(np.concatenate(picks)).to(self.device)
-        sel_hs = hs[last, frame_of, query]
+        sel_hs = hs_last[frame_of, query]
         ih, iw = frames[0].shape[-2:]
         scale = torch.tensor([iw, ih], device=self.device, dtype=torch.float32)
-        points = refs[last][frame_of, query, :2].sigmoid() * scale            # = inter_references[-2][..., :2]
-        masks = dynamic_mask_head(self._mask_features(srcs, memory), points.float(),
-                                  self.detr.controller(sel_hs).float(), frame_of.to(torch.int32), 8)
+        points = ref_last[frame_of, query, :2].sigmoid() * scale              # = inter_references[-2][..., :2]
+        masks = dynamic_mask_head(feats, points.float(), self.detr.controller(sel_hs).float(),
+                                  frame_of.to(torch.int32), 8)
         embeds = self.detr.reid_embed_head(sel_hs)
         out, start = [], 0
         for f, c in enumerate(picks):
