@@ -318,6 +318,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-model", action="store_true", help="skip the model-level DDP step (clips/s) leg")
     ap.add_argument("--model-steps", type=int, default=10)
+    ap.add_argument("--no-warm", action="store_true",
+                    help="skip the cache-warm forward leg (profiling runs: keeps rocprofv3's per-kernel average cold-only)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -396,27 +398,95 @@ def main():
             line["model_step"] = model_leg
             if world == 1:
                 line["other_configs"] = extra_model_legs(device)
-        # ---- per-kernel rooflines, measured live with events on the launch stream -------
+        # ---- per-kernel rooflines, measured live --------------------------------------------
+        # (a) HIP events around a hipGraph of back-to-back launches: includes the ~2-3 us
+        #     dependent-kernel gap, so it over-states a 10 us kernel;
+        # (b) kernel-span stamps: every launch of a tuned kernel leaves {first wave start, last
+        #     wave end} in constant-rate wall-clock ticks (s_memrealtime) -- the kernel's own
+        #     duration on the device, what rocprofv3 --kernel-trace reports.  (b) feeds `achieved`.
+        import ctypes
         inner = max(nsets, 24)
+        L = op.lib
+        L.vnx_debug_arm_stamps.argtypes = [ctypes.c_void_p, ctypes.c_longlong]
+        L.vnx_debug_arm_stamps.restype = None
+        L.vnx_debug_stamp_regions.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_longlong),
+                                              ctypes.POINTER(ctypes.c_longlong), ctypes.c_int]
+        L.vnx_debug_stamp_regions.restype = ctypes.c_int
+        L.vnx_debug_wall_clock_khz.restype = ctypes.c_int
+        n_words = (4 * inner + 64) * 2 * 8192    # <= 8 Ki workgroups per stamped launch
+        stamps = torch.zeros(n_words, dtype=torch.int64, device=device)
+        L.vnx_debug_arm_stamps(stamps.data_ptr(), n_words)
         g_fwd = capture([(lambda s=sets[i % nsets]: op.fwd(s, B, Lq)) for i in range(inner)])
         g_bwd = capture([(lambda s=sets[i % nsets]: op.bwd(s, B, Lq)) for i in range(inner)])
-        g_fwd_warm = capture([(lambda: op.fwd(sets[0], B, Lq)) for _ in range(inner)])
+        # forward + grad_loc kernels (grad_value: see below); capture() also runs its functions
+        # eagerly first -- those launches take regions too, which stay zero in the measured replays
+        max_regions = 4 * inner + 64
+        kinds = (ctypes.c_int * max_regions)()
+        offs = (ctypes.c_longlong * max_regions)()
+        nblk = (ctypes.c_longlong * max_regions)()
+        n_regions = L.vnx_debug_stamp_regions(kinds, offs, nblk, max_regions)
+        L.vnx_debug_arm_stamps(None, 0)
         us_fwd = event_time_us(g_fwd, inner)
         us_bwd = event_time_us(g_bwd, inner)
-        us_fwd_warm = event_time_us(g_fwd_warm, inner)
+        us_fwd_warm = None
+        if not a.no_warm:
+            g_fwd_warm = capture([(lambda: op.fwd(sets[0], B, Lq)) for _ in range(inner)])
+            us_fwd_warm = event_time_us(g_fwd_warm, inner)
+        khz = L.vnx_debug_wall_clock_khz()
+        span = {1: [], 2: [], 3: []}
+        if khz > 0 and 0 < n_regions <= max_regions:
+            for _ in range(10):
+                stamps.zero_()
+                g_fwd.replay()
+                g_bwd.replay()
+                torch.cuda.synchronize()
+                for i in range(n_regions):
+                    t = stamps[offs[i]:offs[i] + 2 * nblk[i]].view(-1, 2)
+                    ran = t[:, 0] > 0                   # placeholder workgroups that returned at once still stamp
+                    if bool(ran.any()):
+                        span[kinds[i]].append(float(t[ran, 1].max() - t[ran, 0].min()) / khz * 1e3)
+        # the grad_value kernel takes no stamp-region argument (register budget, see
+        # msda_d32_gvrec.hip): its workgroups stamp a fixed device array when launched with
+        # variant 412 -- single launches, rotating inputs, read back after each
+        n_rec = 4096 * 16
+        host = (ctypes.c_ulonglong * n_rec)()
+        L.vnx_debug_read_rec_stamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
+        L.vnx_debug_read_rec_stamps.restype = ctypes.c_int
+        if khz > 0:
+            L.vnx_set_kernel_variant(412)
+            try:
+                for rep in range(24):
+                    op.bwd(sets[rep % nsets], B, Lq)
+                    torch.cuda.synchronize()
+                    if L.vnx_debug_read_rec_stamps(host, n_rec) != 0:
+                        break
+                    t = torch.frombuffer(host, dtype=torch.int64).view(4096, 16)
+                    ran = t[:, 12] > t[:, 0]
+                    if rep >= 4 and bool(ran.any()):
+                        span[3].append(float(t[ran, 12].max() - t[ran, 0].min()) / khz * 1e3)
+            finally:
+                L.vnx_set_kernel_variant(0)
+        k_us = {k: (sum(v) / len(v) if v else None) for k, v in span.items()}
+        print(f"[bench] stamp regions {n_regions}/{max_regions}, wall clock {khz} kHz, spans "
+              f"{ {k: len(v) for k, v in span.items()} }", file=sys.stderr)
 
-        def roof(nbytes, us, what):
+        def roof(nbytes, us_kernel, us_events, what):
+            us = us_kernel if us_kernel else us_events
             gbs = nbytes / us / 1e3
             return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": gbs / HBM_PEAK_GBS, "traffic": None, "kernel": what,
                     "algorithmic_bytes_per_launch": nbytes, "us_per_launch": us,
-                    "timing": "HIP events around a hipGraph of back-to-back launches over "
-                              "rotating inputs (cold); includes the inter-kernel gap"}
+                    "us_per_launch_events": us_events,
+                    "timing": ("kernel-span stamps (first wave start to last wave end, s_memrealtime), mean over "
+                               "launches on rotating inputs (cold)" if us_kernel else
+                               "HIP events around a hipGraph of back-to-back launches (cold); includes the gap")
+                              + "; us_per_launch_events = HIP events around the same graph, incl. the inter-kernel gap"}
 
-        line["roofline"] = roof(bytes_fwd, us_fwd, "msda_fwd_d32_kernel (ms_deform_attn_forward)")
-        line["roofline"]["warm_us_per_launch"] = us_fwd_warm
-        line["roofline"]["warm_frac"] = bytes_fwd / us_fwd_warm / 1e3 / HBM_PEAK_GBS
-        line["roofline_bwd"] = roof(bytes_bwd, us_bwd,
+        line["roofline"] = roof(bytes_fwd, k_us[1], us_fwd, "msda_fwd_d32_kernel (ms_deform_attn_forward)")
+        if us_fwd_warm:
+            line["roofline"]["warm_us_per_launch"] = us_fwd_warm
+            line["roofline"]["warm_frac"] = bytes_fwd / us_fwd_warm / 1e3 / HBM_PEAK_GBS   # events, incl. gaps
+        line["roofline_bwd"] = roof(bytes_bwd, (k_us[2] + k_us[3]) if (k_us[2] and k_us[3]) else None, us_bwd,
                                     "msda_bwd_d32_kernel (grad_loc, grad_attn, sample records) + "
                                     "msda_bwd_gv_rec_kernel (grad_value), one ms_deform_attn_backward call")
         # HBM bytes per launch cannot be counted from inside this process: they come from the
@@ -431,6 +501,7 @@ def main():
                 if vals and all(v is not None for v in vals):
                     line[key]["traffic"] = sum(vals)
                     line[key]["traffic_source"] = pmc["file"]
+        line["roofline_bwd"]["us_grad_loc_kernel"], line["roofline_bwd"]["us_grad_value_kernel"] = k_us[2], k_us[3]
         line["fwd_gpoints_per_s"] = points / us_fwd / 1e3
         if not a.no_cpu:
             line["cpu_baseline"] = cpu_baseline(B, Lq, res)

@@ -115,6 +115,25 @@ static int check_common(const char* fn, int vdt, int ldt, const void* value,
 
 using namespace vnx;
 
+// ---- kernel-span stamps (development / bench aid, not in the public header) ------------------
+static unsigned long long* g_stamp_buf = nullptr;
+static long long g_stamp_words = 0, g_stamp_used = 0;
+static int g_stamp_n = 0;
+static int g_stamp_kind[4096];
+static long long g_stamp_off[4096], g_stamp_blocks[4096];
+namespace vnx {
+unsigned long long* take_stamp_region(int kernel, long long blocks) {
+  if (!g_stamp_buf || g_stamp_n >= 4096 || g_stamp_used + 2 * blocks > g_stamp_words) return nullptr;
+  g_stamp_kind[g_stamp_n] = kernel;
+  g_stamp_off[g_stamp_n] = g_stamp_used;
+  g_stamp_blocks[g_stamp_n] = blocks;
+  ++g_stamp_n;
+  unsigned long long* p = g_stamp_buf + g_stamp_used;
+  g_stamp_used += 2 * blocks;
+  return p;
+}
+}  // namespace vnx
+
 extern "C" {
 
 int vnx_abi_version(void) { return VNX_ABI_VERSION; }
@@ -133,6 +152,31 @@ const char* vnx_status_string(int status) {
 const char* vnx_last_error(void) { return t_error; }
 
 void vnx_set_kernel_variant(int variant) { g_kernel_variant = variant; }
+
+// buf: device memory of n_words 64-bit words, ZERO-filled by the caller before every measured run
+// (slots of workgroups that never ran stay {0, 0} and are skipped); nullptr disarms
+void vnx_debug_arm_stamps(void* buf, long long n_words) {
+  g_stamp_buf = (unsigned long long*)buf;
+  g_stamp_words = n_words;
+  g_stamp_used = 0;
+  g_stamp_n = 0;
+}
+// -> number of regions handed out since arming; per region: kernel kind (1 forward, 2
+// grad_loc/attn, 3 grad_value), word offset into the buffer, number of workgroups
+int vnx_debug_stamp_regions(int* kinds, long long* offsets, long long* blocks, int n) {
+  for (int i = 0; i < n && i < g_stamp_n; ++i) {
+    kinds[i] = g_stamp_kind[i];
+    offsets[i] = g_stamp_off[i];
+    blocks[i] = g_stamp_blocks[i];
+  }
+  return g_stamp_n;
+}
+int vnx_debug_wall_clock_khz(void) {
+  int dev = 0, khz = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess) return 0;
+  return khz;
+}
 int vnx_get_kernel_variant(void) { return g_kernel_variant; }
 
 int vnx_msda_forward(int value_dtype, int loc_dtype, const void* value,

@@ -132,7 +132,8 @@ __global__ void VNX_FWD_BOUNDS(64 * WPB)
 msda_fwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ shapes,
                     const int64_t* __restrict__ lsi, const TL* __restrict__ loc,
                     const TL* __restrict__ attn, TV* __restrict__ out, MsdaDims d,
-                    int tiles_per_batch, int prefetch_rows) {
+                    int tiles_per_batch, int prefetch_rows, unsigned long long* stamps) {
+  stamp_begin(stamps);
   constexpr int D = 32;
   constexpr int PG = 8 / QPW;            // sample groups per query
   constexpr int kRowBytes = D * int(sizeof(TV));
@@ -282,6 +283,7 @@ msda_fwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
   }
   // keeps the phase-0 loads from being eliminated; the values never reach the output
   asm volatile("" ::"v"(pf_sink));
+  stamp_end(stamps);
 }
 
 struct FwdCfg { int qpw; int wpb; };
@@ -329,11 +331,13 @@ static int launch_fwd_cfg(const void* value, const int64_t* shapes, const int64_
   if (LP == 16)
     hipLaunchKernelGGL((msda_fwd_d32_kernel<TV, TL, QPW, WPB, 16>), dim3(uint32_t(blocks)),
                        dim3(64 * WPB), lds, stream, (const TV*)value, shapes, lsi,
-                       (const TL*)loc, (const TL*)attn, (TV*)out, d, tiles_per_batch, prefetch_rows);
+                       (const TL*)loc, (const TL*)attn, (TV*)out, d, tiles_per_batch, prefetch_rows,
+                       take_stamp_region(kStampFwd, blocks));
   else
     hipLaunchKernelGGL((msda_fwd_d32_kernel<TV, TL, QPW, WPB, 0>), dim3(uint32_t(blocks)),
                        dim3(64 * WPB), lds, stream, (const TV*)value, shapes, lsi,
-                       (const TL*)loc, (const TL*)attn, (TV*)out, d, tiles_per_batch, prefetch_rows);
+                       (const TL*)loc, (const TL*)attn, (TV*)out, d, tiles_per_batch, prefetch_rows,
+                       take_stamp_region(kStampFwd, blocks));
   return check_launch("msda_fwd_d32");
 }
 
@@ -432,7 +436,9 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
                     const int64_t* __restrict__ lsi, const TL* __restrict__ loc,
                     const TL* __restrict__ attn, const TV* __restrict__ grad_out,
                     float* __restrict__ gv, TL* __restrict__ grad_loc, TL* __restrict__ grad_attn,
-                    MsdaDims d, int tiles_per_batch, uint4_t* __restrict__ sample_records) {
+                    MsdaDims d, int tiles_per_batch, uint4_t* __restrict__ sample_records,
+                    unsigned long long* stamps) {
+  stamp_begin(stamps);
   constexpr int D = 32;
   constexpr int PG = 8 / QPW;
   constexpr int kRowBytes = D * int(sizeof(TV));
@@ -575,6 +581,7 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
       store_loc<TL>(grad_attn + wi, r.z);               // cuh:156
     }
   }
+  stamp_end(stamps);
 }
 
 template <typename TV, typename TL, int QPW, int WPB>
@@ -594,7 +601,7 @@ static int launch_bwd_cfg(const void* value, const int64_t* shapes, const int64_
   hipLaunchKernelGGL((msda_bwd_d32_kernel<TV, TL, QPW, WPB, LPT, AT>), dim3(uint32_t(blocks)),   \
                      dim3(64 * WPB), lds, stream, (const TV*)value, shapes, lsi, (const TL*)loc, \
                      (const TL*)attn, (const TV*)grad_out, (float*)gv, (TL*)grad_loc,            \
-                     (TL*)grad_attn, d, tiles_per_batch, (uint4_t*)records)
+                     (TL*)grad_attn, d, tiles_per_batch, (uint4_t*)records, take_stamp_region(kStampGradLoc, blocks))
   if (!atomics) { if (LP == 16) VNX_LAUNCH(16, false); else VNX_LAUNCH(0, false); }
   else { if (LP == 16) VNX_LAUNCH(16, true); else VNX_LAUNCH(0, true); }
 #undef VNX_LAUNCH

@@ -89,12 +89,17 @@ constexpr int kLevelsMax = 64;
 constexpr size_t kLdsBytes = size_t(kRowsMax) * 128 + size_t(kQcMax) * 128 + size_t(kThreads) * 32 +
                              size_t(kRowsMax) * 12 + 16 + 4 * kLevelsMax * 4;
 
-// Development aid: per-workgroup phase timestamps (s_memtime), written when debug != 0.
+// Development aid: per-workgroup phase timestamps, written when debug != 0: shader-clock
+// ticks (s_memtime; variant 408) or constant-rate wall-clock ticks (s_memrealtime; variant 412,
+// what bench.py uses for this kernel's span: slots 0 and 12 of every workgroup).  Unlike the
+// other two tuned kernels this one takes no stamp-region argument: at its 80-VGPR budget one
+// more kernel argument costs 20 spilled registers.
 __device__ unsigned long long g_rec_stamps[4096 * 16];
 #define VNX_STAMP(k)                                                              \
   do {                                                                            \
     if (debug && tid == 0 && blockIdx.x < 4096)                                   \
-      g_rec_stamps[blockIdx.x * 16 + (k)] = __builtin_readcyclecounter();         \
+      g_rec_stamps[blockIdx.x * 16 + (k)] =                                        \
+          debug == 5 ? (unsigned long long)wall_clock64() : __builtin_readcyclecounter(); \
   } while (0)
 
 // RS (register slab): the rows a group owns accumulate in its registers (4 VGPRs per row)
@@ -386,9 +391,9 @@ int msda_backward_gvrec_d32(int vdt, const int64_t* shapes, const int64_t* lsi, 
   if (variant >= 200 && variant < 300) units_min = variant - 200;
   if (units_min < 1) units_min = 1;
   if (units_min > 16) units_min = 16;
-  if (vdt == VNX_F32) return launch_gvrec<float>(shapes, lsi, records, grad_out, grad_value, d, units_min, (variant >= 408 && variant <= 411 ? variant - 407 : 0), (variant == 420 ? 0 : 3), stream);
-  if (vdt == VNX_BF16) return launch_gvrec<bf16_t>(shapes, lsi, records, grad_out, grad_value, d, units_min, (variant >= 408 && variant <= 411 ? variant - 407 : 0), (variant == 420 ? 0 : 3), stream);
-  if (vdt == VNX_F16) return launch_gvrec<f16_t>(shapes, lsi, records, grad_out, grad_value, d, units_min, (variant >= 408 && variant <= 411 ? variant - 407 : 0), (variant == 420 ? 0 : 3), stream);
+  if (vdt == VNX_F32) return launch_gvrec<float>(shapes, lsi, records, grad_out, grad_value, d, units_min, (variant >= 408 && variant <= 412 ? variant - 407 : 0), (variant == 420 ? 0 : 3), stream);
+  if (vdt == VNX_BF16) return launch_gvrec<bf16_t>(shapes, lsi, records, grad_out, grad_value, d, units_min, (variant >= 408 && variant <= 412 ? variant - 407 : 0), (variant == 420 ? 0 : 3), stream);
+  if (vdt == VNX_F16) return launch_gvrec<f16_t>(shapes, lsi, records, grad_out, grad_value, d, units_min, (variant >= 408 && variant <= 412 ? variant - 407 : 0), (variant == 420 ? 0 : 3), stream);
   set_error("msda_backward_gvrec_d32: unsupported dtype %d", vdt);
   return VNX_ERR_INVALID_ARGUMENT;
 }

@@ -61,6 +61,22 @@ __device__ __forceinline__ double floor_acc(double x) { return floor(x); }
 // ---- host side ---------------------------------------------------------------
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
+
+// Kernel-span stamps (measurement aid behind bench.py's roofline).  While a stamp buffer is armed
+// (vnx_debug_arm_stamps) every launch of a tuned MSDA kernel is handed a region of 2 x gridDim
+// 64-bit slots; each workgroup leaves {its start, its last wave's end} there in constant-rate
+// wall-clock ticks (s_memrealtime).  Host side: span = max(end) - min(start) = the kernel's own
+// duration on the device, without the inter-kernel gap that event timing around back-to-back
+// launches includes.  Per-workgroup slots: no same-address atomics across workgroups.
+// nullptr (the normal case) = no stamps.
+enum StampKernel { kStampFwd = 1, kStampGradLoc = 2, kStampGradValue = 3 };
+unsigned long long* take_stamp_region(int kernel, long long blocks);
+__device__ __forceinline__ void stamp_begin(unsigned long long* s) {
+  if (s && threadIdx.x == 0) s[2 * size_t(blockIdx.x)] = (unsigned long long)wall_clock64();
+}
+__device__ __forceinline__ void stamp_end(unsigned long long* s) {
+  if (s && (threadIdx.x & 63) == 0) atomicMax(s + 2 * size_t(blockIdx.x) + 1, (unsigned long long)wall_clock64());
+}
 extern int g_kernel_variant;
 
 struct MsdaDims {
