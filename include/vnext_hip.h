@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define VNX_ABI_VERSION 5
+#define VNX_ABI_VERSION 6
 
 /* element types */
 enum {
@@ -128,6 +128,45 @@ int vnx_msda_backward(int value_dtype, int loc_dtype,
                       int num_levels, int num_query, int num_point, int flags,
                       void* workspace, size_t workspace_bytes,
                       void* hip_stream);
+
+/*
+ * MSDeformAttn with the module's prologue fused in.  Instead of
+ * sampling_locations / attention_weights the kernels take what the module computes them from:
+ *   sampling_offsets  [batch, num_query, num_heads, num_levels, num_point, 2]  output of the
+ *                     `sampling_offsets` Linear
+ *   attention_logits  [batch, num_query, num_heads, num_levels * num_point]    output of the
+ *                     `attention_weights` Linear, BEFORE the softmax
+ *   reference_points  [batch / reference_batch_div, num_query, num_levels, ref_dim]
+ * and evaluate   attention = softmax(logits)   and
+ *   ref_dim 2:  location = reference + offsets / (W_l, H_l)
+ *   ref_dim 4:  location = reference_xy + offsets / num_point * reference_wh * 0.5
+ * (projects/IDOL/idol/models/ops/modules/ms_deform_attn.py:99-108; SeqFormer :99-112, :159-161)
+ * inside the sampling kernels, so the two intermediate tensors never exist in memory.
+ * reference_batch_div > 1: that many consecutive batch elements share one reference row (the
+ * frames of a clip in SeqFormer's encoder).  Requirements: channels == 32,
+ * num_levels * num_point == 16, value f32 or bf16 (offsets / logits / references all
+ * `query_dtype`: f32, or bf16 with a bf16 value), PACKED levels (level_start_index = running
+ * sum of H*W; the backward's grad_value kernel does nothing on the device otherwise).  Anything
+ * else: VNX_ERR_UNSUPPORTED -- use vnx_msda_forward / vnx_msda_backward.
+ * Backward: grad_sampling_offsets / grad_attention_logits like their inputs; grad_value like
+ * value; grad_reference_points (optional, fp32 [batch, num_query, num_levels, 2], ref_dim 2
+ * and reference_batch_div 1 only) is zero-filled inside and accumulated over heads with fp32
+ * atomics.  workspace: vnx_msda_fused_backward_workspace_bytes(...) bytes of device memory.
+ */
+int vnx_msda_fused_forward(int value_dtype, int query_dtype, const void* value, const int64_t* spatial_shapes,
+                           const int64_t* level_start_index, const void* sampling_offsets,
+                           const void* attention_logits, const void* reference_points, void* output,
+                           int batch, int spatial_size, int num_heads, int channels, int num_levels,
+                           int num_query, int num_point, int ref_dim, int reference_batch_div, void* hip_stream);
+size_t vnx_msda_fused_backward_workspace_bytes(int batch, int num_heads, int num_levels, int num_query,
+                                               int num_point);
+int vnx_msda_fused_backward(int value_dtype, int query_dtype, const void* value, const int64_t* spatial_shapes,
+                            const int64_t* level_start_index, const void* sampling_offsets,
+                            const void* attention_logits, const void* reference_points, const void* grad_output,
+                            void* grad_value, void* grad_sampling_offsets, void* grad_attention_logits,
+                            float* grad_reference_points, int batch, int spatial_size, int num_heads,
+                            int channels, int num_levels, int num_query, int num_point, int ref_dim,
+                            int reference_batch_div, void* workspace, size_t workspace_bytes, void* hip_stream);
 
 /*
  * CondInst-style dynamic mask head, forward (per-instance 1x1 conv stack 10->8->8->1 on

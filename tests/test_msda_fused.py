@@ -1,0 +1,162 @@
+"""MSDeformAttn with the module's prologue fused in: the fused kernels against
+(a) the fp64 oracle fed with numpy-computed softmax / locations and (b) autograd through the unfused
+composition the reference module spells out (ops/modules/ms_deform_attn.py:99-112)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import msda_oracle as O
+
+SHAPES = [(12, 20), (6, 10), (3, 5), (2, 3)]
+
+
+def make(B, Lq, ref_dim, ref_div, seed, dtype=torch.float32, M=8, P=4):
+    g = torch.Generator().manual_seed(seed)
+    L = len(SHAPES)
+    S = sum(h * w for h, w in SHAPES)
+    value = torch.randn(B, S, M, 32, generator=g)
+    offsets = torch.randn(B, Lq, M, L, P, 2, generator=g) * (2.0 if ref_dim == 2 else 1.0)
+    logits = torch.randn(B, Lq, M, L * P, generator=g) * 2
+    ref = torch.rand(B // ref_div, Lq, L, ref_dim, generator=g)
+    if ref_dim == 4:
+        ref[..., 2:] = 0.05 + 0.4 * ref[..., 2:]
+    ref[0, 0, :, :2] = 1.2            # a query whose samples fall outside the map
+    gout = torch.randn(B, Lq, M * 32, generator=g)
+    return [t.to(dtype) for t in (value, offsets, logits, ref)] + [gout.to(dtype)]
+
+
+def compose(value, offsets, logits, ref, ref_div, shapes_t):
+    """the reference module's expressions (IDOL ops/modules/ms_deform_attn.py:99-108)"""
+    B, Lq, M, L, P, _ = offsets.shape
+    attn = torch.softmax(logits, -1).view(B, Lq, M, L, P)
+    r = ref.repeat_interleave(ref_div, 0)
+    if ref.shape[-1] == 2:
+        normalizer = torch.stack([shapes_t[..., 1], shapes_t[..., 0]], -1)
+        loc = r[:, :, None, :, None, :] + offsets / normalizer[None, None, None, :, None, :]
+    else:
+        loc = r[:, :, None, :, None, :2] + offsets / P * r[:, :, None, :, None, 2:] * 0.5
+    return loc, attn
+
+
+def level_tensors(device):
+    from vnext_amd.ops.functions import level_tensors as lt
+    return lt(SHAPES, device)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,Lq,ref_dim,ref_div", [(2, 37, 2, 1), (4, 300, 2, 2), (3, 50, 4, 1), (6, 1200, 4, 3),
+                                                   (1, 1, 2, 1)])
+def test_fused_forward_against_oracle_and_composition(B, Lq, ref_dim, ref_div):
+    from vnext_amd.ops.functions import MSDeformAttnFunction, MSDeformAttnFusedFunction
+    value, offsets, logits, ref, _ = make(B, Lq, ref_dim, ref_div, seed=B * 100 + Lq)
+    dev = "cuda:0"
+    shapes_t, lsi = level_tensors(dev)
+    out = MSDeformAttnFusedFunction.apply(value.to(dev), shapes_t, lsi, offsets.to(dev), logits.to(dev), ref.to(dev))
+    loc, attn = compose(value.to(dev), offsets.to(dev), logits.to(dev), ref.to(dev), ref_div, shapes_t)
+    unfused = MSDeformAttnFunction.apply(value.to(dev), shapes_t, lsi, loc.contiguous(), attn.contiguous(), 64)
+    scale = float(unfused.abs().max())
+    assert float((out - unfused).abs().max()) <= 2e-5 * scale
+    # fp64 oracle on numpy-computed softmax / locations
+    loc64, attn64 = compose(value.double(), offsets.double(), logits.double(), ref.double(), ref_div,
+                            torch.tensor(SHAPES, dtype=torch.long))
+    want = O.msda_forward(value.double().numpy(), np.array(SHAPES, dtype=np.int64), lsi.cpu().numpy(),
+                          loc64.numpy(), attn64.numpy())
+    np.testing.assert_allclose(out.double().cpu().numpy(), want, rtol=0, atol=3e-5 * float(np.abs(want).max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,Lq,ref_dim,ref_div,ref_grad", [(2, 37, 2, 1, True), (4, 300, 2, 2, False), (3, 50, 4, 1, False),
+                                                            (5, 300, 4, 1, False)])
+def test_fused_backward_against_autograd_of_the_composition(B, Lq, ref_dim, ref_div, ref_grad):
+    from vnext_amd.ops.functions import MSDeformAttnFunction, MSDeformAttnFusedFunction
+    dev = "cuda:0"
+    value, offsets, logits, ref, gout = [t.to(dev) for t in make(B, Lq, ref_dim, ref_div, seed=7 * B + Lq)]
+    shapes_t, lsi = level_tensors(dev)
+
+    def leaves():
+        ts = [value.clone().requires_grad_(True), offsets.clone().requires_grad_(True),
+              logits.clone().requires_grad_(True), ref.clone().requires_grad_(ref_grad)]
+        return ts
+    v, o, lg, r = leaves()
+    MSDeformAttnFusedFunction.apply(v, shapes_t, lsi, o, lg, r).backward(gout)
+    v2, o2, lg2, r2 = leaves()
+    loc, attn = compose(v2, o2, lg2, r2, ref_div, shapes_t)
+    MSDeformAttnFunction.apply(v2, shapes_t, lsi, loc.contiguous(), attn.contiguous(), 64).backward(gout)
+    pairs = [("value", v.grad, v2.grad), ("offsets", o.grad, o2.grad), ("logits", lg.grad, lg2.grad)]
+    if ref_grad:
+        pairs.append(("reference", r.grad, r2.grad))
+    for name, got, want in pairs:
+        scale = float(want.abs().max()) + 1e-12
+        assert float((got - want).abs().max()) <= 5e-5 * scale, name
+
+
+@pytest.mark.gpu
+def test_fused_bf16_value_with_fp32_queries():
+    from vnext_amd.ops.functions import MSDeformAttnFusedFunction
+    dev = "cuda:0"
+    value, offsets, logits, ref, gout = [t.to(dev) for t in make(3, 80, 4, 1, seed=5)]
+    shapes_t, lsi = level_tensors(dev)
+    want = MSDeformAttnFusedFunction.apply(value, shapes_t, lsi, offsets, logits, ref)
+    got = MSDeformAttnFusedFunction.apply(value.bfloat16(), shapes_t, lsi, offsets, logits, ref)
+    assert got.dtype == torch.bfloat16
+    assert float((got.float() - want).abs().max()) <= 2e-2 * float(want.abs().max())
+
+
+@pytest.mark.gpu
+def test_unsupported_cases_are_reported_not_guessed():
+    from vnext_amd import msda_ext
+    dev = "cuda:0"
+    value, offsets, logits, ref, _ = [t.to(dev) for t in make(2, 9, 2, 1, seed=1)]
+    shapes_t, lsi = level_tensors(dev)
+    assert msda_ext.fused_supported(value, offsets, logits, ref, lsi)
+    assert not msda_ext.fused_supported(value, offsets, logits, ref, lsi.clone())          # not tagged as packed
+    assert not msda_ext.fused_supported(value.double(), offsets, logits, ref, lsi)
+    assert not msda_ext.fused_supported(value[..., :16].contiguous(), offsets, logits, ref, lsi)
+    with pytest.raises(RuntimeError, match="built for 32-channel heads"):
+        msda_ext.ms_deform_attn_fused_forward(value[..., :16].contiguous(), shapes_t, lsi, offsets, logits, ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["idol", "seqformer_encode", "seqformer_decode"])
+def test_modules_with_the_fused_prologue_equal_the_reference_form(kind):
+    """return_samples=False switches a module to the fused kernels: same output and parameter
+    gradients as the reference-form module (which materialises locations and weights)."""
+    from vnext_amd.ops.modules import MSDeformAttnIDOL, MSDeformAttnSeqFormer
+    dev = "cuda:0"
+    torch.manual_seed(3)
+    N, T, Lq, C = 2, 3, 40, 256
+    S = sum(h * w for h, w in SHAPES)
+    shapes_t, lsi = level_tensors(dev)
+    if kind == "idol":
+        mod = MSDeformAttnIDOL(C, 4, 8, 4).to(dev)
+        args = lambda: (torch.randn(N, Lq, C, device=dev), torch.rand(N, Lq, 4, 2, device=dev),  # noqa: E731
+                        torch.randn(N, S, C, device=dev), shapes_t, lsi, None)
+    elif kind == "seqformer_encode":
+        mod = MSDeformAttnSeqFormer(C, 4, 8, 4, "encode").to(dev)
+        args = lambda: (torch.randn(N, T, Lq, C, device=dev), None, torch.rand(N, Lq, 4, 2, device=dev),  # noqa: E731
+                        torch.randn(N, T, S, C, device=dev), shapes_t, lsi, None)
+    else:
+        mod = MSDeformAttnSeqFormer(C, 4, 8, 4, "decode").to(dev)
+        args = lambda: (torch.randn(N, Lq, C, device=dev), torch.randn(N, T, Lq, C, device=dev),  # noqa: E731
+                        0.1 + 0.5 * torch.rand(N, T, Lq, 4, 4, device=dev), torch.randn(N, T, S, C, device=dev),
+                        shapes_t, lsi, None)
+    with torch.no_grad():
+        mod.sampling_offsets.weight.normal_(0, 0.02)
+        mod.attention_weights.weight.normal_(0, 0.05)
+
+    def run(fused):
+        mod.return_samples = not fused
+        mod.zero_grad()
+        torch.manual_seed(9)
+        out = mod(*args())
+        first = out[0] if isinstance(out, tuple) else out
+        first.square().sum().backward()
+        return first.detach(), {n: p.grad.clone() for n, p in mod.named_parameters() if p.grad is not None}, out
+    ref_out, ref_grads, _ = run(False)
+    got_out, got_grads, raw = run(True)
+    if kind != "seqformer_encode":
+        assert raw[-1] is None and raw[-2] is None          # nothing materialised
+    assert float((got_out - ref_out).abs().max()) <= 2e-5 * float(ref_out.abs().max())
+    assert set(got_grads) == set(ref_grads)
+    for n in ref_grads:
+        assert float((got_grads[n] - ref_grads[n]).abs().max()) <= 2e-4 * (float(ref_grads[n].abs().max()) + 1e-12), n

@@ -49,6 +49,11 @@ int msda_forward_d32(int, int, const void*, const int64_t*, const int64_t*, cons
 int msda_backward_d32(int, int, const void*, const int64_t*, const int64_t*, const void*,
                       const void*, const void*, void*, void*, void*, MsdaDims, int variant,
                       void* records, hipStream_t);
+bool msda_d32_fused_supported(int vdt, int ldt, const MsdaDims& d);
+int msda_fused_d32(bool backward, int vdt, int ldt, const void* value, const int64_t* shapes, const int64_t* lsi,
+                   const void* raw_off, const void* raw_logit, const void* grad_out, void* out_or_grad_off,
+                   void* grad_logit, MsdaDims d, void* records, const void* reference, float* grad_reference,
+                   int ref_dim, int ref_div, hipStream_t stream);
 bool msda_d32_gvrec_supported(int vdt, int ldt, const MsdaDims& d);
 size_t msda_gvrec_record_bytes(const MsdaDims& d);
 int msda_backward_gvrec_d32(int vdt, const int64_t*, const int64_t*, const void* records, const void*,
@@ -359,6 +364,97 @@ int vnx_msda_backward(int value_dtype, int loc_dtype, const void* value,
     return convert_f32_to(value_dtype, workspace, grad_value, int64_t(n_value), nullptr, nullptr, 0, 0,
                           stream);
   return VNX_OK;
+}
+
+
+// ---- fused prologue (include/vnext_hip.h) -----------------------------------------------------
+static int check_fused(const char* fn, int value_dtype, int q_dtype, const MsdaDims& d, int ref_dim, int ref_div) {
+  if (d.B < 0 || d.S < 0 || d.M <= 0 || d.D <= 0 || d.L <= 0 || d.Lq < 0 || d.P <= 0) {
+    set_error("%s: bad sizes", fn);
+    return VNX_ERR_INVALID_ARGUMENT;
+  }
+  if ((ref_dim != 2 && ref_dim != 4) || ref_div <= 0 || (d.B % ref_div) != 0) {
+    set_error("%s: reference points must have 2 or 4 components and batch must be a multiple of "
+              "reference_batch_div (got ref_dim=%d, batch=%d, div=%d)", fn, ref_dim, d.B, ref_div);
+    return VNX_ERR_INVALID_ARGUMENT;
+  }
+  if (!msda_d32_fused_supported(value_dtype, q_dtype, d) || !msda_d32_gvrec_supported(value_dtype, q_dtype, d)) {
+    set_error("%s: the fused prologue is built for 32-channel heads, levels*points == 16, fp32 or bf16 "
+              "(got D=%d, L*P=%d, dtypes %d/%d); use vnx_msda_forward/backward", fn, d.D, d.L * d.P,
+              value_dtype, q_dtype);
+    return VNX_ERR_UNSUPPORTED;
+  }
+  return VNX_OK;
+}
+
+int vnx_msda_fused_forward(int value_dtype, int query_dtype, const void* value, const int64_t* spatial_shapes,
+                           const int64_t* level_start_index, const void* sampling_offsets,
+                           const void* attention_logits, const void* reference_points, void* output, int batch,
+                           int spatial_size, int num_heads, int channels, int num_levels, int num_query,
+                           int num_point, int ref_dim, int reference_batch_div, void* hip_stream) {
+  const MsdaDims d{batch, spatial_size, num_heads, channels, num_levels, num_query, num_point};
+  const int st = check_fused("vnx_msda_fused_forward", value_dtype, query_dtype, d, ref_dim, reference_batch_div);
+  if (st != VNX_OK) return st;
+  if (batch == 0 || num_query == 0) return VNX_OK;
+  if (!value || !spatial_shapes || !level_start_index || !sampling_offsets || !attention_logits ||
+      !reference_points || !output) {
+    set_error("vnx_msda_fused_forward: null pointer argument");
+    return VNX_ERR_INVALID_ARGUMENT;
+  }
+  return msda_fused_d32(false, value_dtype, query_dtype, value, spatial_shapes, level_start_index, sampling_offsets,
+                        attention_logits, nullptr, output, nullptr, d, nullptr, reference_points, nullptr, ref_dim,
+                        reference_batch_div, (hipStream_t)hip_stream);
+}
+
+size_t vnx_msda_fused_backward_workspace_bytes(int batch, int num_heads, int num_levels, int num_query,
+                                               int num_point) {
+  const MsdaDims d{batch, 0, num_heads, 32, num_levels, num_query, num_point};
+  return align256(msda_gvrec_record_bytes(d));
+}
+
+int vnx_msda_fused_backward(int value_dtype, int query_dtype, const void* value, const int64_t* spatial_shapes,
+                            const int64_t* level_start_index, const void* sampling_offsets,
+                            const void* attention_logits, const void* reference_points, const void* grad_output,
+                            void* grad_value, void* grad_sampling_offsets, void* grad_attention_logits,
+                            float* grad_reference_points, int batch, int spatial_size, int num_heads,
+                            int channels, int num_levels, int num_query, int num_point, int ref_dim,
+                            int reference_batch_div, void* workspace, size_t workspace_bytes, void* hip_stream) {
+  const MsdaDims d{batch, spatial_size, num_heads, channels, num_levels, num_query, num_point};
+  int st = check_fused("vnx_msda_fused_backward", value_dtype, query_dtype, d, ref_dim, reference_batch_div);
+  if (st != VNX_OK) return st;
+  hipStream_t stream = (hipStream_t)hip_stream;
+  if (grad_reference_points && (ref_dim != 2 || reference_batch_div != 1)) {
+    set_error("vnx_msda_fused_backward: reference-point gradients are built for 2-d, per-batch references");
+    return VNX_ERR_UNSUPPORTED;
+  }
+  if (grad_reference_points && batch > 0 && num_query > 0 &&
+      hipMemsetAsync(grad_reference_points, 0, size_t(batch) * num_query * num_levels * 2 * sizeof(float), stream) !=
+          hipSuccess)
+    return check_launch("msda_fused_backward memset");
+  if (batch == 0 || num_query == 0) {
+    // no samples: grad_value is all zeros
+    const size_t nbytes = size_t(batch) * spatial_size * num_heads * channels * size_t(elem_size(value_dtype));
+    if (nbytes && hipMemsetAsync(grad_value, 0, nbytes, stream) != hipSuccess) return check_launch("memset");
+    return VNX_OK;
+  }
+  if (!value || !spatial_shapes || !level_start_index || !sampling_offsets || !attention_logits ||
+      !reference_points || !grad_output || !grad_value || !grad_sampling_offsets || !grad_attention_logits) {
+    set_error("vnx_msda_fused_backward: null pointer argument");
+    return VNX_ERR_INVALID_ARGUMENT;
+  }
+  const size_t need = align256(msda_gvrec_record_bytes(d));
+  if (!workspace || workspace_bytes < need) {
+    set_error("vnx_msda_fused_backward: workspace of %zu bytes needed (got %zu)", need, workspace_bytes);
+    return VNX_ERR_WORKSPACE;
+  }
+  // (1) grad of the Linear outputs (+ reference points) and the sample records; (2) grad_value from
+  // the records.  Packed levels are required (the records-fed kernel is a no-op on the device otherwise).
+  st = msda_fused_d32(true, value_dtype, query_dtype, value, spatial_shapes, level_start_index, sampling_offsets,
+                      attention_logits, grad_output, grad_sampling_offsets, grad_attention_logits, d, workspace,
+                      reference_points, grad_reference_points, ref_dim, reference_batch_div, stream);
+  if (st != VNX_OK) return st;
+  return msda_backward_gvrec_d32(value_dtype, spatial_shapes, level_start_index, workspace, grad_output,
+                                 grad_value, d, g_kernel_variant, stream);
 }
 
 }  // extern "C"

@@ -109,6 +109,65 @@ __device__ __forceinline__ void store_row4<f16_t>(f16_t* p, float4_t v) {
 // forward
 // -----------------------------------------------------------------------------
 // LP = levels*points (template value 0 = use the runtime value, no unrolling).
+// -----------------------------------------------------------------------------
+// fused prologue
+// -----------------------------------------------------------------------------
+// The module computes  attention = softmax(Linear(q))  over the L*P samples of a (query, head)
+// and  location = reference + offsets / (W_l, H_l)   (2-d references,
+// projects/IDOL/idol/models/ops/modules/ms_deform_attn.py:102-105) or
+// reference_xy + offsets / P * reference_wh * 0.5   (4-d, :106-108) in separate kernels and
+// hands the op two tensors that exist only to be read once.  With FUSED the kernels take the
+// two Linear outputs and the reference points instead: `loc` = raw offsets, `attn` = raw
+// logits, and the softmax (a 16-lane row per (query, head): L*P == 16) and the location
+// arithmetic happen in the one-lane-per-sample phase that decoded them anyway.
+struct FusedArgs {
+  const void* reference;   // [B / ref_div, Lq, L, ref_dim], same element type as the offsets
+  float* grad_reference;   // [B, Lq, L, 2] fp32, zero-filled, accumulated over heads; or null
+  int ref_dim;             // 2 or 4
+  int ref_div;             // consecutive batch elements sharing one reference row (frames of a clip)
+};
+
+__device__ __forceinline__ float row16_max(float v) {
+#pragma unroll
+  for (int k = 1; k < 16; k <<= 1) v = fmaxf(v, __shfl_xor(v, k, 16));
+  return v;
+}
+__device__ __forceinline__ float row16_sum(float v) {
+#pragma unroll
+  for (int k = 1; k < 16; k <<= 1) v += __shfl_xor(v, k, 16);
+  return v;
+}
+
+// -> location (x, y) in [0, 1] units, softmax weight a, and d(location)/d(offset) (sx, sy).
+// Called by all 16 lanes of a (query, head) row together (`valid` is uniform over the row).
+template <typename TL>
+__device__ __forceinline__ void fused_decode(const TL* __restrict__ raw_off, const TL* __restrict__ raw_logit,
+                                             const FusedArgs& fa, int64_t wi, int b, int q, int l, int H, int W,
+                                             const MsdaDims& d, bool valid, float& x, float& y, float& a,
+                                             float& sx, float& sy) {
+  const float lg = valid ? to_acc(raw_logit[wi]) : 0.f;
+  const float ex = expf(lg - row16_max(lg));
+  a = ex / row16_sum(ex);
+  x = y = sx = sy = 0.f;
+  if (valid) {
+    const TL* r = static_cast<const TL*>(fa.reference) +
+                  ((int64_t(b / fa.ref_div) * d.Lq + q) * d.L + l) * fa.ref_dim;
+    const float ox = to_acc(raw_off[2 * wi]), oy = to_acc(raw_off[2 * wi + 1]);
+    if (fa.ref_dim == 2) {
+      x = to_acc(r[0]) + ox / float(W);
+      y = to_acc(r[1]) + oy / float(H);
+      sx = 1.f / float(W);
+      sy = 1.f / float(H);
+    } else {
+      const float rw = to_acc(r[2]), rh = to_acc(r[3]), np = float(d.P);
+      x = to_acc(r[0]) + ox / np * rw * 0.5f;
+      y = to_acc(r[1]) + oy / np * rh * 0.5f;
+      sx = rw * 0.5f / np;
+      sy = rh * 0.5f / np;
+    }
+  }
+}
+
 // VNX_FWD_WPE / VNX_K1_WPE: amdgpu_waves_per_eu hint (second __launch_bounds__ argument); the
 // register-allocation and scheduling heuristics follow it, and the measured best is built in.
 #ifndef VNX_FWD_WPE
@@ -127,12 +186,13 @@ __device__ __forceinline__ void store_row4<f16_t>(f16_t* p, float4_t v) {
 #else
 #define VNX_K1_BOUNDS(n) __launch_bounds__(n)
 #endif
-template <typename TV, typename TL, int QPW, int WPB, int LP_T>
+template <typename TV, typename TL, int QPW, int WPB, int LP_T, bool FUSED = false>
 __global__ void VNX_FWD_BOUNDS(64 * WPB)
 msda_fwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ shapes,
                     const int64_t* __restrict__ lsi, const TL* __restrict__ loc,
                     const TL* __restrict__ attn, TV* __restrict__ out, MsdaDims d,
-                    int tiles_per_batch, int prefetch_rows, unsigned long long* stamps) {
+                    int tiles_per_batch, int prefetch_rows, unsigned long long* stamps, FusedArgs fa) {
+  static_assert(!FUSED || LP_T == 16, "the fused prologue is built for L*P == 16");
   stamp_begin(stamps);
   constexpr int D = 32;
   constexpr int PG = 8 / QPW;            // sample groups per query
@@ -182,11 +242,20 @@ msda_fwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
     const int q = q0 + qi;
     uint4_t o4 = {kTapOutside, kTapOutside, kTapOutside, kTapOutside};
     float4_t w4 = {0.f, 0.f, 0.f, 0.f};
+    const int l = p / d.P;
+    const int64_t wi = ((int64_t(b) * d.Lq + q) * d.M + m) * LP + p;
+    float x = 0.f, y = 0.f, a = 0.f;
+    if constexpr (FUSED) {
+      float sx, sy;
+      const bool valid = q < d.Lq;
+      fused_decode<TL>(loc, attn, fa, wi, b, q, l, valid ? int(shapes[2 * l]) : 1, valid ? int(shapes[2 * l + 1]) : 1,
+                       d, valid, x, y, a, sx, sy);
+    }
     if (q < d.Lq) {
-      const int l = p / d.P;
-      const int64_t wi = ((int64_t(b) * d.Lq + q) * d.M + m) * LP + p;
-      const float x = to_acc(loc[2 * wi]), y = to_acc(loc[2 * wi + 1]);
-      const float a = to_acc(attn[wi]);
+      if constexpr (!FUSED) {
+        x = to_acc(loc[2 * wi]); y = to_acc(loc[2 * wi + 1]);
+        a = to_acc(attn[wi]);
+      }
       const int H = int(shapes[2 * l]), W = int(shapes[2 * l + 1]);
       const int start = int(lsi[l]);
       const float h = y * float(H) - 0.5f, w = x * float(W) - 0.5f;
@@ -332,12 +401,12 @@ static int launch_fwd_cfg(const void* value, const int64_t* shapes, const int64_
     hipLaunchKernelGGL((msda_fwd_d32_kernel<TV, TL, QPW, WPB, 16>), dim3(uint32_t(blocks)),
                        dim3(64 * WPB), lds, stream, (const TV*)value, shapes, lsi,
                        (const TL*)loc, (const TL*)attn, (TV*)out, d, tiles_per_batch, prefetch_rows,
-                       take_stamp_region(kStampFwd, blocks));
+                       take_stamp_region(kStampFwd, blocks), FusedArgs{});
   else
     hipLaunchKernelGGL((msda_fwd_d32_kernel<TV, TL, QPW, WPB, 0>), dim3(uint32_t(blocks)),
                        dim3(64 * WPB), lds, stream, (const TV*)value, shapes, lsi,
                        (const TL*)loc, (const TL*)attn, (TV*)out, d, tiles_per_batch, prefetch_rows,
-                       take_stamp_region(kStampFwd, blocks));
+                       take_stamp_region(kStampFwd, blocks), FusedArgs{});
   return check_launch("msda_fwd_d32");
 }
 
@@ -430,14 +499,15 @@ __device__ __forceinline__ void store_loc(TL* p, float v) { *p = from_acc<TL>(v)
 //      cuh:376-394, become 9 DPP adds).
 // grad_value accumulates in fp32 (`gv`: grad_value itself for fp32, the workspace
 // image for 16-bit values), laid out [B,S,M,32] fp32.
-template <typename TV, typename TL, int QPW, int WPB, int LP_T, bool ATOMICS>
+template <typename TV, typename TL, int QPW, int WPB, int LP_T, bool ATOMICS, bool FUSED = false>
 __global__ void VNX_K1_BOUNDS(64 * WPB)
 msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ shapes,
                     const int64_t* __restrict__ lsi, const TL* __restrict__ loc,
                     const TL* __restrict__ attn, const TV* __restrict__ grad_out,
                     float* __restrict__ gv, TL* __restrict__ grad_loc, TL* __restrict__ grad_attn,
                     MsdaDims d, int tiles_per_batch, uint4_t* __restrict__ sample_records,
-                    unsigned long long* stamps) {
+                    unsigned long long* stamps, FusedArgs fa) {
+  static_assert(!FUSED || (LP_T == 16 && !ATOMICS), "the fused prologue is built for L*P == 16, record-fed grad_value");
   stamp_begin(stamps);
   constexpr int D = 32;
   constexpr int PG = 8 / QPW;
@@ -468,11 +538,21 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
     const int q = q0 + qi;
     uint4_t o4 = {kTapOutsideElem, kTapOutsideElem, kTapOutsideElem, kTapOutsideElem};
     float4_t g4 = {0.f, 0.f, 0.f, 0.f};
+    const int l = p / d.P;
+    const int64_t wi = ((int64_t(b) * d.Lq + q) * d.M + m) * LP + p;
+    float x = 0.f, y = 0.f, a = 0.f;
+    if constexpr (FUSED) {
+      float sx, sy;
+      const bool valid = q < d.Lq;
+      fused_decode<TL>(loc, attn, fa, wi, b, q, l, valid ? int(shapes[2 * l]) : 1, valid ? int(shapes[2 * l + 1]) : 1,
+                       d, valid, x, y, a, sx, sy);
+      g4.w = a;   // the softmax weight of every sample, in or out of the map (softmax backward, phase 3)
+    }
     if (q < d.Lq) {
-      const int l = p / d.P;
-      const int64_t wi = ((int64_t(b) * d.Lq + q) * d.M + m) * LP + p;
-      const float x = to_acc(loc[2 * wi]), y = to_acc(loc[2 * wi + 1]);
-      const float a = to_acc(attn[wi]);
+      if constexpr (!FUSED) {
+        x = to_acc(loc[2 * wi]); y = to_acc(loc[2 * wi + 1]);
+        a = to_acc(attn[wi]);
+      }
       const int H = int(shapes[2 * l]), W = int(shapes[2 * l + 1]);
       const int start = int(lsi[l]);
       const float h = y * float(H) - 0.5f, w = x * float(W) - 0.5f;
@@ -576,9 +656,36 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
       const int64_t wi = ((int64_t(b) * d.Lq + q3) * d.M + m) * LP + p;
       const float4_t r = s_res[qi3 * (LP + 1) + p];
       const float Hf = float(int(shapes[2 * l])), Wf = float(int(shapes[2 * l + 1]));
-      store_loc<TL>(grad_loc + 2 * wi, Wf * r.x);       // cuh:157
-      store_loc<TL>(grad_loc + 2 * wi + 1, Hf * r.y);   // cuh:158
-      store_loc<TL>(grad_attn + wi, r.z);               // cuh:156
+      if constexpr (!FUSED) {
+        store_loc<TL>(grad_loc + 2 * wi, Wf * r.x);       // cuh:157
+        store_loc<TL>(grad_loc + 2 * wi + 1, Hf * r.y);   // cuh:158
+        store_loc<TL>(grad_attn + wi, r.z);               // cuh:156
+      } else {
+        // chain rule through the prologue: d loc / d offset is a per-sample scale, the softmax
+        // backward  g_logit = a (g_a - sum_j a_j g_a_j)  is a 16-lane row sum, and 2-d reference
+        // points collect the location gradients of their level over points (lanes) and heads
+        const float gx = Wf * r.x, gy = Hf * r.y, a = s_geo[qi3 * (LP + 1) + p].w;
+        const float dot = row16_sum(a * r.z);
+        float sx, sy;
+        if (fa.ref_dim == 2) {
+          sx = 1.f / Wf; sy = 1.f / Hf;
+        } else {
+          const TL* rf = static_cast<const TL*>(fa.reference) + ((int64_t(b / fa.ref_div) * d.Lq + q3) * d.L + l) * 4;
+          sx = to_acc(rf[2]) * 0.5f / float(d.P); sy = to_acc(rf[3]) * 0.5f / float(d.P);
+        }
+        store_loc<TL>(grad_loc + 2 * wi, gx * sx);
+        store_loc<TL>(grad_loc + 2 * wi + 1, gy * sy);
+        store_loc<TL>(grad_attn + wi, a * (r.z - dot));
+        if (fa.grad_reference != nullptr) {
+          float rx = gx, ry = gy;
+          for (int k = 1; k < d.P; k <<= 1) { rx += __shfl_xor(rx, k, 16); ry += __shfl_xor(ry, k, 16); }
+          if (p - l * d.P == 0) {
+            float* gr = fa.grad_reference + ((int64_t(b) * d.Lq + q3) * d.L + l) * 2;
+            atomic_add(gr, rx);
+            atomic_add(gr + 1, ry);
+          }
+        }
+      }
     }
   }
   stamp_end(stamps);
@@ -601,7 +708,8 @@ static int launch_bwd_cfg(const void* value, const int64_t* shapes, const int64_
   hipLaunchKernelGGL((msda_bwd_d32_kernel<TV, TL, QPW, WPB, LPT, AT>), dim3(uint32_t(blocks)),   \
                      dim3(64 * WPB), lds, stream, (const TV*)value, shapes, lsi, (const TL*)loc, \
                      (const TL*)attn, (const TV*)grad_out, (float*)gv, (TL*)grad_loc,            \
-                     (TL*)grad_attn, d, tiles_per_batch, (uint4_t*)records, take_stamp_region(kStampGradLoc, blocks))
+                     (TL*)grad_attn, d, tiles_per_batch, (uint4_t*)records, take_stamp_region(kStampGradLoc, blocks), \
+                     FusedArgs{})
   if (!atomics) { if (LP == 16) VNX_LAUNCH(16, false); else VNX_LAUNCH(0, false); }
   else { if (LP == 16) VNX_LAUNCH(16, true); else VNX_LAUNCH(0, true); }
 #undef VNX_LAUNCH
@@ -648,6 +756,78 @@ int msda_backward_d32(int vdt, int ldt, const void* value, const int64_t* shapes
 #undef VNX_ARGS
   set_error("msda_backward_d32: unsupported dtype pair (%d, %d)", vdt, ldt);
   return VNX_ERR_INVALID_ARGUMENT;
+}
+
+// ---- fused prologue: launchers (L*P == 16, the three auto-selected configurations) -----------
+template <typename TV, typename TL, int QPW, int WPB>
+static int launch_fwd_fused_cfg(const void* value, const int64_t* shapes, const int64_t* lsi, const void* raw_off,
+                                const void* raw_logit, void* out, const MsdaDims& d, const FusedArgs& fa,
+                                hipStream_t stream) {
+  const int tiles_per_batch = (d.Lq + QPW * WPB - 1) / (QPW * WPB);
+  const int64_t blocks = int64_t(d.B) * tiles_per_batch * d.M;
+  if (blocks >= (int64_t(1) << 31)) {
+    set_error("msda_fused_forward: %lld workgroups exceed the grid limit", (long long)blocks);
+    return VNX_ERR_UNSUPPORTED;
+  }
+  const size_t lds = size_t(WPB) * 2 * QPW * 17 * 16;
+  hipLaunchKernelGGL((msda_fwd_d32_kernel<TV, TL, QPW, WPB, 16, true>), dim3(uint32_t(blocks)), dim3(64 * WPB), lds,
+                     stream, (const TV*)value, shapes, lsi, (const TL*)raw_off, (const TL*)raw_logit, (TV*)out, d,
+                     tiles_per_batch, 0, take_stamp_region(kStampFwd, blocks), fa);
+  return check_launch("msda_fwd_d32_fused");
+}
+
+template <typename TV, typename TL, int QPW, int WPB>
+static int launch_bwd_fused_cfg(const void* value, const int64_t* shapes, const int64_t* lsi, const void* raw_off,
+                                const void* raw_logit, const void* grad_out, void* grad_off, void* grad_logit,
+                                const MsdaDims& d, void* records, const FusedArgs& fa, hipStream_t stream) {
+  const int tiles_per_batch = (d.Lq + QPW * WPB - 1) / (QPW * WPB);
+  const int64_t blocks = int64_t(d.B) * tiles_per_batch * d.M;
+  if (blocks >= (int64_t(1) << 31)) {
+    set_error("msda_fused_backward: %lld workgroups exceed the grid limit", (long long)blocks);
+    return VNX_ERR_UNSUPPORTED;
+  }
+  const size_t lds = size_t(WPB) * 3 * QPW * 17 * 16;
+  hipLaunchKernelGGL((msda_bwd_d32_kernel<TV, TL, QPW, WPB, 16, false, true>), dim3(uint32_t(blocks)), dim3(64 * WPB),
+                     lds, stream, (const TV*)value, shapes, lsi, (const TL*)raw_off, (const TL*)raw_logit,
+                     (const TV*)grad_out, (float*)nullptr, (TL*)grad_off, (TL*)grad_logit, d, tiles_per_batch,
+                     (uint4_t*)records, take_stamp_region(kStampGradLoc, blocks), fa);
+  return check_launch("msda_bwd_d32_fused");
+}
+
+template <typename TV, typename TL>
+static int fused_dispatch(bool backward, const void* value, const int64_t* shapes, const int64_t* lsi,
+                          const void* raw_off, const void* raw_logit, const void* grad_out, void* out_or_grad_off,
+                          void* grad_logit, const MsdaDims& d, void* records, const FusedArgs& fa, hipStream_t stream) {
+  const FwdCfg c = pick_fwd_cfg(d, 0);
+#define VNX_CASE(Q, W)                                                                                   \
+  if (c.qpw == Q && c.wpb == W)                                                                          \
+    return backward ? launch_bwd_fused_cfg<TV, TL, Q, W>(value, shapes, lsi, raw_off, raw_logit, grad_out, \
+                                                         out_or_grad_off, grad_logit, d, records, fa, stream) \
+                    : launch_fwd_fused_cfg<TV, TL, Q, W>(value, shapes, lsi, raw_off, raw_logit,           \
+                                                         out_or_grad_off, d, fa, stream);
+  VNX_CASE(4, 1) VNX_CASE(4, 4) VNX_CASE(8, 4)
+#undef VNX_CASE
+  set_error("msda_fused: no kernel for qpw=%d wpb=%d", c.qpw, c.wpb);
+  return VNX_ERR_UNSUPPORTED;
+}
+
+bool msda_d32_fused_supported(int vdt, int ldt, const MsdaDims& d) {
+  if (!msda_d32_bwd_supported(vdt, ldt, d) || d.L * d.P != 16) return false;
+  return (vdt == VNX_F32 && ldt == VNX_F32) || (vdt == VNX_BF16 && (ldt == VNX_F32 || ldt == VNX_BF16));
+}
+
+int msda_fused_d32(bool backward, int vdt, int ldt, const void* value, const int64_t* shapes, const int64_t* lsi,
+                   const void* raw_off, const void* raw_logit, const void* grad_out, void* out_or_grad_off,
+                   void* grad_logit, MsdaDims d, void* records, const void* reference, float* grad_reference,
+                   int ref_dim, int ref_div, hipStream_t stream) {
+  const FusedArgs fa{reference, grad_reference, ref_dim, ref_div};
+#define VNX_ARGS backward, value, shapes, lsi, raw_off, raw_logit, grad_out, out_or_grad_off, grad_logit, d, records, fa, stream
+  if (vdt == VNX_F32) return fused_dispatch<float, float>(VNX_ARGS);
+  if (vdt == VNX_BF16 && ldt == VNX_F32) return fused_dispatch<bf16_t, float>(VNX_ARGS);
+  if (vdt == VNX_BF16 && ldt == VNX_BF16) return fused_dispatch<bf16_t, bf16_t>(VNX_ARGS);
+#undef VNX_ARGS
+  set_error("msda_fused: unsupported dtype pair (%d, %d)", vdt, ldt);
+  return VNX_ERR_UNSUPPORTED;
 }
 
 }  // namespace vnx

@@ -153,6 +153,13 @@ class DeformableTransformer(nn.Module):
         self.level_embed = nn.Parameter(torch.Tensor(num_feature_levels, d_model))
         self.reference_points = nn.Linear(d_model, 2)
         self._reset_parameters()
+        for m in self.encoder.modules():   # the encoder never reads locations / weights: fused prologue
+            if isinstance(m, MSDeformAttnIDOL):
+                m.return_samples = False
+        if not return_samples:             # nor does the decoder, unless the sample keeper is on
+            for m in self.decoder.modules():
+                if isinstance(m, MSDeformAttnIDOL):
+                    m.return_samples = False
 
     def _reset_parameters(self):
         for p in self.parameters():

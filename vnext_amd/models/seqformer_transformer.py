@@ -243,6 +243,9 @@ class DeformableTransformer(nn.Module):
         self.level_embed = nn.Parameter(torch.Tensor(num_feature_levels, d_model))
         self.reference_points = nn.Linear(d_model, 2)
         self._reset_parameters()
+        for m in self.modules():     # nothing here reads the modules' locations / weights: fused prologue
+            if isinstance(m, MSDeformAttnSeqFormer):
+                m.return_samples = False
 
     def _reset_parameters(self):
         for p in self.parameters():

@@ -131,3 +131,76 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
             _stream_ptr(value.device))
     _lib.check(st)
     return [grad_value, grad_sampling_loc, grad_attn_weight]
+
+
+# ---------------------------------------------------------------------------------- fused prologue
+def fused_supported(value, sampling_offsets, attention_logits, reference_points, level_start_index):
+    """True when vnx_msda_fused_* can take these tensors (else: compose the unfused op)."""
+    if not (value.is_cuda and value.dim() == 4 and value.shape[-1] == 32):
+        return False
+    if sampling_offsets.dim() != 6 or sampling_offsets.shape[3] * sampling_offsets.shape[4] != 16:
+        return False
+    if sampling_offsets.shape[0] != value.shape[0] or reference_points.shape[-1] not in (2, 4):
+        return False
+    if not getattr(level_start_index, "_vnx_levels_packed", False):
+        return False
+    q = sampling_offsets.dtype
+    if attention_logits.dtype != q or reference_points.dtype != q:
+        return False
+    return (value.dtype == torch.float32 and q == torch.float32) or \
+        (value.dtype == torch.bfloat16 and q in (torch.float32, torch.bfloat16))
+
+
+def _fused_dims(value, sampling_offsets, reference_points):
+    B, S, M, D = value.shape
+    _, Lq, _, L, P, _ = sampling_offsets.shape
+    ref_dim = reference_points.shape[-1]
+    if reference_points.shape[0] == 0 or B % reference_points.shape[0] != 0:
+        raise RuntimeError("ms_deform_attn_fused: batch must be a multiple of the reference batch")
+    return B, S, M, D, L, Lq, P, ref_dim, B // reference_points.shape[0]
+
+
+def ms_deform_attn_fused_forward(value, spatial_shapes, level_start_index, sampling_offsets, attention_logits,
+                                 reference_points):
+    """value [B,S,M,32]; sampling_offsets [B,Lq,M,L,P,2], attention_logits [B,Lq,M,L*P] (the two
+    Linear outputs, pre-softmax); reference_points [B or B/T, Lq, L, 2|4]  ->  [B, Lq, M*32]"""
+    tensors = [("value", value), ("spatial_shapes", spatial_shapes), ("level_start_index", level_start_index),
+               ("sampling_offsets", sampling_offsets), ("attention_logits", attention_logits),
+               ("reference_points", reference_points)]
+    _check_inputs(tensors)
+    B, S, M, D, L, Lq, P, ref_dim, ref_div = _fused_dims(value, sampling_offsets, reference_points)
+    out = torch.empty((B, Lq, M * D), dtype=value.dtype, device=value.device)
+    with torch.cuda.device(value.device):
+        st = _lib.lib().vnx_msda_fused_forward(
+            _DT[value.dtype], _DT[sampling_offsets.dtype], value.data_ptr(), spatial_shapes.data_ptr(),
+            level_start_index.data_ptr(), sampling_offsets.data_ptr(), attention_logits.data_ptr(),
+            reference_points.data_ptr(), out.data_ptr(), B, S, M, D, L, Lq, P, ref_dim, ref_div,
+            torch.cuda.current_stream(value.device).cuda_stream)
+    _lib.check(st)
+    return out
+
+
+def ms_deform_attn_fused_backward(value, spatial_shapes, level_start_index, sampling_offsets, attention_logits,
+                                  reference_points, grad_output, want_reference_grad=False):
+    """-> [grad_value, grad_sampling_offsets, grad_attention_logits, grad_reference_points | None]"""
+    tensors = [("value", value), ("spatial_shapes", spatial_shapes), ("level_start_index", level_start_index),
+               ("sampling_offsets", sampling_offsets), ("attention_logits", attention_logits),
+               ("reference_points", reference_points), ("grad_output", grad_output)]
+    _check_inputs(tensors)
+    B, S, M, D, L, Lq, P, ref_dim, ref_div = _fused_dims(value, sampling_offsets, reference_points)
+    gv = torch.empty_like(value)
+    goff = torch.empty_like(sampling_offsets)
+    glog = torch.empty_like(attention_logits)
+    gref = torch.empty((B, Lq, L, 2), dtype=torch.float32, device=value.device) if want_reference_grad else None
+    lib = _lib.lib()
+    n = lib.vnx_msda_fused_backward_workspace_bytes(B, M, L, Lq, P)
+    ws = torch.empty(max(n, 1), dtype=torch.uint8, device=value.device)
+    with torch.cuda.device(value.device):
+        st = lib.vnx_msda_fused_backward(
+            _DT[value.dtype], _DT[sampling_offsets.dtype], value.data_ptr(), spatial_shapes.data_ptr(),
+            level_start_index.data_ptr(), sampling_offsets.data_ptr(), attention_logits.data_ptr(),
+            reference_points.data_ptr(), grad_output.data_ptr(), gv.data_ptr(), goff.data_ptr(), glog.data_ptr(),
+            gref.data_ptr() if gref is not None else None, B, S, M, D, L, Lq, P, ref_dim, ref_div,
+            ws.data_ptr(), n, torch.cuda.current_stream(value.device).cuda_stream)
+    _lib.check(st)
+    return [gv, goff, glog, gref]

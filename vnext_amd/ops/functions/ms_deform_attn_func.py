@@ -89,3 +89,31 @@ def check_flattened_length(spatial_shapes, length):
         assert sum(h * w for h, w in hw) == length
     else:
         assert (spatial_shapes[:, 0] * spatial_shapes[:, 1]).sum() == length
+
+
+class MSDeformAttnFusedFunction(Function):
+    """MSDeformAttn with the module's prologue (softmax + location arithmetic) inside the kernels:
+    apply(value, spatial_shapes, level_start_index, sampling_offsets, attention_logits,
+    reference_points) -> output.  See include/vnext_hip.h (vnx_msda_fused_*).  Gradients for
+    value, the two Linear outputs and -- 2-d, per-batch references only -- the reference points."""
+
+    @staticmethod
+    def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_offsets, attention_logits,
+                reference_points):
+        output = MSDA.ms_deform_attn_fused_forward(value, value_spatial_shapes, value_level_start_index,
+                                                   sampling_offsets, attention_logits, reference_points)
+        ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index, sampling_offsets,
+                              attention_logits, reference_points)
+        return output
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        value, shapes, level_start, offsets, logits, ref = ctx.saved_tensors
+        want_ref = ctx.needs_input_grad[5]
+        if want_ref and (ref.shape[-1] != 2 or ref.shape[0] != value.shape[0]):
+            raise RuntimeError("MSDeformAttnFusedFunction: reference-point gradients exist for 2-d, per-batch "
+                               "references only (4-d references are detached by every caller)")
+        gv, goff, glog, gref = MSDA.ms_deform_attn_fused_backward(
+            value, shapes, level_start, offsets, logits, ref, grad_output.contiguous(), want_reference_grad=want_ref)
+        return gv, None, None, goff, glog, (gref.to(ref.dtype) if gref is not None else None)

@@ -26,7 +26,8 @@ import torch.nn.functional as F
 from torch import nn
 from torch.nn.init import constant_, xavier_uniform_
 
-from ..functions import MSDeformAttnFunction, check_flattened_length
+from ... import msda_ext
+from ..functions import MSDeformAttnFunction, MSDeformAttnFusedFunction, check_flattened_length
 
 
 def _is_power_of_2(n):
@@ -71,6 +72,31 @@ class _MSDeformAttnBase(nn.Module):
         xavier_uniform_(self.output_proj.weight.data)
         constant_(self.output_proj.bias.data, 0.)
 
+    # -- fused prologue -----------------------------------------------------------------------
+    # When a caller does not read the sampling_locations / attention_weights the reference module
+    # returns (`return_samples = False`; the transformers in vnext_amd/models set it), the softmax and
+    # the location arithmetic run inside the sampling kernels (MSDeformAttnFusedFunction) and the two
+    # tensors are never materialised; the module then returns None in their place.
+    return_samples = True
+    fused_prologue = True
+
+    def _raw_offsets_and_logits(self, query):
+        lead = query.shape[:-1]
+        offsets = self.sampling_offsets(query).view(*lead, self.n_heads, self.n_levels, self.n_points, 2)
+        logits = self.attention_weights(query).view(*lead, self.n_heads, self.n_levels * self.n_points)
+        return offsets, logits
+
+    def _try_fused(self, value, offsets, logits, reference, spatial_shapes, level_start_index):
+        """value [B,S,M,D], offsets [B,Lq,M,L,P,2], logits [B,Lq,M,L*P], reference [B or B/T,Lq,L,2|4]
+        -> sampled [B, Lq, C] or None when the fused kernels do not take this case."""
+        if self.return_samples or not self.fused_prologue:
+            return None
+        reference = reference.to(offsets.dtype).contiguous()
+        if not msda_ext.fused_supported(value, offsets, logits, reference, level_start_index):
+            return None
+        return MSDeformAttnFusedFunction.apply(value.contiguous(), spatial_shapes, level_start_index,
+                                               offsets.contiguous(), logits.contiguous(), reference)
+
     # -- shared pieces ------------------------------------------------------------------------
     def _project_value(self, input_flatten, input_padding_mask):
         value = self.value_proj(input_flatten)
@@ -112,6 +138,12 @@ class MSDeformAttnIDOL(_MSDeformAttnBase):
         check_flattened_length(input_spatial_shapes, Len_in)
         value = self._project_value(input_flatten, input_padding_mask)
         value = value.view(N, Len_in, self.n_heads, self.d_model // self.n_heads)
+        if not self.return_samples and self.fused_prologue:
+            offsets, logits = self._raw_offsets_and_logits(query)
+            output = self._try_fused(value, offsets, logits, reference_points, input_spatial_shapes,
+                                     input_level_start_index)
+            if output is not None:
+                return self.output_proj(output), None, None
         sampling_offsets, attention_weights = self._offsets_and_weights(query)
         sampling_locations = self._locations(reference_points, sampling_offsets, input_spatial_shapes)
         output = MSDeformAttnFunction.apply(value, input_spatial_shapes, input_level_start_index,
@@ -156,10 +188,19 @@ class MSDeformAttnSeqFormer(_MSDeformAttnBase):
         check_flattened_length(input_spatial_shapes, Len_in)
         value = self._project_value(input_flatten, input_padding_mask)
         value = value.view(N, nf, Len_in, self.n_heads, self.d_model // self.n_heads)
-        sampling_offsets, attention_weights = self._offsets_and_weights(query)  # [N,nf,Lq,M,L,P(,2)]
         if reference_points.shape[-1] != 2:
             raise ValueError('Last dim of reference_points must be 2 or 4, but get {} instead.'.format(
                 reference_points.shape[-1]))
+        if self.fused_prologue:      # encode_forward never returned locations / weights
+            offsets, logits = self._raw_offsets_and_logits(query)
+            keep, self.return_samples = self.return_samples, False
+            sampled = self._try_fused(value.reshape(N * nf, *value.shape[2:]), offsets.reshape(N * nf, *offsets.shape[2:]),
+                                      logits.reshape(N * nf, *logits.shape[2:]), reference_points,
+                                      input_spatial_shapes, input_level_start_index)
+            self.return_samples = keep
+            if sampled is not None:
+                return self.output_proj(sampled.view(N, nf, Len_q, -1))
+        sampling_offsets, attention_weights = self._offsets_and_weights(query)  # [N,nf,Lq,M,L,P(,2)]
         # the encoder's reference points are shared by the frames: [N, Lq, L, 2] (SeqFormer :107-112)
         locations = self._locations(reference_points[:, None], sampling_offsets, input_spatial_shapes)
         sampled = self._apply_folded(value, locations, attention_weights, input_spatial_shapes,
@@ -172,6 +213,15 @@ class MSDeformAttnSeqFormer(_MSDeformAttnBase):
         check_flattened_length(input_spatial_shapes, Len_in)
         value = self._project_value(input_flatten, input_padding_mask)
         value = value.view(N, nf, Len_in, self.n_heads, self.d_model // self.n_heads)
+        if query_box.dim() == 4 and not self.return_samples and self.fused_prologue:
+            offsets, logits = self._raw_offsets_and_logits(query_box)          # per-frame box queries
+            sampled = self._try_fused(value.reshape(N * nf, *value.shape[2:]), offsets.reshape(N * nf, *offsets.shape[2:]),
+                                      logits.reshape(N * nf, *logits.shape[2:]),
+                                      reference_points.reshape(N * nf, *reference_points.shape[2:]),
+                                      input_spatial_shapes, input_level_start_index)
+            if sampled is not None:
+                sampled = sampled.view(N, nf, sampled.shape[1], -1)
+                return self.output_proj(sampled), self.output_proj_box(sampled), None, None
         sampling_offsets, attention_weights = self._offsets_and_weights(query_box)
         if query_box.dim() == 3:
             # first decoder layer: one set of offsets / weights per query, shared by the frames
