@@ -221,3 +221,21 @@ def test_graph_captured_training_trunk_matches_eager_gradients_on_gpu():
         for n in ge:
             scale = float(ge[n].abs().max()) + 1e-12
             assert float((gg[n] - ge[n]).abs().max()) <= 2e-3 * scale + 1e-7, n
+
+
+@pytest.mark.gpu
+def test_clip_matching_inference_on_gpu():
+    """CLIP_MATCHING: a 7-frame video as clips of 3 frames every 2 -- (query, class) results with a
+    mask per frame; one graph per clip shape."""
+    torch.manual_seed(6)
+    cfg = get_seqformer_cfg(**{"MODEL.DEVICE": "cuda:0", "MODEL.SeqFormer.CLIP_MATCHING": True,
+                               "MODEL.SeqFormer.CLIP_LENGTH": 3, "MODEL.SeqFormer.CLIP_STRIDE": 2, **TINY})
+    model = build_model(cfg).eval()
+    model.multi_cls = False
+    video = [{"image": T.synthetic_clips(1, 7, 96, 160, "cuda:0", seed=2, num_instances=0)[0]["image"],
+              "height": 100, "width": 170}]
+    res = model(video)
+    assert set(res) == {"image_size", "pred_scores", "pred_labels", "pred_masks"} and res["image_size"] == (100, 170)
+    assert len(res["pred_masks"]) == len(res["pred_scores"]) >= 10            # at least the first clip's 10 tracks
+    assert all(tuple(m.shape) == (7, 100, 170) and m.dtype == torch.bool for m in res["pred_masks"])
+    assert len(model._graphs) == 1

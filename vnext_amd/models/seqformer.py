@@ -227,6 +227,7 @@ class SeqFormer(nn.Module):
                                       num_frames=self.num_frames)
         self.deep_supervision = m.DEEP_SUPERVISION
         self.multi_cls, self.cls_thres = m.MULTI_CLS_ON, m.APPLY_CLS_THRES
+        self.clip_matching, self.clip_length, self.clip_stride = m.CLIP_MATCHING, m.CLIP_LENGTH, m.CLIP_STRIDE
         self.graph_inference = True     # replay the inference trunk from a hipGraph (per clip shape)
         self.graph_training = False     # capture the training trunk's forward and backward (opt-in)
         self._graphs = {}
@@ -444,45 +445,81 @@ class SeqFormer(nn.Module):
         graph.replay()
         return static_out
 
-    @torch.no_grad()
-    def inference(self, batched_inputs):
-        """Whole clip at once (seqformer.py:231-238, 351-410; CondInst_segm.inference,
-        segmentation_condInst.py:242-352): the 10 queries with the best class score, their masks
-        on every frame, every (query, class) pair above APPLY_CLS_THRES reported.  The reference
-        runs the mask head for all 300 queries of all 6 decoder layers and keeps 10 of the last."""
-        assert len(batched_inputs) == 1
-        clip = batched_inputs[0]
-        frames = [f.to(self.device, torch.float32) for f in clip["image"]]
-        same = all(f.shape == frames[0].shape for f in frames)
-        if same:
-            stack = torch.stack(frames)
-            trunk = self._clip_trunk_graphed if (self.graph_inference and stack.is_cuda) else self._clip_trunk
-            logits, ref_last, hs_last, feats = trunk(stack)
-            H, W = feats.shape[-2] * 8, feats.shape[-1] * 8
-        else:   # frames of different sizes: the general (eager, padded-batch) path
-            x, srcs, hs, memory, logits_all, _, refs = self._run(batched_inputs, want_refs=True)
-            logits, ref_last, hs_last, feats = logits_all[-1], refs[-1], hs[-1], self._mask_features(srcs, memory)
-            H, W = x.shape[-2:]
-        T = self.num_frames
-        ih, iw = clip["image"][0].shape[-2:]                                  # size fed to the network
+    def _top_instances(self, frames):
+        """Frames of one clip (any length; the reference sets `num_frames` to it, seqformer.py:231,249)
+        -> class probabilities [10, K] of the 10 best queries and their mask logits
+        [10, T, H/4, W/4] at a quarter of the padded input size (`inference_clip`, :302-326)."""
+        T = len(frames)
+        keep, self.num_frames = self.num_frames, T
+        try:
+            if all(f.shape == frames[0].shape for f in frames):
+                stack = torch.stack(frames)
+                trunk = self._clip_trunk_graphed if (self.graph_inference and stack.is_cuda) else self._clip_trunk
+                logits, ref_last, hs_last, feats = trunk(stack)
+            else:   # frames of different sizes: the general (eager, padded-batch) path
+                x, srcs, hs, memory, logits_all, _, refs = self._run([{"image": frames}], want_refs=True)
+                logits, ref_last, hs_last, feats = logits_all[-1], refs[-1], hs[-1], self._mask_features(srcs, memory)
+        finally:
+            self.num_frames = keep
+        ih, iw = frames[0].shape[-2:]                                         # size fed to the network
         prob = logits[0].sigmoid()                                            # [Q, classes]
         query = prob.max(1)[0].topk(min(10, prob.shape[0]))[1]
-        prob = prob[query]
         params = self.detr.controller(hs_last[0, query])                     # [10, 169]
         scale = torch.tensor([iw, ih], device=self.device, dtype=torch.float32)
         ref = ref_last[0][:, query, :2].sigmoid() * scale                     # [T, 10, 2] image pixels
         n = len(query)
         logits_m = dynamic_mask_with_coords(feats, ref.reshape(1, T * n, 2).float(),
                                             params.float().repeat(T, 1)[None], [n] * T, 8)
-        masks = logits_m.view(T, n, H // 4, W // 4).transpose(0, 1)          # [10, T, H/4, W/4]
-        masks = F.interpolate(masks, size=(H, W), mode="bilinear", align_corners=False).sigmoid()
+        return prob[query], logits_m.view(T, n, *logits_m.shape[-2:]).transpose(0, 1)
+
+    def _report(self, prob, mask_logits, image_size, out_size):
+        """class probabilities [n, K] + mask logits [n, T, H/4, W/4] -> the output dict
+        (`whole_video_inference` :351-410 == `clip_matching_postprocess` :328-349)."""
+        if prob.shape[0] == 0:
+            return {"image_size": out_size, "pred_scores": [], "pred_labels": [], "pred_masks": []}
+        h, w = mask_logits.shape[-2:]
+        masks = F.interpolate(mask_logits, size=(h * self.mask_stride, w * self.mask_stride), mode="bilinear",
+                              align_corners=False).sigmoid()
         if self.multi_cls:
             who, label = torch.where(prob > self.cls_thres)
             score = prob[who, label]
             masks = masks[who]
         else:
             score, label = prob.max(-1)
-        oh, ow = clip.get("height", ih), clip.get("width", iw)
-        masks = F.interpolate(masks[:, :, :ih, :iw], size=(oh, ow), mode="nearest") > 0.5
-        return {"image_size": (oh, ow), "pred_scores": score.tolist(), "pred_labels": label.tolist(),
+        masks = F.interpolate(masks[:, :, :image_size[0], :image_size[1]], size=out_size, mode="nearest") > 0.5
+        return {"image_size": out_size, "pred_scores": score.tolist(), "pred_labels": label.tolist(),
                 "pred_masks": [m for m in masks.cpu()]}
+
+    @torch.no_grad()
+    def inference(self, batched_inputs):
+        """One video (seqformer.py:227-264).  Default: the whole video as one clip -- the 10 queries
+        with the best class score, their masks on every frame, every (query, class) pair above
+        APPLY_CLS_THRES reported (the reference runs the mask head for all 300 queries of all 6 decoder
+        layers and keeps 10 of the last).  With CLIP_MATCHING: overlapping clips of CLIP_LENGTH frames
+        every CLIP_STRIDE, linked by mask sIoU (vnext_amd/models/clip_matching.py), tracks averaged."""
+        assert len(batched_inputs) == 1
+        video = batched_inputs[0]
+        frames = [f.to(self.device, torch.float32) for f in video["image"]]
+        ih, iw = frames[0].shape[-2:]
+        out_size = (video.get("height", ih), video.get("width", iw))
+        if not self.clip_matching:
+            prob, mask_logits = self._top_instances(frames)
+            return self._report(prob, mask_logits, (ih, iw), out_size)
+        from types import SimpleNamespace
+        from .clip_matching import Clips, Videos
+        n_frames, merged = len(frames), None
+        for start in range(0, n_frames, self.clip_stride):
+            end, last = start + self.clip_length, False
+            if end >= n_frames:
+                start, end, last = max(0, n_frames - self.clip_length), n_frames, True
+            idx = list(range(start, end))
+            prob, mask_logits = self._top_instances([frames[i] for i in idx])
+            if merged is None:
+                merged = Videos(self.clip_length, n_frames, self.num_classes, mask_logits.shape[-2:], self.device)
+            score, label = prob.max(-1)
+            merged.update(Clips(idx, SimpleNamespace(pred_classes=label, scores=score, cls_probs=prob,
+                                                     pred_masks=mask_logits)))
+            if last:
+                break
+        cls, mask_logits = merged.get_result()
+        return self._report(cls, mask_logits, (ih, iw), out_size)
