@@ -28,7 +28,7 @@ a = ap.parse_args()
 dev = "cuda:0"
 torch.manual_seed(0)
 if a.bf16:
-    torch.autocast("cuda", dtype=torch.bfloat16).__enter__()   # for the whole script
+    torch.autocast("cuda", dtype=torch.bfloat16, cache_enabled=not a.graph).__enter__()   # for the whole script
 H_, W_ = (int(v) for v in a.size.split("x"))
 
 
