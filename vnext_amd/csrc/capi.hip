@@ -120,6 +120,19 @@ static int check_common(const char* fn, int vdt, int ldt, const void* value,
 
 using namespace vnx;
 
+namespace vnx {
+int gv_units_min(const MsdaDims& d) {
+  const int v = g_kernel_variant;
+  if (v >= 200 && v < 300) return v - 200 < 1 ? 1 : (v - 200 > 16 ? 16 : v - 200);
+  // Tried with per-unit selection: enough units that each expects about one selection window of
+  // samples (10 per level at the encoder shape).  Slower on MI355X -- 353 vs 332 us per encoder-shape
+  // backward -- because a unit's chunk count is set by its DISTINCT queries (128 staged rows per
+  // chunk), and finer units multiply the (query, unit) incidences.
+  (void)d;
+  return 2;
+}
+}  // namespace vnx
+
 // ---- kernel-span stamps (development / bench aid, not in the public header) ------------------
 static unsigned long long* g_stamp_buf = nullptr;
 static long long g_stamp_words = 0, g_stamp_used = 0;

@@ -109,6 +109,25 @@ __device__ __forceinline__ void store_row4<f16_t>(f16_t* p, float4_t v) {
 // forward
 // -----------------------------------------------------------------------------
 // LP = levels*points (template value 0 = use the runtime value, no unrolling).
+// a / b for 0 <= a < 2^24, 0 < b < 2^24 without the integer-division sequence (one reciprocal,
+// one multiply, an exact remainder check)
+__device__ __forceinline__ int small_div(int a, int b) {
+  int q = int(float(a) * __frcp_rn(float(b)));
+  int r = a - q * b;
+  if (r < 0) { --q; r += b; }
+  if (r >= b) ++q;
+  return q;
+}
+// rows per unit of the grad_value kernels for a level of n pixels: the split of
+// msda_d32_gvrec.hip's level table (kGvRowsMax rows per unit at most, units_min units at least)
+constexpr int kGvRowsMax = 320;
+__device__ __forceinline__ int gv_rows_per_unit(int n, int units_min) {
+  int units = (n + kGvRowsMax - 1) / kGvRowsMax;
+  if (units < units_min) units = units_min;
+  if (units > n) units = n;
+  return units > 0 ? small_div(n + units - 1, units) : 1;
+}
+
 // -----------------------------------------------------------------------------
 // fused prologue
 // -----------------------------------------------------------------------------
@@ -506,7 +525,7 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
                     const TL* __restrict__ attn, const TV* __restrict__ grad_out,
                     float* __restrict__ gv, TL* __restrict__ grad_loc, TL* __restrict__ grad_attn,
                     MsdaDims d, int tiles_per_batch, uint4_t* __restrict__ sample_records,
-                    unsigned long long* stamps, FusedArgs fa) {
+                    uint32_t* __restrict__ sample_units, int units_min, unsigned long long* stamps, FusedArgs fa) {
   static_assert(!FUSED || (LP_T == 16 && !ATOMICS), "the fused prologue is built for L*P == 16, record-fed grad_value");
   stamp_begin(stamps);
   constexpr int D = 32;
@@ -573,9 +592,25 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
                          __float_as_uint(g4.y), __float_as_uint(a)};
       }
       // the geometry, kept for the grad_value kernel (msda_d32_gvrec.hip):
-      // [batch][head][level][query*points], 16 B per sample
-      if (sample_records != nullptr)
-        sample_records[((int64_t(b) * d.M + m) * d.L + l) * (int64_t(d.Lq) * d.P) + int64_t(q) * d.P + (p - l * d.P)] = record;
+      // [batch][head][level][query*points], 16 B per sample -- plus, in 4 B, the range of that
+      // kernel's units (pixel ranges of `rows per unit` rows) the sample's corners fall into
+      if (sample_records != nullptr) {
+        const int64_t ri = ((int64_t(b) * d.M + m) * d.L + l) * (int64_t(d.Lq) * d.P) + int64_t(q) * d.P + (p - l * d.P);
+        sample_records[ri] = record;
+        if (sample_units != nullptr) {
+          uint32_t uu = 0xffffffffu;
+          if (record.x != 0xffffffffu) {
+            const int h0 = int(record.x >> 16) - 1, w0 = int(record.x & 0xffffu) - 1;
+            const bool top = h0 >= 0, bot = h0 + 1 <= H - 1, lef = w0 >= 0, rig = w0 + 1 <= W - 1;
+            const int p00 = h0 * W + w0;
+            const int lo = (top && lef) ? p00 : (top && rig) ? p00 + 1 : (bot && lef) ? p00 + W : p00 + W + 1;
+            const int hi = (bot && rig) ? p00 + W + 1 : (bot && lef) ? p00 + W : (top && rig) ? p00 + 1 : p00;
+            const int rpu = gv_rows_per_unit(H * W, units_min);
+            uu = uint32_t(small_div(lo, rpu)) | (uint32_t(small_div(hi, rpu)) << 16);
+          }
+          sample_units[ri] = uu;
+        }
+      }
     }
     s_off[qi * (LP + 1) + p] = o4;
     s_geo[qi * (LP + 1) + p] = g4;
@@ -704,12 +739,16 @@ static int launch_bwd_cfg(const void* value, const int64_t* shapes, const int64_
     return VNX_ERR_UNSUPPORTED;
   }
   const size_t lds = size_t(WPB) * 3 * QPW * (LP + 1) * 16;
+  // the unit ranges sit behind the records in the workspace (gv_unit_ids_offset); only the P == 4
+  // grad_value kernel reads them
+  void* unit_ids = (records != nullptr && d.P == 4) ? (void*)((char*)records + gv_unit_ids_offset(d)) : nullptr;
+  const int units_min = gv_units_min(d);
 #define VNX_LAUNCH(LPT, AT)                                                                     \
   hipLaunchKernelGGL((msda_bwd_d32_kernel<TV, TL, QPW, WPB, LPT, AT>), dim3(uint32_t(blocks)),   \
                      dim3(64 * WPB), lds, stream, (const TV*)value, shapes, lsi, (const TL*)loc, \
                      (const TL*)attn, (const TV*)grad_out, (float*)gv, (TL*)grad_loc,            \
-                     (TL*)grad_attn, d, tiles_per_batch, (uint4_t*)records, take_stamp_region(kStampGradLoc, blocks), \
-                     FusedArgs{})
+                     (TL*)grad_attn, d, tiles_per_batch, (uint4_t*)records, (uint32_t*)unit_ids, units_min,       \
+                     take_stamp_region(kStampGradLoc, blocks), FusedArgs{})
   if (!atomics) { if (LP == 16) VNX_LAUNCH(16, false); else VNX_LAUNCH(0, false); }
   else { if (LP == 16) VNX_LAUNCH(16, true); else VNX_LAUNCH(0, true); }
 #undef VNX_LAUNCH
@@ -787,10 +826,12 @@ static int launch_bwd_fused_cfg(const void* value, const int64_t* shapes, const 
     return VNX_ERR_UNSUPPORTED;
   }
   const size_t lds = size_t(WPB) * 3 * QPW * 17 * 16;
+  void* unit_ids = (records != nullptr && d.P == 4) ? (void*)((char*)records + gv_unit_ids_offset(d)) : nullptr;
+  const int units_min = gv_units_min(d);
   hipLaunchKernelGGL((msda_bwd_d32_kernel<TV, TL, QPW, WPB, 16, false, true>), dim3(uint32_t(blocks)), dim3(64 * WPB),
                      lds, stream, (const TV*)value, shapes, lsi, (const TL*)raw_off, (const TL*)raw_logit,
                      (const TV*)grad_out, (float*)nullptr, (TL*)grad_off, (TL*)grad_logit, d, tiles_per_batch,
-                     (uint4_t*)records, take_stamp_region(kStampGradLoc, blocks), fa);
+                     (uint4_t*)records, (uint32_t*)unit_ids, units_min, take_stamp_region(kStampGradLoc, blocks), fa);
   return check_launch("msda_bwd_d32_fused");
 }
 

@@ -344,14 +344,282 @@ msda_bwd_gv_rec_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
   VNX_STAMP(12);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Per-unit sample selection (P == 4).
+//
+// The kernel above makes every unit of a level scan ALL of that level's samples, chunk by chunk,
+// although a fine-level unit receives a small share of them: 1/12 at the finest 360p level, and at
+// the encoder shape (Lq = S) 40 chunks are sorted for taps that four would hold.  The grad_loc
+// kernel therefore also leaves, per sample, the range of units its four corners touch
+// (`unit_lo | unit_hi << 16`, 0xffffffff = no taps; same [batch][head][level][query*points] layout),
+// and a unit first COMPACTS: it reads those 4-byte words for a window of 2048 samples (512
+// queries), keeps the samples whose range contains it (wave ballots + one 32-entry scan: their
+// ascending order is kept, so every sum stays deterministic), numbers the distinct queries among
+// them, and only then runs the sort / apply chunks -- over the kept samples, 128 distinct queries
+// (<= 512 samples) per chunk, staging only those queries' grad_out rows.
+constexpr int kWin = 2048;                        // samples per selection window
+constexpr int kWinQueries = kWin / 4;
+constexpr int kSelRounds = kWin / kThreads;       // 4
+constexpr int kSelParts = kSelRounds * kWaves;    // 32 (round, wave) pieces per window
+constexpr size_t kSelLdsBytes = size_t(kQcMax) * 128 + size_t(kThreads) * 32 + size_t(kRowsMax) * 12 + 16 +
+                                4 * kLevelsMax * 4 + size_t(kWin) * 4 + size_t(kWinQueries) * 2 +
+                                size_t(kSelParts) * 16 + 64;
+
+template <typename TV>
+__global__ void __launch_bounds__(kThreads, 3 * kWaves / 4)
+msda_bwd_gv_sel_kernel(const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
+                       const uint4_t* __restrict__ records, const uint32_t* __restrict__ unit_ids,
+                       const TV* __restrict__ grad_out, TV* __restrict__ grad_value, MsdaDims d, int units_min,
+                       int units_bound, int debug) {
+  constexpr int D = 32, P = 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float4_t* grows = reinterpret_cast<float4_t*>(smem);                       // [128][8] grad_out rows
+  uint2_t* list = reinterpret_cast<uint2_t*>(grows + kQcMax * 8);            // [4*threads] taps
+  uint32_t* cnt2 = reinterpret_cast<uint32_t*>(list + 4 * kThreads);         // [2][rows]
+  uint32_t* offs = cnt2 + 2 * kRowsMax;                                      // [rows]
+  uint32_t* alloc = offs + kRowsMax;                                         // [4]
+  int* meta = reinterpret_cast<int*>(alloc + 4);                             // [4*L]
+  uint16_t* sel_id = reinterpret_cast<uint16_t*>(meta + 4 * kLevelsMax);     // [kWin] window-relative sample
+  uint16_t* sel_qr = sel_id + kWin;                                          // [kWin] rank of its query
+  uint16_t* selq = sel_qr + kWin;                                            // [kWin/4] window-relative query
+  uint32_t* part_s = reinterpret_cast<uint32_t*>(selq + kWinQueries);        // [32] kept samples per piece
+  uint32_t* part_q = part_s + kSelParts;                                     // [32] new queries per piece
+  uint32_t* pre_s = part_q + kSelParts;                                      // [32] exclusive prefixes
+  uint32_t* pre_q = pre_s + kSelParts;
+  uint32_t* cs = pre_q + kSelParts;                                          // [6] chunk starts, [8..9] totals
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = blockIdx.x % d.M;
+  const int rest = blockIdx.x / d.M;
+  const int unit = rest % units_bound;
+  const int b = rest / units_bound;
+  VNX_STAMP(0);
+
+  if (tid < d.L) {
+    const int H = int(shapes[2 * tid]), W = int(shapes[2 * tid + 1]);
+    const int n = H * W;
+    int units = 0, rpu = 1;
+    if (n > 0) {
+      units = (n + kRowsMax - 1) / kRowsMax;
+      if (units < units_min) units = units_min;
+      if (units > n) units = n;
+      rpu = (n + units - 1) / units;
+      units = (n + rpu - 1) / rpu;
+    }
+    meta[4 * tid] = H; meta[4 * tid + 1] = W; meta[4 * tid + 2] = int(lsi[tid]);
+    meta[4 * tid + 3] = units | (rpu << 12);
+  }
+  for (int i = tid; i < 2 * kRowsMax; i += kThreads) cnt2[i] = 0;
+  if (tid == 0) alloc[0] = 0;
+  __syncthreads();
+
+  int lvl = -1, r0 = 0, r1 = 0, Hl = 0, Wl = 0, start = 0, u_lvl = 0;
+  {
+    int running = 0;
+    bool packed = true;
+    int u = unit;
+    for (int l = 0; l < d.L; ++l) {
+      const int H = meta[4 * l], W = meta[4 * l + 1], st = meta[4 * l + 2], ur = meta[4 * l + 3];
+      const int n = H * W, units = ur & 0xfff, rpu = ur >> 12;
+      packed = packed && (st == running);
+      running += n;
+      if (lvl < 0) {
+        if (u < units) {
+          lvl = l; Hl = H; Wl = W; start = st; u_lvl = u;
+          r0 = u * rpu;
+          r1 = r0 + rpu < n ? r0 + rpu : n;
+        } else {
+          u -= units;
+        }
+      }
+    }
+    packed = packed && (running == d.S);
+    if (!packed || lvl < 0) return;  // uniform over the workgroup
+  }
+  const int rows = r1 - r0;
+  constexpr int kRpg = (kRowsMax + kGroups - 1) / kGroups;
+  float4_t racc[kRpg];
+#pragma unroll
+  for (int k = 0; k < kRpg; ++k) racc[k] = float4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int n_samples = d.Lq * P;
+  const int64_t level_base = ((int64_t(b) * d.M + m) * d.L + lvl) * n_samples;
+  const uint4_t* my_recs = records + level_base;
+  const uint32_t* my_uids = unit_ids + level_base;
+  const TV* go_head = grad_out + (int64_t(b) * d.Lq * d.M + m) * D;
+  const int64_t q_stride = int64_t(d.M) * D;
+  const uint4_t none = {0xffffffffu, 0u, 0u, 0u};
+  const int g0 = tid, g1 = tid + kThreads;          // the two 16-B pieces of staged rows this thread moves
+  const int grp = tid >> 3, ch4 = tid & 7;
+  const int dr[4] = {0, 1, Wl, Wl + 1};
+  const uint32_t below = uint32_t(lane & 3);
+  int gchunk = 0;                                    // parity of the double-buffered row counters
+
+  for (int win0 = 0; win0 < n_samples; win0 += kWin) {
+    const int n_w = n_samples - win0 < kWin ? n_samples - win0 : kWin;
+    // ---- selection: which samples of this window touch my rows -----------------------------
+    unsigned long long bal[kSelRounds], balf[kSelRounds];
+    uint32_t hitbits = 0;
+#pragma unroll
+    for (int r = 0; r < kSelRounds; ++r) {
+      const int sidx = r * kThreads + tid;
+      const uint32_t v = sidx < n_w ? my_uids[win0 + sidx] : 0xffffffffu;
+      const bool hit = int(v & 0xffffu) <= u_lvl && u_lvl <= int(v >> 16) && v != 0xffffffffu;
+      const unsigned long long bh = __ballot(hit);
+      const uint32_t quad = uint32_t(bh >> (lane & ~3)) & 0xfu;       // my query's four samples
+      const bool first = hit && (quad & ((1u << below) - 1u)) == 0u;
+      const unsigned long long bf = __ballot(first);
+      bal[r] = bh; balf[r] = bf;
+      hitbits |= uint32_t(hit) << r | uint32_t(first) << (8 + r);
+      if (lane == 0) { part_s[r * kWaves + wave] = uint32_t(__popcll(bh)); part_q[r * kWaves + wave] = uint32_t(__popcll(bf)); }
+    }
+    __syncthreads();
+    if (tid < 64) {                                   // one wave scans the 32 (round, wave) pieces
+      const uint32_t ns = tid < kSelParts ? part_s[tid] : 0u, nq = tid < kSelParts ? part_q[tid] : 0u;
+      const uint32_t is = wave_inclusive_scan(ns), iq = wave_inclusive_scan(nq);
+      if (tid < kSelParts) { pre_s[tid] = is - ns; pre_q[tid] = iq - nq; }
+      if (tid == kSelParts - 1) { cs[8] = is; cs[9] = iq; }
+    }
+    __syncthreads();
+    const int n_sel = int(cs[8]), n_q = int(cs[9]);
+    if (n_sel == 0) continue;                         // uniform: nothing of this window lands here
+#pragma unroll
+    for (int r = 0; r < kSelRounds; ++r) {
+      if (hitbits & (1u << r)) {
+        const uint32_t lo_mask_lo = __builtin_amdgcn_mbcnt_lo(uint32_t(bal[r]), 0u);
+        const uint32_t pos = pre_s[r * kWaves + wave] + __builtin_amdgcn_mbcnt_hi(uint32_t(bal[r] >> 32), lo_mask_lo);
+        const uint32_t qlo = __builtin_amdgcn_mbcnt_lo(uint32_t(balf[r]), 0u);
+        const bool first = hitbits & (1u << (8 + r));
+        // firsts at lanes <= mine: those strictly below, plus my own flag
+        const uint32_t qr = pre_q[r * kWaves + wave] + __builtin_amdgcn_mbcnt_hi(uint32_t(balf[r] >> 32), qlo) +
+                            (first ? 1u : 0u) - 1u;
+        sel_id[pos] = uint16_t(r * kThreads + tid);
+        sel_qr[pos] = uint16_t(qr);
+        if (first) {
+          selq[qr] = uint16_t((r * kThreads + tid) >> 2);
+          if ((qr & uint32_t(kQcMax - 1)) == 0u) cs[qr / kQcMax] = pos;
+        }
+      }
+    }
+    const int n_chunks = (n_q + kQcMax - 1) / kQcMax;
+    if (tid == 0) cs[n_chunks] = uint32_t(n_sel);
+    __syncthreads();
+
+    // ---- chunks of <= 128 distinct queries over the kept samples -----------------------------
+    const int q_win = win0 >> 2;
+    uint4_t next = none;
+    int next_slot = 0;
+    float4_t pg0 = {0.f, 0.f, 0.f, 0.f}, pg1 = pg0;
+    auto prefetch = [&](int c) {
+      const int i = int(cs[c]) + tid;
+      if (i < int(cs[c + 1])) {
+        next = my_recs[win0 + int(sel_id[i])];
+        next_slot = int(sel_qr[i]) - c * kQcMax;
+      } else {
+        next = none;
+      }
+      const int qa = c * kQcMax + (g0 >> 3), qb = c * kQcMax + (g1 >> 3);
+      if (qa < n_q) pg0 = load4<TV>(go_head + int64_t(q_win + int(selq[qa])) * q_stride + (g0 & 7) * 4);
+      if (qb < n_q) pg1 = load4<TV>(go_head + int64_t(q_win + int(selq[qb])) * q_stride + (g1 & 7) * 4);
+    };
+    prefetch(0);
+    for (int c = 0; c < n_chunks; ++c, ++gchunk) {
+      uint32_t* cnt = cnt2 + (gchunk & 1) * kRowsMax;
+      uint32_t* cnt_next = cnt2 + ((gchunk + 1) & 1) * kRowsMax;
+      const uint4_t r = next;
+      const uint32_t slot = uint32_t(next_slot);
+      grows[g0] = pg0;
+      grows[g1] = pg1;
+      if (c + 1 < n_chunks) prefetch(c + 1);
+      uint32_t mask = 0;
+      int row00 = 0;
+      float wt[4] = {0.f, 0.f, 0.f, 0.f};
+      uint32_t rank[4] = {0u, 0u, 0u, 0u};
+      if (r.x != 0xffffffffu) {
+        const int h0 = int(r.x >> 16) - 1, w0 = int(r.x & 0xffffu) - 1;
+        const float lh = __uint_as_float(r.y), lw = __uint_as_float(r.z), a = __uint_as_float(r.w);
+        const float hh = 1.f - lh, hw = 1.f - lw;
+        const bool top = h0 >= 0, bot = h0 + 1 <= Hl - 1, lef = w0 >= 0, rig = w0 + 1 <= Wl - 1;
+        const int p00 = h0 * Wl + w0;
+        mask = (uint32_t(top && lef && p00 >= r0 && p00 < r1)) |
+               (uint32_t(top && rig && p00 + 1 >= r0 && p00 + 1 < r1) << 1) |
+               (uint32_t(bot && lef && p00 + Wl >= r0 && p00 + Wl < r1) << 2) |
+               (uint32_t(bot && rig && p00 + Wl + 1 >= r0 && p00 + Wl + 1 < r1) << 3);
+        row00 = p00 - r0;
+        wt[0] = a * (hh * hw); wt[1] = a * (hh * lw); wt[2] = a * (lh * hw); wt[3] = a * (lh * lw);
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (mask & (1u << t))
+          rank[t] = __hip_atomic_fetch_add(cnt + row00 + dr[t], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __syncthreads();
+      {
+        const uint32_t my_cnt = tid < rows ? cnt[tid] : 0u;
+        const uint32_t incl = wave_inclusive_scan(my_cnt);
+        const uint32_t wave_total = uint32_t(__builtin_amdgcn_readlane(int(incl), 63));
+        uint32_t base = 0;
+        if (lane == 0 && wave_total != 0)
+          base = __hip_atomic_fetch_add(alloc, wave_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        base = uint32_t(__builtin_amdgcn_readfirstlane(int(base)));
+        if (tid < rows) offs[tid] = base + incl - my_cnt;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (mask & (1u << t)) list[offs[row00 + dr[t]] + rank[t]] = uint2_t{slot, __float_as_uint(wt[t])};
+      __syncthreads();
+      if (tid == 0) alloc[0] = 0;
+      uint32_t rn[kRpg], ro[kRpg];
+#pragma unroll
+      for (int k = 0; k < kRpg; ++k) {
+        const int row = grp + k * kGroups;
+        rn[k] = row < rows ? cnt[row] : 0u;
+        ro[k] = row < rows ? offs[row] : 0u;
+        if (row < rows) cnt_next[row] = 0;
+      }
+      const float4_t* g4 = grows + ch4;
+#pragma unroll
+      for (int k = 0; k < kRpg; ++k) {
+        const uint32_t n = rn[k];
+        if (n == 0) continue;
+        const uint2_t* seg = list + ro[k];
+        float4_t a1 = {0.f, 0.f, 0.f, 0.f};
+        uint32_t i = 0;
+        for (; i + 2 <= n; i += 2) {
+          const uint2_t e0 = seg[i], e1 = seg[i + 1];
+          const float4_t x0 = g4[e0.x * 8], x1 = g4[e1.x * 8];
+          racc[k] += __uint_as_float(e0.y) * x0;
+          a1 += __uint_as_float(e1.y) * x1;
+        }
+        if (i < n) {
+          const uint2_t e = seg[i];
+          a1 += __uint_as_float(e.y) * g4[e.x * 8];
+        }
+        racc[k] += a1;
+      }
+      __syncthreads();
+    }
+  }
+
+  TV* out = grad_value + ((int64_t(b) * d.S + start + r0) * d.M + m) * D;
+#pragma unroll
+  for (int k = 0; k < kRpg; ++k) {
+    const int row = grp + k * kGroups;
+    if (row < rows) store4<TV>(out + int64_t(row) * d.M * D + ch4 * 4, racc[k]);
+  }
+  VNX_STAMP(12);
+}
+
 }  // namespace rec
 
 int msda_gvrec_units_bound(const MsdaDims& d, int units_min) {
   return d.L * (units_min + 1) + (d.S + rec::kRowsMax - 1) / rec::kRowsMax;
 }
 
-size_t msda_gvrec_record_bytes(const MsdaDims& d) {
-  return size_t(16) * size_t(d.B) * d.M * d.L * d.Lq * d.P;
+size_t msda_gvrec_record_bytes(const MsdaDims& d) {   // records + (aligned) unit ranges
+  return gv_unit_ids_offset(d) + size_t(4) * size_t(d.B) * d.M * d.L * d.Lq * d.P;
 }
 
 bool msda_d32_gvrec_supported(int vdt, int ldt, const MsdaDims& d) {
@@ -367,15 +635,24 @@ bool msda_d32_gvrec_supported(int vdt, int ldt, const MsdaDims& d) {
 template <typename TV>
 static int launch_gvrec(const int64_t* shapes, const int64_t* lsi, const void* records,
                         const void* grad_out, void* grad_value, const MsdaDims& d, int units_min,
-                        int debug, int reg_slab, hipStream_t stream) {
+                        int debug, int mode, hipStream_t stream) {
+  // mode 0: per-unit sample selection (P == 4); 3: register slab, every unit scans its level;
+  // 1: the LDS-slab form (variants 425 / 420 select the last two)
   const int units_bound = msda_gvrec_units_bound(d, units_min);
   const int64_t blocks = int64_t(d.B) * d.M * units_bound;
+  if (mode == 0 && d.P == 4 && d.L <= rec::kLevelsMax) {
+    const uint32_t* unit_ids = reinterpret_cast<const uint32_t*>((const char*)records + gv_unit_ids_offset(d));
+    hipLaunchKernelGGL((rec::msda_bwd_gv_sel_kernel<TV>), dim3(uint32_t(blocks)), dim3(rec::kThreads),
+                       rec::kSelLdsBytes, stream, shapes, lsi, (const rec::uint4_t*)records, unit_ids,
+                       (const TV*)grad_out, (TV*)grad_value, d, units_min, units_bound, debug);
+    return check_launch("msda_bwd_gv_sel");
+  }
 #define VNX_LAUNCH(PT, RS)                                                                             \
   hipLaunchKernelGGL((rec::msda_bwd_gv_rec_kernel<TV, PT, RS>), dim3(uint32_t(blocks)), dim3(rec::kThreads), \
                      rec::kLdsBytes - (RS ? size_t(rec::kRowsMax) * 128 : 0), stream, shapes, lsi,       \
                      (const rec::uint4_t*)records, (const TV*)grad_out, (TV*)grad_value, d, units_min,  \
                      units_bound, debug)
-  if (reg_slab == 3) { if (d.P == 4) VNX_LAUNCH(4, 3); else VNX_LAUNCH(0, 3); }
+  if (mode != 1) { if (d.P == 4) VNX_LAUNCH(4, 3); else VNX_LAUNCH(0, 3); }
   else { if (d.P == 4) VNX_LAUNCH(4, 0); else VNX_LAUNCH(0, 0); }
 #undef VNX_LAUNCH
   return check_launch("msda_bwd_gv_rec");
@@ -385,15 +662,12 @@ static int launch_gvrec(const int64_t* shapes, const int64_t* lsi, const void* r
 int msda_backward_gvrec_d32(int vdt, const int64_t* shapes, const int64_t* lsi, const void* records,
                             const void* grad_out, void* grad_value, MsdaDims d, int variant,
                             hipStream_t stream) {
-  // every level is split into at least this many units.  2: 19 units per (b, head) at 360p = 760
-  // workgroups <= the 768 resident at 3 per CU -- one round (4: 960 workgroups, 39.2 vs 37.3 us)
-  int units_min = 2;
-  if (variant >= 200 && variant < 300) units_min = variant - 200;
-  if (units_min < 1) units_min = 1;
-  if (units_min > 16) units_min = 16;
-  if (vdt == VNX_F32) return launch_gvrec<float>(shapes, lsi, records, grad_out, grad_value, d, units_min, (variant >= 408 && variant <= 412 ? variant - 407 : 0), (variant == 420 ? 0 : 3), stream);
-  if (vdt == VNX_BF16) return launch_gvrec<bf16_t>(shapes, lsi, records, grad_out, grad_value, d, units_min, (variant >= 408 && variant <= 412 ? variant - 407 : 0), (variant == 420 ? 0 : 3), stream);
-  if (vdt == VNX_F16) return launch_gvrec<f16_t>(shapes, lsi, records, grad_out, grad_value, d, units_min, (variant >= 408 && variant <= 412 ? variant - 407 : 0), (variant == 420 ? 0 : 3), stream);
+  // every level is split into at least gv_units_min(d) units (2: 19 units per (b, head) at 360p = 760
+  // workgroups <= the 768 resident at 3 per CU -- one round; 4: 960 workgroups, 39.2 vs 37.3 us)
+  const int units_min = gv_units_min(d);
+  if (vdt == VNX_F32) return launch_gvrec<float>(shapes, lsi, records, grad_out, grad_value, d, units_min, (variant >= 408 && variant <= 412 ? variant - 407 : 0), (variant == 420 ? 1 : variant == 425 ? 3 : 0), stream);
+  if (vdt == VNX_BF16) return launch_gvrec<bf16_t>(shapes, lsi, records, grad_out, grad_value, d, units_min, (variant >= 408 && variant <= 412 ? variant - 407 : 0), (variant == 420 ? 1 : variant == 425 ? 3 : 0), stream);
+  if (vdt == VNX_F16) return launch_gvrec<f16_t>(shapes, lsi, records, grad_out, grad_value, d, units_min, (variant >= 408 && variant <= 412 ? variant - 407 : 0), (variant == 420 ? 1 : variant == 425 ? 3 : 0), stream);
   set_error("msda_backward_gvrec_d32: unsupported dtype %d", vdt);
   return VNX_ERR_INVALID_ARGUMENT;
 }

@@ -83,6 +83,17 @@ struct MsdaDims {
   int B, S, M, D, L, Lq, P;
 };
 
+// grad_value units: every level is split into at least this many.  Shared by the grad_loc kernel
+// (which tags every sample with the units it touches) and the grad_value kernels.  2 (variants
+// 200+x: x).
+int gv_units_min(const MsdaDims& d);
+// Backward workspace of the record-fed path: [16-B sample records | 256-B aligned | 4-B unit ranges]
+inline size_t gv_unit_ids_offset(const MsdaDims& d) {
+  const size_t n = size_t(d.B) * d.M * d.L * d.Lq * d.P;
+  return (16 * n + 255) & ~size_t(255);
+}
+
+
 inline int elem_size(int dtype) {
   switch (dtype) {
     case VNX_F32: return 4;
