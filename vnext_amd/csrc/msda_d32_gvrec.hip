@@ -184,8 +184,7 @@ msda_bwd_gv_rec_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
 
   const int n_samples = d.Lq * P;
   const int qc_ = kThreads / P < kQcMax ? kThreads / P : kQcMax;
-  int n_chunks = (d.Lq + qc_ - 1) / qc_;
-  if (debug == 2 || (debug == 3 && lvl == 0) || (debug == 4 && lvl <= 1)) n_chunks = 1;  // timing experiments only (wrong results)
+  const int n_chunks = (d.Lq + qc_ - 1) / qc_;
   const uint4_t* my_recs = records + ((int64_t(b) * d.M + m) * d.L + lvl) * n_samples;
   const TV* go_head = grad_out + (int64_t(b) * d.Lq * d.M + m) * D;
   const int64_t q_stride = int64_t(d.M) * D;
@@ -665,9 +664,9 @@ int msda_backward_gvrec_d32(int vdt, const int64_t* shapes, const int64_t* lsi, 
   // every level is split into at least gv_units_min(d) units (2: 19 units per (b, head) at 360p = 760
   // workgroups <= the 768 resident at 3 per CU -- one round; 4: 960 workgroups, 39.2 vs 37.3 us)
   const int units_min = gv_units_min(d);
-  if (vdt == VNX_F32) return launch_gvrec<float>(shapes, lsi, records, grad_out, grad_value, d, units_min, (variant >= 408 && variant <= 412 ? variant - 407 : 0), (variant == 420 ? 1 : variant == 425 ? 3 : 0), stream);
-  if (vdt == VNX_BF16) return launch_gvrec<bf16_t>(shapes, lsi, records, grad_out, grad_value, d, units_min, (variant >= 408 && variant <= 412 ? variant - 407 : 0), (variant == 420 ? 1 : variant == 425 ? 3 : 0), stream);
-  if (vdt == VNX_F16) return launch_gvrec<f16_t>(shapes, lsi, records, grad_out, grad_value, d, units_min, (variant >= 408 && variant <= 412 ? variant - 407 : 0), (variant == 420 ? 1 : variant == 425 ? 3 : 0), stream);
+  if (vdt == VNX_F32) return launch_gvrec<float>(shapes, lsi, records, grad_out, grad_value, d, units_min, (variant == 408 ? 1 : variant == 412 ? 5 : 0), (variant == 420 ? 1 : variant == 425 ? 3 : 0), stream);
+  if (vdt == VNX_BF16) return launch_gvrec<bf16_t>(shapes, lsi, records, grad_out, grad_value, d, units_min, (variant == 408 ? 1 : variant == 412 ? 5 : 0), (variant == 420 ? 1 : variant == 425 ? 3 : 0), stream);
+  if (vdt == VNX_F16) return launch_gvrec<f16_t>(shapes, lsi, records, grad_out, grad_value, d, units_min, (variant == 408 ? 1 : variant == 412 ? 5 : 0), (variant == 420 ? 1 : variant == 425 ? 3 : 0), stream);
   set_error("msda_backward_gvrec_d32: unsupported dtype %d", vdt);
   return VNX_ERR_INVALID_ARGUMENT;
 }

@@ -33,7 +33,7 @@ from ..registry import META_ARCH_REGISTRY
 from .criterion import box_cxcywh_to_xyxy, box_xyxy_to_cxcywh
 from .idol_criterion import IDOLCriterion, OTAMatcher, reid_terms, select_pos_neg_masks
 from .idol_transformer import DeformableTransformer
-from .seqformer import MLP, DeformableDETR, MaskHeadSmallConv, ResNet50Trunk, sine_position
+from .seqformer import MLP, DeformableDETR, MaskHeadSmallConv, ResNet50Trunk, scale_tensor, sine_position
 from .seqformer_transformer import inverse_sigmoid
 from .tracker import IDOL_Tracker
 
@@ -168,7 +168,7 @@ class IDOL(nn.Module):
         for video in batched_inputs:
             for fr in video["instances"]:
                 h, w = field(fr, "image_size")
-                scale = torch.as_tensor([w, h, w, h], dtype=torch.float32, device=self.device)
+                scale = scale_tensor([w, h, w, h], self.device)
                 ids = field(fr, "gt_ids").to(self.device)
                 per_frame.append({"labels": field(fr, "gt_classes").to(self.device),
                                   "boxes": box_xyxy_to_cxcywh(field(fr, "gt_boxes").to(self.device, torch.float32) / scale),
@@ -196,8 +196,8 @@ class IDOL(nn.Module):
         params, points, image = [], [], []
         for l in range(Ld):
             for i, (sel, _) in enumerate(indices_list[l]):
-                q = torch.nonzero(sel).flatten().to(self.device)
-                scale = torch.tensor([sizes[i][1], sizes[i][0]], device=self.device, dtype=torch.float32)
+                q = torch.nonzero(sel).flatten().to(self.device, non_blocking=True)
+                scale = scale_tensor([sizes[i][1], sizes[i][0]], self.device)
                 params.append(self.detr.controller(hs[l, 2 * i, q]))
                 points.append(refs[l][2 * i, q, :2].sigmoid() * scale)
                 image.append(torch.full((len(q),), i, device=self.device, dtype=torch.int32))
@@ -304,7 +304,7 @@ class IDOL(nn.Module):
         query = torch.from_numpy(np.concatenate(picks)).to(self.device)
         sel_hs = hs_last[frame_of, query]
         ih, iw = frames[0].shape[-2:]
-        scale = torch.tensor([iw, ih], device=self.device, dtype=torch.float32)
+        scale = scale_tensor([iw, ih], self.device)
         points = ref_last[frame_of, query, :2].sigmoid() * scale              # = inter_references[-2][..., :2]
         masks = dynamic_mask_head(feats, points.float(), self.detr.controller(sel_hs).float(),
                                   frame_of.to(torch.int32), 8)

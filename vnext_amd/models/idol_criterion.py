@@ -30,6 +30,18 @@ import torch.nn.functional as F
 from .criterion import box_cxcywh_to_xyxy, dice_loss, giou_loss, pairwise_giou, sigmoid_focal_loss
 
 
+class _one_thread:
+    """Context: ATen intra-op threads = 1 while the tiny host-side matching matrices are processed."""
+
+    def __enter__(self):
+        self.n = torch.get_num_threads()
+        torch.set_num_threads(1)
+
+    def __exit__(self, *exc):
+        torch.set_num_threads(self.n)
+        return False
+
+
 def _pairwise_iou(a, b):
     a, b = a[:, None, :], b[None, :, :]
     wh = (torch.minimum(a[..., 2:], b[..., 2:]) - torch.maximum(a[..., :2], b[..., :2])).clamp(min=0)
@@ -94,6 +106,8 @@ class OTAMatcher(nn.Module):
 
     @staticmethod
     def _one(boxes, prob, target, nf):
+        """Host tensors in, host tensors out.  The matrices are [300, n_gt]: run the ATen CPU ops on
+        one thread (their default fan-out over all host cores costs ~1 ms per op on a 256-core box)."""
         n = len(target["labels"])
         if n == 0:
             return (torch.zeros(prob.shape[0], dtype=torch.bool), torch.zeros(0, dtype=torch.int64)), \
@@ -111,7 +125,8 @@ class OTAMatcher(nn.Module):
         prob = outputs["pred_logits"].detach().sigmoid().cpu()
         boxes = outputs["pred_boxes"].detach().cpu()
         tg = [{k: t[k].cpu() for k in ("labels", "boxes")} for t in targets]
-        res = [self._one(boxes[i], prob[i], tg[i], nf) for i in range(len(tg))]
+        with _one_thread():
+            res = [self._one(boxes[i], prob[i], tg[i], nf) for i in range(len(tg))]
         return [r[0] for r in res], [r[1] for r in res]
 
     @torch.no_grad()
@@ -121,7 +136,8 @@ class OTAMatcher(nn.Module):
         prob = logits.detach().sigmoid().cpu()
         boxes = boxes.detach().cpu()
         tg = [{k: t[k].cpu() for k in ("labels", "boxes")} for t in targets]
-        out = [[self._one(boxes[l, i], prob[l, i], tg[i], nf) for i in range(len(tg))] for l in range(prob.shape[0])]
+        with _one_thread():
+            out = [[self._one(boxes[l, i], prob[l, i], tg[i], nf) for i in range(len(tg))] for l in range(prob.shape[0])]
         return [[r[0] for r in layer] for layer in out], [r[1] for r in out[-1]]
 
 
@@ -136,6 +152,8 @@ def select_pos_neg_masks(ref_boxes, ref_prob, ref_targets, rng=_random):
     `rng.sample` (host RNG, same call sequence as the reference)."""
     out = []
     ref_boxes, ref_prob = ref_boxes.detach().cpu(), ref_prob.detach().cpu()
+    threads = _one_thread()
+    threads.__enter__()
     for i, t in enumerate(ref_targets):
         valid = t["valid"].cpu().bool()
         Q = ref_boxes.shape[1]
@@ -157,6 +175,7 @@ def select_pos_neg_masks(ref_boxes, ref_prob, ref_targets, rng=_random):
                 aux[:, c] = pos[:, c]
                 aux[neg_rows[picked], c] = True
         out.append((inst, pos, neg, aux))
+    threads.__exit__()
     return out
 
 
@@ -169,25 +188,33 @@ class IDOLCriterion(nn.Module):
         self.num_classes, self.matcher, self.weight_dict, self.losses = num_classes, matcher, weight_dict, losses
         self.focal_alpha, self.mask_out_stride, self.num_frames = focal_alpha, mask_out_stride, num_frames
 
+    @staticmethod
+    def _on_device(indices, device):
+        """[(selected [Q] bool, gt idx)] on the host -> [(query idx, gt idx)] on the device.  Indexing a
+        device tensor with a boolean mask makes the host wait for the device (the output size is data);
+        with index tensors built on the host it does not."""
+        return [(torch.nonzero(sel).flatten().to(device, non_blocking=True), gt.to(device, non_blocking=True))
+                for sel, gt in indices]
+
     def loss_labels(self, outputs, targets, ref_targets, indices, num_boxes, log=True):
         logits = outputs["pred_logits"]
         onehot = torch.zeros_like(logits)
         count = 0
-        for i, (sel, gt) in enumerate(indices):
+        for i, (q, gt) in enumerate(self._on_device(indices, logits.device)):
             if len(gt):
-                q = torch.nonzero(sel).flatten().to(logits.device)
-                onehot[i, q, targets[i]["labels"].to(logits.device)[gt.to(logits.device)]] = 1
+                onehot[i, q, targets[i]["labels"].to(logits.device)[gt]] = 1
                 count += len(gt)
         return {"loss_ce": sigmoid_focal_loss(logits, onehot, max(count, 1), self.focal_alpha, 2.0) * logits.shape[1]}
 
     def loss_boxes(self, outputs, targets, ref_targets, indices, num_boxes):
         boxes = outputs["pred_boxes"]
-        pred = [boxes[i][sel.to(boxes.device)] for i, (sel, gt) in enumerate(indices) if len(gt)]
+        dev = self._on_device(indices, boxes.device)
+        pred = [boxes[i][q] for i, (q, gt) in enumerate(dev) if len(gt)]
         if not pred:
             zero = boxes.sum() * 0
             return {"loss_bbox": zero, "loss_giou": zero}
         pred = torch.cat(pred)
-        tgt = torch.cat([targets[i]["boxes"].to(boxes)[gt.to(boxes.device)] for i, (_, gt) in enumerate(indices) if len(gt)])
+        tgt = torch.cat([targets[i]["boxes"].to(boxes)[gt] for i, (_, gt) in enumerate(dev) if len(gt)])
         n = pred.shape[0]
         return {"loss_bbox": F.l1_loss(pred, tgt, reduction="none").sum() / n,
                 "loss_giou": giou_loss(box_cxcywh_to_xyxy(pred), box_cxcywh_to_xyxy(tgt)).sum() / n}

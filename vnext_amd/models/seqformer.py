@@ -32,6 +32,22 @@ from ..registry import META_ARCH_REGISTRY
 from .seqformer_transformer import DeformableTransformer, inverse_sigmoid
 
 
+_SCALES = {}
+
+
+def scale_tensor(values, device):
+    """A small constant tensor (image width / height factors) on `device`, built once per value
+    and reused: `torch.tensor([...], device=cuda)` is a synchronous pageable host->device copy
+    (~0.4 ms on this box) and the training step made ~20 of them."""
+    key = (tuple(float(v) for v in values), str(device))
+    t = _SCALES.get(key)
+    if t is None:
+        if len(_SCALES) > 256:
+            _SCALES.clear()
+        t = _SCALES[key] = torch.tensor(key[0], dtype=torch.float32, device=device)
+    return t
+
+
 class FrozenBatchNorm2d(nn.Module):
     """models/backbone.py:27-64: fixed statistics and affine parameters."""
 
@@ -312,18 +328,18 @@ class SeqFormer(nn.Module):
                 targets.append({"labels": torch.zeros(0, dtype=torch.int64, device=self.device),
                                 "boxes": torch.zeros(0, T, 4, device=self.device),
                                 "masks": torch.zeros(0, T, h, w, dtype=torch.bool, device=self.device),
-                                "size": torch.as_tensor([h, w], dtype=torch.long, device=self.device)})
+                                "size": torch.as_tensor([h, w], dtype=torch.long)})     # host: only the host reads it
                 continue
             boxes, masks, classes = [], [], []
             for fr in frames:
                 h, w = field(fr, "image_size")
-                scale = torch.as_tensor([w, h, w, h], dtype=torch.float32, device=self.device)
+                scale = scale_tensor([w, h, w, h], self.device)
                 boxes.append(box_xyxy_to_cxcywh(field(fr, "gt_boxes").to(self.device, torch.float32) / scale))
                 masks.append(field(fr, "gt_masks").to(self.device))
                 classes.append(field(fr, "gt_classes").to(self.device) * (field(fr, "gt_ids").to(self.device) != -1))
             targets.append({"labels": torch.stack(classes, 0).max(0)[0], "boxes": torch.stack(boxes, 1),
                             "masks": torch.stack(masks, 1),
-                            "size": torch.as_tensor([h, w], dtype=torch.long, device=self.device)})
+                            "size": torch.as_tensor([h, w], dtype=torch.long)})
         return targets
 
     def _mask_features(self, srcs, memory):
@@ -372,7 +388,7 @@ class SeqFormer(nn.Module):
             for i, (q, _) in enumerate(indices_list[l]):
                 q = q.to(self.device)
                 p = ctl(hs[l][i, q])                                              # [n, 169]
-                scale = targets[i]["size"].flip(0).to(torch.float32)              # (w, h) of the frames
+                scale = scale_tensor(targets[i]["size"].flip(0).tolist(), self.device)   # (w, h) of the frames
                 pt = refs[l][i][:, q, :2].sigmoid() * scale                       # [T, n, 2] image pixels
                 params.append(p[:, None].expand(-1, T, -1))
                 points.append(pt.transpose(0, 1))
@@ -465,7 +481,7 @@ class SeqFormer(nn.Module):
         prob = logits[0].sigmoid()                                            # [Q, classes]
         query = prob.max(1)[0].topk(min(10, prob.shape[0]))[1]
         params = self.detr.controller(hs_last[0, query])                     # [10, 169]
-        scale = torch.tensor([iw, ih], device=self.device, dtype=torch.float32)
+        scale = scale_tensor([iw, ih], self.device)
         ref = ref_last[0][:, query, :2].sigmoid() * scale                     # [T, 10, 2] image pixels
         n = len(query)
         logits_m = dynamic_mask_with_coords(feats, ref.reshape(1, T * n, 2).float(),

@@ -91,7 +91,12 @@ class _MSDeformAttnBase(nn.Module):
         -> sampled [B, Lq, C] or None when the fused kernels do not take this case."""
         if self.return_samples or not self.fused_prologue:
             return None
-        reference = reference.to(offsets.dtype).contiguous()
+        if reference.dtype != offsets.dtype:
+            # autocast: the Linears emit bf16, reference points stay fp32.  Promote the (small) query-side
+            # tensors rather than rounding positions to 8 mantissa bits; the kernels take a 16-bit value
+            # with fp32 offsets / logits / references.
+            offsets, logits, reference = offsets.float(), logits.float(), reference.float()
+        reference = reference.contiguous()
         if not msda_ext.fused_supported(value, offsets, logits, reference, level_start_index):
             return None
         return MSDeformAttnFusedFunction.apply(value.contiguous(), spatial_shapes, level_start_index,
