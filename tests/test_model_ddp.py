@@ -220,7 +220,8 @@ def test_graph_captured_training_trunk_matches_eager_gradients_on_gpu():
         assert set(ge) == set(gg)
         for n in ge:
             scale = float(ge[n].abs().max()) + 1e-12
-            assert float((gg[n] - ge[n]).abs().max()) <= 2e-3 * scale + 1e-7, n
+            # MIOpen's weight-gradient kernels and the mask head's atomics sum in run-dependent order
+            assert float((gg[n] - ge[n]).abs().max()) <= 1e-2 * scale + 1e-7, n
 
 
 @pytest.mark.gpu
@@ -239,3 +240,18 @@ def test_clip_matching_inference_on_gpu():
     assert len(res["pred_masks"]) == len(res["pred_scores"]) >= 10            # at least the first clip's 10 tracks
     assert all(tuple(m.shape) == (7, 100, 170) and m.dtype == torch.bool for m in res["pred_masks"])
     assert len(model._graphs) == 1
+
+
+def test_frozen_batchnorm_folded_into_the_convolution():
+    from vnext_amd.models.seqformer import FrozenBatchNorm2d, conv_bn
+    torch.manual_seed(0)
+    conv = torch.nn.Conv2d(5, 7, 3, 2, 1, bias=False)
+    bn = FrozenBatchNorm2d(7)
+    bn.weight.copy_(torch.rand(7) + 0.5); bn.bias.copy_(torch.randn(7))
+    bn.running_mean.copy_(torch.randn(7)); bn.running_var.copy_(torch.rand(7) + 0.2)
+    x = torch.randn(2, 5, 9, 11)
+    np.testing.assert_allclose(conv_bn(x, conv, bn).detach().numpy(), bn(conv(x)).detach().numpy(), rtol=1e-4, atol=1e-5)
+    bn.running_var.mul_(2.0)                      # a changed buffer invalidates the cached constants
+    np.testing.assert_allclose(conv_bn(x, conv, bn).detach().numpy(), bn(conv(x)).detach().numpy(), rtol=1e-4, atol=1e-5)
+    conv_bn(x, conv, bn).sum().backward()
+    assert conv.weight.grad is not None

@@ -90,7 +90,7 @@ class IDOL(nn.Module):
             dim_feedforward=m.DIM_FEEDFORWARD, dropout=m.DROPOUT, activation="relu", return_intermediate_dec=True,
             num_frames=self.num_frames, num_feature_levels=m.NUM_FEATURE_LEVELS, dec_n_points=m.DEC_N_POINTS,
             enc_n_points=m.ENC_N_POINTS)
-        detr = DeformableDETR(ResNet50Trunk(), transformer, m.NUM_CLASSES, self.num_frames, m.NUM_OBJECT_QUERIES,
+        detr = DeformableDETR(ResNet50Trunk().freeze(2), transformer, m.NUM_CLASSES, self.num_frames, m.NUM_OBJECT_QUERIES,
                               m.NUM_FEATURE_LEVELS, hidden)
         self.detr = CondInstSegmIDOL(detr, hidden)
         weights = {"loss_ce": m.CLASS_WEIGHT, "loss_bbox": m.L1_WEIGHT, "loss_giou": m.GIOU_WEIGHT,

@@ -49,7 +49,10 @@ def scale_tensor(values, device):
 
 
 class FrozenBatchNorm2d(nn.Module):
-    """models/backbone.py:27-64: fixed statistics and affine parameters."""
+    """models/backbone.py:27-64: fixed statistics and affine parameters.  As a standalone module it
+    is `x * scale + shift`; inside the trunk below the two constants are folded into the preceding
+    convolution instead (`folded()`), which removes two full-resolution elementwise passes per
+    convolution from the forward and one from the backward."""
 
     def __init__(self, n):
         super().__init__()
@@ -57,11 +60,27 @@ class FrozenBatchNorm2d(nn.Module):
         self.register_buffer("bias", torch.zeros(n))
         self.register_buffer("running_mean", torch.zeros(n))
         self.register_buffer("running_var", torch.ones(n))
+        self._fold = None
+
+    def folded(self):
+        """(scale [C], shift [C]), recomputed only when a buffer changed (load_state_dict, .to())."""
+        key = tuple((t.data_ptr(), t._version) for t in (self.weight, self.bias, self.running_mean, self.running_var))
+        if self._fold is None or self._fold[0] != key:
+            with torch.no_grad():
+                scale = self.weight * (self.running_var + 1e-5).rsqrt()
+                self._fold = (key, scale, self.bias - self.running_mean * scale)
+        return self._fold[1], self._fold[2]
 
     def forward(self, x):
-        scale = (self.weight * (self.running_var + 1e-5).rsqrt()).reshape(1, -1, 1, 1)
-        bias = (self.bias - self.running_mean * scale.flatten()).reshape(1, -1, 1, 1)
-        return x * scale + bias
+        scale, shift = self.folded()
+        return x * scale.reshape(1, -1, 1, 1) + shift.reshape(1, -1, 1, 1)
+
+
+def conv_bn(x, conv, bn):
+    """bn(conv(x)) for a frozen bn: one convolution with scaled filters and the shift as its bias
+    (the filters stay trainable: the scaling is a differentiable [Cout,1,1,1] multiply on the weights)."""
+    scale, shift = bn.folded()
+    return F.conv2d(x, conv.weight * scale.reshape(-1, 1, 1, 1), shift, conv.stride, conv.padding)
 
 
 class _Bottleneck(nn.Module):
@@ -75,10 +94,10 @@ class _Bottleneck(nn.Module):
             self.down = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), FrozenBatchNorm2d(cout))
 
     def forward(self, x):
-        y = F.relu(self.bn1(self.conv1(x)))
-        y = F.relu(self.bn2(self.conv2(y)))
-        y = self.bn3(self.conv3(y))
-        return F.relu(y + (x if self.down is None else self.down(x)))
+        y = F.relu(conv_bn(x, self.conv1, self.bn1))
+        y = F.relu(conv_bn(y, self.conv2, self.bn2))
+        y = conv_bn(y, self.conv3, self.bn3)
+        return F.relu(y + (x if self.down is None else conv_bn(x, self.down[0], self.down[1])))
 
 
 class ResNet50Trunk(nn.Module):
@@ -98,8 +117,18 @@ class ResNet50Trunk(nn.Module):
         self.res4 = stage(512, 256, 1024, 6, 2)
         self.res5 = stage(1024, 512, 2048, 3, 2)
 
+    def freeze(self, freeze_at=2):
+        """detectron2's MODEL.BACKBONE.FREEZE_AT (default 2, kept by the reference's configs): the
+        stem and res2 are not trained, so the backward stops at res3's input."""
+        stages = [self.stem, self.res2, self.res3, self.res4, self.res5]
+        for stage in stages[:freeze_at]:
+            for p in stage.parameters():
+                p.requires_grad_(False)
+        return self
+
     def forward(self, x):
-        x = self.res2(self.stem(x))
+        x = F.max_pool2d(F.relu(conv_bn(x, self.stem[0], self.stem[1])), 3, 2, 1)
+        x = self.res2(x)
         c3 = self.res3(x)
         c4 = self.res4(c3)
         return [c3, c4, self.res5(c4)]
@@ -229,7 +258,7 @@ class SeqFormer(nn.Module):
             dim_feedforward=m.DIM_FEEDFORWARD, dropout=m.DROPOUT, activation="relu", return_intermediate_dec=True,
             num_frames=self.num_frames, num_feature_levels=m.NUM_FEATURE_LEVELS, dec_n_points=m.DEC_N_POINTS,
             enc_n_points=m.ENC_N_POINTS)
-        detr = DeformableDETR(ResNet50Trunk(), transformer, m.NUM_CLASSES, self.num_frames, m.NUM_OBJECT_QUERIES,
+        detr = DeformableDETR(ResNet50Trunk().freeze(2), transformer, m.NUM_CLASSES, self.num_frames, m.NUM_OBJECT_QUERIES,
                               m.NUM_FEATURE_LEVELS, hidden)
         self.detr = CondInstSegm(detr, hidden)
         weights = {"loss_ce": m.CLASS_WEIGHT, "loss_bbox": m.L1_WEIGHT, "loss_giou": m.GIOU_WEIGHT,
