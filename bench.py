@@ -137,10 +137,11 @@ def event_time_us(graph, launches, reps=15):
     return ts[len(ts) // 2]
 
 
-def model_step_leg(rank, local_rank, world, device, steps, warmup=3):
+def model_step_leg(rank, local_rank, world, device, steps, warmup=3, clips_per_rank=2):
     """clips/s of the SeqFormer-R50 training step (BASELINE config: T=5 synthetic 360p clip, 300
-    queries): forward + backward + RCCL gradient all-reduce + clipped AdamW step, one clip per
-    rank (weak scaling).  The loss is the reference's objective (clip-level Hungarian matching,
+    queries): forward + backward + RCCL gradient all-reduce + clipped AdamW step, two clips per
+    rank -- the reference's per-GPU batch (IMS_PER_BATCH 16 on 8 GPUs, configs/base_ytvis.yaml:18) --
+    weak scaling.  The loss is the reference's objective (clip-level Hungarian matching,
     focal / L1 / GIoU / mask focal + dice over the 6 decoder layers, vnext_amd/models/criterion.py)
     on 4 synthetic tracks per clip, with the fused dynamic mask head forward and backward."""
     import torch.distributed as dist
@@ -152,7 +153,7 @@ def model_step_leg(rank, local_rank, world, device, steps, warmup=3):
     model = build_model(cfg).train()
     ddp = T.wrap_ddp(model, local_rank)
     opt = T.build_optimizer(model)
-    clips = T.synthetic_clips(1, 5, 360, 640, device, seed=100 + rank, num_instances=4)
+    clips = T.synthetic_clips(clips_per_rank, 5, 360, 640, device, seed=100 + rank, num_instances=4)
     for _ in range(warmup):
         T.train_step(ddp, opt, clips)
     torch.cuda.synchronize()
@@ -174,8 +175,8 @@ def model_step_leg(rank, local_rank, world, device, steps, warmup=3):
     n_params = sum(p.numel() for p in model.parameters() if p.requires_grad)
     del ddp, opt, model
     torch.cuda.empty_cache()
-    return {"clips_per_s": world * steps / dt, "ms_per_step": dt * 1e3 / steps, "steps": steps,
-            "clips_per_rank": 1, "n_gpus": world, "trainable_params": n_params,
+    return {"clips_per_s": world * clips_per_rank * steps / dt, "ms_per_step": dt * 1e3 / steps, "steps": steps,
+            "clips_per_rank": clips_per_rank, "n_gpus": world, "trainable_params": n_params,
             "grad_allreduce_MB_per_step": round(n_params * 4 / 1e6, 1),
             "config": "SeqFormer R50 (random init), T=5, 360x640 -> 384x640, 300 queries, 6+6 layers, fp32; "
                       "SetCriterion on 4 synthetic tracks per clip (matcher + focal/L1/GIoU/mask losses, deep supervision); DDP static_graph + gradient_as_bucket_view over RCCL"}
@@ -392,6 +393,9 @@ def main():
     model_leg = None
     if not a.no_model:
         model_leg = model_step_leg(rank, local_rank, world, device, a.model_steps)
+        if model_leg is not None and world == 1:
+            one = model_step_leg(rank, local_rank, world, device, a.model_steps, clips_per_rank=1)
+            model_leg["one_clip_per_rank"] = {k: one[k] for k in ("clips_per_s", "ms_per_step")}
 
     if rank == 0:
         if model_leg is not None:
