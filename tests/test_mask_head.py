@@ -167,3 +167,31 @@ def test_no_instances_gives_empty_output_and_zero_feature_gradient():
     f = torch.randn(1, 8, 4, 6, device="cuda:0", requires_grad=True)
     out = dynamic_mask_with_coords(f, torch.zeros(1, 0, 2, device="cuda:0"), torch.zeros(1, 0, 169, device="cuda:0"), [0], 8)
     assert out.shape == (1, 0, 8, 12)
+
+
+@pytest.mark.gpu
+def test_backward_at_the_training_shape_of_a_360p_clip():
+    """forward_mask_head_train at BASELINE config 2: T = 5 frames of 48x80 features, the matched
+    instances of 6 decoder layers in one launch (here 6 x 5 x 4 = 120 instances in arbitrary
+    image order through the flat-instance surface) -- every gradient against the fp64 oracle."""
+    from vnext_amd.heads import dynamic_mask_head
+    gen = torch.Generator().manual_seed(123)
+    T_, H_, W_, n = 5, 48, 80, 120
+    feats = torch.randn(T_, 8, H_, W_, generator=gen)
+    pts = torch.rand(n, 2, generator=gen) * torch.tensor([W_ * 8.0, H_ * 8.0])
+    params = 0.3 * torch.randn(n, 169, generator=gen)
+    image = torch.randint(0, T_, (n,), generator=gen, dtype=torch.int32)
+    gout = torch.randn(n, 2 * H_, 2 * W_, generator=gen)
+    f = feats.cuda().requires_grad_(True); p = pts.cuda().requires_grad_(True); w = params.cuda().requires_grad_(True)
+    out = dynamic_mask_head(f, p, w, image.cuda(), 8)
+    out.backward(gout.cuda())
+    # oracle: instances grouped by image (its layout), then scattered back
+    order = torch.argsort(image, stable=True)
+    counts = torch.bincount(image, minlength=T_).tolist()
+    of, orf, op = H.dynamic_mask_head_backward(feats.double().numpy(), pts[order].double().numpy(),
+                                               params[order].double().numpy(), counts, gout[order].double().numpy())
+    _close(f.grad.double().cpu().numpy(), of, 3e-5)
+    _close(p.grad[order].double().cpu().numpy(), orf, 3e-5)
+    _close(w.grad[order].double().cpu().numpy(), op, 3e-5)
+    one = H.dynamic_mask_head(feats.double().numpy(), pts[order].double().numpy(), params[order].double().numpy(), counts)
+    _close(out[order].double().detach().cpu().numpy(), one, 2e-5)

@@ -160,3 +160,37 @@ def test_modules_with_the_fused_prologue_equal_the_reference_form(kind):
     assert set(got_grads) == set(ref_grads)
     for n in ref_grads:
         assert float((got_grads[n] - ref_grads[n]).abs().max()) <= 2e-4 * (float(ref_grads[n].abs().max()) + 1e-12), n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("res", ["360p", "720p"])
+def test_fused_at_the_encoder_shape_of_the_baseline_configs(res):
+    """BASELINE configs 2-5: Lq = S, B = 5 (T folded), references shared by the frames.  Fused vs
+    the unfused composition on the full tensors, and the adjoint identity
+    <f(value), g> == <value, grad_value(g)> (the op is linear in `value`)."""
+    from vnext_amd.ops.functions import MSDeformAttnFunction, MSDeformAttnFusedFunction, level_tensors as lt
+    shapes = {"360p": [(48, 80), (24, 40), (12, 20), (6, 10)], "720p": [(92, 160), (46, 80), (23, 40), (12, 20)]}[res]
+    dev = "cuda:0"
+    S = sum(h * w for h, w in shapes)
+    B, T, M, L, P = 5, 5, 8, 4, 4
+    g = torch.Generator(device=dev).manual_seed(17)
+    value = torch.randn(B, S, M, 32, device=dev, generator=g)
+    offsets = 2.0 * torch.randn(B, S, M, L, P, 2, device=dev, generator=g)
+    logits = torch.randn(B, S, M, L * P, device=dev, generator=g)
+    centres = torch.cat([torch.stack(torch.meshgrid((torch.arange(h, device=dev) + 0.5) / h,
+                                                    (torch.arange(w, device=dev) + 0.5) / w, indexing="ij"), -1)
+                         .flip(-1).reshape(-1, 2) for h, w in shapes])            # pixel centres (x, y)
+    ref = centres[None, :, None, :].expand(B // T, S, L, 2).contiguous()
+    shapes_t, lsi = lt(shapes, dev)
+    out = MSDeformAttnFusedFunction.apply(value, shapes_t, lsi, offsets, logits, ref)
+    attn = torch.softmax(logits, -1).view(B, S, M, L, P)
+    normalizer = torch.stack([shapes_t[..., 1], shapes_t[..., 0]], -1)
+    loc = ref.repeat_interleave(T, 0)[:, :, None, :, None, :] + offsets / normalizer[None, None, None, :, None, :]
+    want = MSDeformAttnFunction.apply(value, shapes_t, lsi, loc.contiguous(), attn.contiguous(), 64)
+    assert float((out - want).abs().max()) <= 3e-5 * float(want.abs().max())
+    gout = torch.randn(out.shape, device=dev, generator=g)
+    v = value.clone().requires_grad_(True)
+    MSDeformAttnFusedFunction.apply(v, shapes_t, lsi, offsets, logits, ref).backward(gout)
+    lhs = float((out.double() * gout.double()).sum())
+    rhs = float((value.double() * v.grad.double()).sum())
+    assert abs(lhs - rhs) <= 1e-4 * max(abs(lhs), 1.0)
