@@ -210,12 +210,17 @@ def extra_model_legs(device):
     del model
     model = build_model(get_idol_cfg(**{"MODEL.DEVICE": str(device)})).train()
     opt = T.build_optimizer(model, base_lr=1e-4)
-    pair = T.synthetic_clips(1, 2, 360, 640, device, seed=8, num_instances=8)
+    pair = T.synthetic_clips(1, 2, 720, 1280, device, seed=8, num_instances=8)
+
+    def idol_step():
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            return T.train_step(model, opt, pair)
     for _ in range(3):
-        T.train_step(model, opt, pair)
-    ms = timed(lambda: T.train_step(model, opt, pair), 5)
+        idol_step()
+    ms = timed(idol_step, 5)
     out["idol_train_step"] = {"ms_per_step": ms, "pairs_per_s": 1e3 / ms,
-                              "config": "IDOL R50, one key/reference pair 360x640, 8 objects, simOTA + reid losses, AdamW"}
+                              "config": "IDOL R50, one key/reference pair 720x1280, 8 objects, bf16 autocast (bf16 GEMMs and op "
+                                        "value, fp32 locations / losses / reid kernels), simOTA + reid losses, AdamW"}
     del opt
     model.eval()
     g = torch.Generator(device=device).manual_seed(1)

@@ -173,3 +173,19 @@ def test_config_c1_single_480x640_frame_on_cpu_with_the_oracle_op(monkeypatch):
     assert [tuple(s.shape[-2:]) for s in srcs] == [(60, 80), (30, 40), (15, 20), (8, 10)]
     assert tuple(memory.shape) == (1, 6380, 256) and tuple(hs.shape) == (1, 1, 20, 256)
     assert torch.isfinite(memory).all() and torch.isfinite(hs).all()
+
+
+@pytest.mark.gpu
+def test_idol_train_step_under_bf16_autocast_on_gpu():
+    """BASELINE config 3 (bf16): GEMMs and the op's value in bf16, fp32 reference points / matching /
+    losses / reid kernels."""
+    cfg = get_idol_cfg(**{"MODEL.DEVICE": "cuda:0", **TINY})
+    model = build_model(cfg).train()
+    pairs = T.synthetic_clips(1, 2, 96, 160, "cuda:0", seed=5, num_instances=3)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        losses = model(pairs)
+    total = sum(losses.values())
+    assert torch.isfinite(total)
+    total.backward()
+    g = model.detr.reid_embed_head.layers[0].weight.grad
+    assert g is not None and torch.isfinite(g).all()

@@ -93,6 +93,8 @@ class HungarianMatcher(nn.Module):
         tgt_ids = torch.cat([t["labels"] for t in targets])
         nf = boxes.shape[-3]
         tgt = torch.cat([t["boxes"] for t in targets]).reshape(len(tgt_ids), nf, 4).to(boxes.dtype)
+        if logits.dtype in (torch.bfloat16, torch.float16) or boxes.dtype in (torch.bfloat16, torch.float16):
+            logits, boxes = logits.float(), boxes.float()                    # autocast outputs: fp32 costs
         prob = logits.sigmoid()
         out = boxes.transpose(-3, -2)                                        # [..., bs, Q, nf, 4]
         # Euclidean distance over the clip's nf*4 coordinates (torch.cdist default p=2, matcher.py:66)

@@ -42,6 +42,12 @@ class _one_thread:
         return False
 
 
+def _host32(t):
+    """detach -> host; 16-bit (autocast) tensors as fp32, fp32 / fp64 as they are"""
+    t = t.detach()
+    return (t.float() if t.dtype in (torch.bfloat16, torch.float16) else t).cpu()
+
+
 def _pairwise_iou(a, b):
     a, b = a[:, None, :], b[None, :, :]
     wh = (torch.minimum(a[..., 2:], b[..., 2:]) - torch.maximum(a[..., :2], b[..., :2])).clamp(min=0)
@@ -122,8 +128,8 @@ class OTAMatcher(nn.Module):
 
     @torch.no_grad()
     def forward(self, outputs, targets, nf=1):
-        prob = outputs["pred_logits"].detach().sigmoid().cpu()
-        boxes = outputs["pred_boxes"].detach().cpu()
+        prob = _host32(outputs["pred_logits"].detach().sigmoid())
+        boxes = _host32(outputs["pred_boxes"])
         tg = [{k: t[k].cpu() for k in ("labels", "boxes")} for t in targets]
         with _one_thread():
             res = [self._one(boxes[i], prob[i], tg[i], nf) for i in range(len(tg))]
@@ -133,8 +139,9 @@ class OTAMatcher(nn.Module):
     def match_all_layers(self, logits, boxes, targets, nf=1):
         """logits [Ld, bz, Q, K], boxes [Ld, bz, Q, 4] -> (indices_list over layers, matched ids
         of the last layer); one device->host copy."""
-        prob = logits.detach().sigmoid().cpu()
-        boxes = boxes.detach().cpu()
+        prob = _host32(logits.detach().float().sigmoid() if logits.dtype in (torch.bfloat16, torch.float16)
+                       else logits.detach().sigmoid())
+        boxes = _host32(boxes)
         tg = [{k: t[k].cpu() for k in ("labels", "boxes")} for t in targets]
         with _one_thread():
             out = [[self._one(boxes[l, i], prob[l, i], tg[i], nf) for i in range(len(tg))] for l in range(prob.shape[0])]
@@ -151,7 +158,7 @@ def select_pos_neg_masks(ref_boxes, ref_prob, ref_targets, rng=_random):
     pos [Q, I], neg [Q, I], aux [Q, I] bool masks); aux = positives + the negatives drawn with
     `rng.sample` (host RNG, same call sequence as the reference)."""
     out = []
-    ref_boxes, ref_prob = ref_boxes.detach().cpu(), ref_prob.detach().cpu()
+    ref_boxes, ref_prob = _host32(ref_boxes), _host32(ref_prob)
     threads = _one_thread()
     threads.__enter__()
     for i, t in enumerate(ref_targets):
