@@ -57,11 +57,18 @@ def algorithmic_bytes(B, S, Lq, e=4, e_loc=4, M=8, D=32, L=4, K=4):
     return fwd, bwd
 
 
+_LEVELS = {}
+
+
 def make_set(res, B, Lq, seed, device, dist="U"):
     g = torch.Generator(device=device).manual_seed(seed)
-    shapes = torch.tensor(SHAPES[res], dtype=torch.long, device=device)
+    # the level geometry (two 32-byte int64 tensors) is ONE pair shared by every input set, as in the
+    # models, where all 12 layers' calls pass the same tensors; what rotates is the data
+    if (res, str(device)) not in _LEVELS:
+        sh = torch.tensor(SHAPES[res], dtype=torch.long, device=device)
+        _LEVELS[(res, str(device))] = (sh, torch.cat((sh.new_zeros((1,)), sh.prod(1).cumsum(0)[:-1])))
+    shapes, lsi = _LEVELS[(res, str(device))]
     S = int(shapes.prod(1).sum())
-    lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
     value = torch.randn(B, S, 8, 32, device=device, generator=g)
     if dist == "U":
         loc = torch.rand(B, Lq, 8, 4, 4, 2, device=device, generator=g)
