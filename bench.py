@@ -429,38 +429,42 @@ def main():
                                               ctypes.POINTER(ctypes.c_longlong), ctypes.c_int]
         L.vnx_debug_stamp_regions.restype = ctypes.c_int
         L.vnx_debug_wall_clock_khz.restype = ctypes.c_int
-        n_words = (4 * inner + 64) * 2 * 8192    # <= 8 Ki workgroups per stamped launch
+        n_words = (6 * inner + 96) * 2 * 8192    # <= 8 Ki workgroups per stamped launch
         stamps = torch.zeros(n_words, dtype=torch.int64, device=device)
         L.vnx_debug_arm_stamps(stamps.data_ptr(), n_words)
         g_fwd = capture([(lambda s=sets[i % nsets]: op.fwd(s, B, Lq)) for i in range(inner)])
         g_bwd = capture([(lambda s=sets[i % nsets]: op.bwd(s, B, Lq)) for i in range(inner)])
         # forward + grad_loc kernels (grad_value: see below); capture() also runs its functions
         # eagerly first -- those launches take regions too, which stay zero in the measured replays
-        max_regions = 4 * inner + 64
+        max_regions = 6 * inner + 96
         kinds = (ctypes.c_int * max_regions)()
         offs = (ctypes.c_longlong * max_regions)()
         nblk = (ctypes.c_longlong * max_regions)()
+        n_cold = L.vnx_debug_stamp_regions(kinds, offs, nblk, max_regions)
+        us_fwd_warm, g_fwd_warm = None, None
+        if not a.no_warm:     # same launches on ONE input set: value / locations stay in L2 + Infinity Cache
+            g_fwd_warm = capture([(lambda: op.fwd(sets[0], B, Lq)) for _ in range(inner)])
         n_regions = L.vnx_debug_stamp_regions(kinds, offs, nblk, max_regions)
         L.vnx_debug_arm_stamps(None, 0)
         us_fwd = event_time_us(g_fwd, inner)
         us_bwd = event_time_us(g_bwd, inner)
-        us_fwd_warm = None
-        if not a.no_warm:
-            g_fwd_warm = capture([(lambda: op.fwd(sets[0], B, Lq)) for _ in range(inner)])
+        if g_fwd_warm is not None:
             us_fwd_warm = event_time_us(g_fwd_warm, inner)
         khz = L.vnx_debug_wall_clock_khz()
-        span = {1: [], 2: [], 3: []}
+        span = {1: [], 2: [], 3: [], "warm": []}
         if khz > 0 and 0 < n_regions <= max_regions:
             for _ in range(10):
                 stamps.zero_()
                 g_fwd.replay()
                 g_bwd.replay()
+                if g_fwd_warm is not None:
+                    g_fwd_warm.replay()
                 torch.cuda.synchronize()
                 for i in range(n_regions):
                     t = stamps[offs[i]:offs[i] + 2 * nblk[i]].view(-1, 2)
                     ran = t[:, 0] > 0                   # placeholder workgroups that returned at once still stamp
                     if bool(ran.any()):
-                        span[kinds[i]].append(float(t[ran, 1].max() - t[ran, 0].min()) / khz * 1e3)
+                        span["warm" if i >= n_cold else kinds[i]].append(float(t[ran, 1].max() - t[ran, 0].min()) / khz * 1e3)
         # the grad_value kernel takes no stamp-region argument (register budget, see
         # msda_d32_gvrec.hip): its workgroups stamp a fixed device array when launched with
         # variant 412 -- single launches, rotating inputs, read back after each
@@ -500,8 +504,10 @@ def main():
 
         line["roofline"] = roof(bytes_fwd, k_us[1], us_fwd, "msda_fwd_d32_kernel (ms_deform_attn_forward)")
         if us_fwd_warm:
-            line["roofline"]["warm_us_per_launch"] = us_fwd_warm
-            line["roofline"]["warm_frac"] = bytes_fwd / us_fwd_warm / 1e3 / HBM_PEAK_GBS   # events, incl. gaps
+            warm = k_us.get("warm") or us_fwd_warm       # kernel span like the cold number; events as fallback
+            line["roofline"]["warm_us_per_launch"] = warm
+            line["roofline"]["warm_us_per_launch_events"] = us_fwd_warm
+            line["roofline"]["warm_frac"] = bytes_fwd / warm / 1e3 / HBM_PEAK_GBS
         line["roofline_bwd"] = roof(bytes_bwd, (k_us[2] + k_us[3]) if (k_us[2] and k_us[3]) else None, us_bwd,
                                     "msda_bwd_d32_kernel (grad_loc, grad_attn, sample records) + "
                                     "msda_bwd_gv_rec_kernel (grad_value), one ms_deform_attn_backward call")
