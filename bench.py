@@ -510,14 +510,14 @@ def main():
             line["roofline"]["warm_frac"] = bytes_fwd / warm / 1e3 / HBM_PEAK_GBS
         line["roofline_bwd"] = roof(bytes_bwd, (k_us[2] + k_us[3]) if (k_us[2] and k_us[3]) else None, us_bwd,
                                     "msda_bwd_d32_kernel (grad_loc, grad_attn, sample records) + "
-                                    "msda_bwd_gv_rec_kernel (grad_value), one ms_deform_attn_backward call")
+                                    "msda_bwd_gv_sel_kernel (grad_value), one ms_deform_attn_backward call")
         # HBM bytes per launch cannot be counted from inside this process: they come from the
         # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command
         # (profiles/rNN_bench_pmc_hbm.json, corrected as MI355X_MICROARCH.md section HBM says).
         pmc = latest_pmc_profile()
         if pmc is not None and (B, Lq, res, a.dist) == (5, 300, "360p", "U"):
             for key, names in (("roofline", ["msda_fwd_d32_kernel"]),
-                               ("roofline_bwd", ["msda_bwd_d32_kernel", "msda_bwd_gv_rec_kernel"])):
+                               ("roofline_bwd", ["msda_bwd_d32_kernel", "msda_bwd_gv_rec_kernel", "msda_bwd_gv_sel_kernel"])):
                 vals = [v.get("hbm_bytes_per_launch_corrected") for k, v in pmc["data"].items()
                         if any(n in k for n in names)]
                 if vals and all(v is not None for v in vals):
