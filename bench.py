@@ -144,7 +144,7 @@ def event_time_us(graph, launches, reps=15):
     return ts[len(ts) // 2]
 
 
-def model_step_leg(rank, local_rank, world, device, steps, warmup=3, clips_per_rank=2):
+def model_step_leg(rank, local_rank, world, device, steps, warmup=3, clips_per_rank=2, bf16=False):
     """clips/s of the SeqFormer-R50 training step (BASELINE config: T=5 synthetic 360p clip, 300
     queries): forward + backward + RCCL gradient all-reduce + clipped AdamW step, two clips per
     rank -- the reference's per-GPU batch (IMS_PER_BATCH 16 on 8 GPUs, configs/base_ytvis.yaml:18) --
@@ -161,15 +161,20 @@ def model_step_leg(rank, local_rank, world, device, steps, warmup=3, clips_per_r
     ddp = T.wrap_ddp(model, local_rank)
     opt = T.build_optimizer(model)
     clips = T.synthetic_clips(clips_per_rank, 5, 360, 640, device, seed=100 + rank, num_instances=4)
+    def step():
+        if bf16:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                return T.train_step(ddp, opt, clips)
+        return T.train_step(ddp, opt, clips)
     for _ in range(warmup):
-        T.train_step(ddp, opt, clips)
+        step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        T.train_step(ddp, opt, clips)
+        step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -408,6 +413,10 @@ def main():
         if model_leg is not None and world == 1:
             one = model_step_leg(rank, local_rank, world, device, a.model_steps, clips_per_rank=1)
             model_leg["one_clip_per_rank"] = {k: one[k] for k in ("clips_per_s", "ms_per_step")}
+            amp = model_step_leg(rank, local_rank, world, device, a.model_steps, bf16=True)
+            model_leg["bf16_autocast"] = {**{k: amp[k] for k in ("clips_per_s", "ms_per_step")},
+                                          "note": "same step under torch.autocast(bfloat16): bf16 GEMMs and op value, fp32 "
+                                                  "locations / losses; the reference trains in fp32, so this is not the headline"}
 
     if rank == 0:
         if model_leg is not None:
