@@ -534,7 +534,7 @@ def main():
                     line[key]["traffic_source"] = pmc["file"]
         line["roofline_bwd"]["us_grad_loc_kernel"], line["roofline_bwd"]["us_grad_value_kernel"] = k_us[2], k_us[3]
         line["fwd_gpoints_per_s"] = points / us_fwd / 1e3
-        if not a.no_cpu:
+        if not a.no_cpu and world == 1:     # the CPU leg runs at N = 1 only
             line["cpu_baseline"] = cpu_baseline(B, Lq, res)
         print(json.dumps(line), flush=True)
     if world > 1:

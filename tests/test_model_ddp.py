@@ -255,3 +255,32 @@ def test_frozen_batchnorm_folded_into_the_convolution():
     np.testing.assert_allclose(conv_bn(x, conv, bn).detach().numpy(), bn(conv(x)).detach().numpy(), rtol=1e-4, atol=1e-5)
     conv_bn(x, conv, bn).sum().backward()
     assert conv.weight.grad is not None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("arch", ["SeqFormer", "IDOL"])
+def test_ddp_wrapper_over_rccl_on_one_gpu(arch):
+    """The N > 1 code path with the real backend: a one-rank RCCL process group, the DDP wrapper
+    bench.py / train.py use (static graph, gradients as bucket views), the criteria's own
+    all-reduce of the box count, frozen stages and never-used parameters -- three steps."""
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel
+    from vnext_amd.registry import get_idol_cfg
+    port = 29600 + (os.getpid() % 300) + (0 if arch == "SeqFormer" else 1)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        if arch == "SeqFormer":
+            model = build_model(get_seqformer_cfg(**{"MODEL.DEVICE": "cuda:0", **TINY})).train()
+        else:
+            model = build_model(get_idol_cfg(**{"MODEL.DEVICE": "cuda:0", "MODEL.IDOL.ENC_LAYERS": 1,
+                                                "MODEL.IDOL.DEC_LAYERS": 2, "MODEL.IDOL.NUM_OBJECT_QUERIES": 110,
+                                                "MODEL.IDOL.DIM_FEEDFORWARD": 64, "MODEL.IDOL.DROPOUT": 0.0})).train()
+        ddp = DistributedDataParallel(model, device_ids=[0], broadcast_buffers=False, find_unused_parameters=False,
+                                      static_graph=True, gradient_as_bucket_view=True)
+        opt = T.build_optimizer(model)
+        clips = T.synthetic_clips(2, 2, 96, 160, "cuda:0", seed=12, num_instances=2)
+        losses = [float(T.train_step(ddp, opt, clips)) for _ in range(3)]
+        assert all(np.isfinite(losses))
+    finally:
+        dist.destroy_process_group()
