@@ -189,3 +189,50 @@ def test_idol_train_step_under_bf16_autocast_on_gpu():
     total.backward()
     g = model.detr.reid_embed_head.layers[0].weight.grad
     assert g is not None and torch.isfinite(g).all()
+
+
+def _idol_ddp_worker(rank, world, port, out):
+    import sys
+    import torch.distributed as dist
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from oracle.heads_torch_fallback import dynamic_mask_head_torch
+    from oracle.msda_torch_fallback import msda_grid_sample
+    from vnext_amd.ops.modules import ms_deform_attn as mod
+
+    class Fn:
+        @staticmethod
+        def apply(value, shapes, lsi, loc, attn, step):
+            return msda_grid_sample(value, shapes, loc, attn)
+    mod.MSDeformAttnFunction = Fn
+    idol_mod.dynamic_mask_head = dynamic_mask_head_torch
+    idol_mod.loss_reid = _loss_reid_torch
+    T.init_distributed("gloo")
+    torch.manual_seed(0)
+    model = build_model(get_idol_cfg(**{"MODEL.DEVICE": "cpu", **TINY})).train()
+    ddp = T.wrap_ddp(model)
+    pairs = T.synthetic_clips(2, 2, 64, 96, "cpu", seed=21, num_instances=2)
+    import random
+    random.seed(3)                                    # the host-RNG negative sampling of select_pos_neg
+    mine = [pairs[i] for i in T.shard_indices(len(pairs), rank, world)]
+    sum(ddp(mine).values()).backward()
+    flat = torch.cat([p.grad.flatten() for p in model.parameters() if p.grad is not None])
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    if rank == 0:
+        torch.save(gathered, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_idol_ddp_world_size_2_gloo_ranks_agree(tmp_path):
+    """Key/reference pairs sharded over two CPU processes (gloo): after backward both ranks hold the
+    same (averaged) gradient, reid head included."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "idol_ddp.pt")
+    port = 29800 + (os.getpid() % 150)
+    mp.spawn(_idol_ddp_worker, args=(2, port, out), nprocs=2, join=True)
+    g0, g1 = torch.load(out)
+    assert torch.equal(g0, g1) and float(g0.abs().sum()) > 0
