@@ -60,6 +60,20 @@ def test_losses_equal_reference(case):
     np.testing.assert_allclose(float(again["loss_dice"]), want["loss_dice"], rtol=1e-10)
 
 
+def test_all_layers_in_one_pass_equals_the_per_layer_form(case):
+    g, targets, outs, (bs, nf, Q, K, H, W, layers) = case
+    crit = SetCriterion(K, _matcher(), {}, ["labels", "boxes", "masks"], mask_out_stride=4, num_frames=nf)
+    indices_list = [[(torch.from_numpy(g[f"l{l}.src{i}"]), torch.from_numpy(g[f"l{l}.tgt{i}"])) for i in range(bs)]
+                    for l in range(layers)]
+    masks = torch.cat([torch.cat([torch.from_numpy(g[f"l{l}.masks{i}"]) for i in range(bs)], 1)[0] for l in range(layers)])
+    got = crit.forward_all_layers(torch.stack([o["pred_logits"] for o in outs]), torch.stack([o["pred_boxes"] for o in outs]),
+                                  masks, targets, indices_list)
+    want = {k[5:]: float(v) for k, v in g.items() if k.startswith("loss.")}
+    assert set(got) == set(want)
+    for k, v in want.items():
+        np.testing.assert_allclose(float(got[k]), v, rtol=1e-10, atol=1e-12, err_msg=k)
+
+
 def test_no_targets_anywhere():
     K, nf, Q = 4, 2, 5
     crit = SetCriterion(K, _matcher(), {}, ["labels", "boxes", "masks"], num_frames=nf)

@@ -201,6 +201,82 @@ class SetCriterion(nn.Module):
         src, tgt = src.flatten(1), tgt.flatten(1)
         return {"loss_mask": sigmoid_focal_loss(src, tgt, num_boxes), "loss_dice": dice_loss(src, tgt, num_boxes)}
 
+    # ---- all decoder layers in one pass ------------------------------------------------------
+    def forward_all_layers(self, logits, boxes, masks, targets, indices_list):
+        """`forward` for every decoder layer at once: logits [Ld, N, Q, K], boxes [Ld, N, T, Q, 4],
+        masks [Ld * n, T, h, w] (the matched instances' mask logits, layer-major, clips in order,
+        instances in matched order -- what the fused mask head returns), indices_list[layer][clip] =
+        (query idx, target idx).  Same names and numbers as `forward` with deep supervision; one set of
+        kernels instead of one per layer (the Hungarian matching assigns every target in every layer,
+        so each layer contributes the same number n of instances)."""
+        Ld, N, Q, K = logits.shape
+        T = boxes.shape[2]
+        dev = logits.device
+        num_boxes = torch.as_tensor([float(sum(len(t["labels"]) for t in targets))], device=dev)
+        world = 1
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            torch.distributed.all_reduce(num_boxes)
+            world = torch.distributed.get_world_size()
+        num_boxes = torch.clamp(num_boxes / world, min=1)[0]
+        # stacked index tensors, built on the host, one transfer each
+        lay = torch.cat([torch.full_like(q, l) for l, ind in enumerate(indices_list) for q, _ in ind]).to(dev)
+        clip = torch.cat([torch.full_like(q, i) for ind in indices_list for i, (q, _) in enumerate(ind)]).to(dev)
+        qry = torch.cat([q for ind in indices_list for q, _ in ind]).to(dev)
+        start = [0]
+        for t in targets:
+            start.append(start[-1] + len(t["labels"]))
+        tgt = torch.cat([j + start[i] for ind in indices_list for i, (_, j) in enumerate(ind)]).to(dev)   # into the concatenated targets
+        n = len(qry) // Ld
+        names = [f"_{l}" for l in range(Ld - 1)] + [""]
+        out = {}
+        # labels (focal): mean over Q * Q = sum over Q
+        all_labels = torch.cat([t["labels"] for t in targets]).to(dev)
+        onehot = torch.zeros_like(logits)
+        onehot[lay, clip, qry, all_labels[tgt]] = 1
+        p = logits.sigmoid()
+        ce = F.binary_cross_entropy_with_logits(logits, onehot, reduction="none")
+        p_t = p * onehot + (1 - p) * (1 - onehot)
+        focal = ce * (1 - p_t) ** 2.0
+        if self.focal_alpha >= 0:
+            focal = (self.focal_alpha * onehot + (1 - self.focal_alpha) * (1 - onehot)) * focal
+        loss_ce = focal.mean(2).sum((1, 2)) / num_boxes * Q
+        with torch.no_grad():
+            if n:
+                sel = logits[-1][clip[-n:], qry[-n:]]
+                out["class_error"] = 100 - (sel.argmax(-1) == all_labels[tgt[-n:]]).float().mean() * 100
+            else:
+                out["class_error"] = 100 - torch.zeros([], device=dev)
+        # boxes (L1 + GIoU over the clip's frames)
+        pred = boxes.transpose(2, 3)[lay, clip, qry]                                   # [Ld*n, T, 4]
+        all_boxes = torch.cat([t["boxes"].reshape(-1, T, 4) for t in targets]).to(pred)
+        want = all_boxes[tgt]
+        l1 = (pred - want).abs().flatten(1).sum(1).view(Ld, n).sum(1) / T / num_boxes
+        g = giou_loss(box_cxcywh_to_xyxy(pred.flatten(0, 1)), box_cxcywh_to_xyxy(want.flatten(0, 1)))
+        g = g.view(Ld, n * T).sum(1) / T / num_boxes
+        # masks (focal + dice)
+        if n:
+            h, w = masks.shape[-2:]
+            s_ = self.mask_out_stride
+            gt = []
+            for t in targets:
+                m = t["masks"][..., s_ // 2::s_, s_ // 2::s_]
+                gt.append(F.pad(m.to(masks.dtype), (0, w - m.shape[-1], 0, h - m.shape[-2])))
+            gt = torch.cat(gt).to(dev)[tgt].flatten(1)                                 # [Ld*n, T*h*w]
+            src = masks.flatten(1)
+            pm = src.sigmoid()
+            ce_m = F.binary_cross_entropy_with_logits(src, gt, reduction="none")
+            pt_m = pm * gt + (1 - pm) * (1 - gt)
+            fm = (0.25 * gt + 0.75 * (1 - gt)) * ce_m * (1 - pt_m) ** 2.0
+            loss_mask = fm.mean(1).view(Ld, n).sum(1) / num_boxes
+            dice = 1 - (2 * (pm * gt).sum(1) + 1) / (pm.sum(1) + gt.sum(1) + 1)
+            loss_dice = dice.view(Ld, n).sum(1) / num_boxes
+        else:
+            loss_mask = loss_dice = (masks * 0).sum() + torch.zeros(Ld, device=dev)
+        for l, suffix in enumerate(names):
+            out["loss_ce" + suffix], out["loss_bbox" + suffix], out["loss_giou" + suffix] = loss_ce[l], l1[l], g[l]
+            out["loss_mask" + suffix], out["loss_dice" + suffix] = loss_mask[l], loss_dice[l]
+        return out
+
     def get_loss(self, loss, outputs, targets, indices, num_boxes, **kw):
         table = {"labels": self.loss_labels, "boxes": self.loss_boxes, "masks": self.loss_masks}
         assert loss in table, f"do you really want to compute {loss} loss?"

@@ -409,33 +409,29 @@ class SeqFormer(nn.Module):
             feats = self._mask_features(srcs, memory)
         Ld, N, T = boxes.shape[:3]
         indices_list = self.criterion.matcher.match_all_layers(logits, boxes, targets)
-        # the matched instances of every decoder layer, on every frame of their clip, in one launch
-        params, points, image = [], [], []
-        frame = torch.arange(T, device=self.device)
-        for l in range(Ld):
-            ctl = self.detr.controller
-            for i, (q, _) in enumerate(indices_list[l]):
-                q = q.to(self.device)
-                p = ctl(hs[l][i, q])                                              # [n, 169]
-                scale = scale_tensor(targets[i]["size"].flip(0).tolist(), self.device)   # (w, h) of the frames
-                pt = refs[l][i][:, q, :2].sigmoid() * scale                       # [T, n, 2] image pixels
-                params.append(p[:, None].expand(-1, T, -1))
-                points.append(pt.transpose(0, 1))
-                image.append((i * T + frame)[None].expand(len(q), -1))
-        params = torch.cat(params).flatten(0, 1)                                    # [(l, i, inst, t), 169]
-        points = torch.cat(points).flatten(0, 1)
-        image = torch.cat(image).flatten().to(torch.int32)
+        # the matched instances of every decoder layer, on every frame of their clip: one gather, one
+        # controller call, one mask-head launch (the reference: a Python loop over layers x clips x frames)
+        lay = torch.cat([torch.full_like(q, l) for l, ind in enumerate(indices_list) for q, _ in ind]).to(self.device)
+        clip = torch.cat([torch.full_like(q, i) for ind in indices_list for i, (q, _) in enumerate(ind)]).to(self.device)
+        qry = torch.cat([q for ind in indices_list for q, _ in ind]).to(self.device)
+        params = self.detr.controller(hs[lay, clip, qry])                         # [Ld*n, 169]
+        ref_xy = torch.stack([r[..., :2] for r in refs])                          # [Ld, N, T, Q, 2] pre-sigmoid
+        sizes = torch.stack([scale_tensor(t["size"].flip(0).tolist(), self.device) for t in targets])   # [N, (w, h)]
+        points = ref_xy[lay, clip, :, qry].sigmoid() * sizes[clip][:, None, :]    # [Ld*n, T, 2] image pixels
+        image = (clip * T)[:, None] + torch.arange(T, device=self.device)[None, :]
+        params = params[:, None].expand(-1, T, -1).flatten(0, 1)                   # [(l, i, inst, t), 169]
+        points = points.flatten(0, 1)
+        image = image.flatten().to(torch.int32)
         masks = dynamic_mask_head(feats, points.float(), params.float(), image, 8)  # [sum, H/4, W/4]
         masks = masks.view(-1, T, *masks.shape[-2:])
         if masks.shape[0] == 0:  # nothing matched anywhere: keep the mask branch in the autograd graph
             masks = masks + 0 * (feats.sum() + sum(p.sum() for p in self.detr.controller.parameters()))
-        counts = [sum(len(q) for q, _ in ind) for ind in indices_list]
-        per_layer = masks.split(counts)
-        outs = [{"pred_logits": logits[l], "pred_boxes": boxes[l], "pred_masks": per_layer[l]} for l in range(Ld)]
-        outputs = dict(outs[-1])
-        if self.deep_supervision:
-            outputs["aux_outputs"] = outs[:-1]
-        loss = self.criterion(outputs, targets, indices_list)
+        if self.deep_supervision:   # every decoder layer's losses in one pass over stacked tensors
+            loss = self.criterion.forward_all_layers(logits, boxes, masks, targets, indices_list)
+        else:
+            n_last = sum(len(q) for q, _ in indices_list[-1])
+            outputs = {"pred_logits": logits[-1], "pred_boxes": boxes[-1], "pred_masks": masks[masks.shape[0] - n_last:]}
+            loss = self.criterion(outputs, targets, indices_list)
         w = self.criterion.weight_dict
         return {k: v * w[k] if k in w else v for k, v in loss.items()}
 
