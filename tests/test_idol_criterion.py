@@ -97,6 +97,25 @@ def test_losses_equal_reference(case):
         np.testing.assert_allclose(float(losses[k]), v, rtol=1e-6 if k == "loss_reid_aux" else 1e-9, atol=1e-12, err_msg=k)
 
 
+def test_all_layers_in_one_pass_equals_the_per_layer_form(case):
+    g, det, ref, outs, (bz, Q, K, H, W, layers, C) = case
+    crit = IDOLCriterion(K, OTAMatcher(), {}, ["labels", "boxes", "masks", "reid"], mask_out_stride=4)
+    indices_list = [[(torch.from_numpy(g[f"l{l}.sel{i}"]), torch.from_numpy(g[f"l{l}.gt{i}"])) for i in range(bz)]
+                    for l in range(layers)]
+    masks = torch.cat([torch.cat([torch.from_numpy(g[f"l{l}.masks{i}"]) for i in range(bz)], 1)[0] for l in range(layers)])
+    head = torch.from_numpy(g["head_w"])
+    key = torch.from_numpy(g["hs_key"]) @ head.t()
+    refe = torch.from_numpy(g["hs_ref"]) @ head.t()
+    matched = [torch.from_numpy(g[f"matched{i}"]) for i in range(bz)]
+    qd = reid_terms(key, refe, matched, _selection(g, ref), _loss_reid_torch)
+    got = crit.forward_all_layers(torch.stack([o["pred_logits"] for o in outs]), torch.stack([o["pred_boxes"] for o in outs]),
+                                  masks, det, indices_list, qd)
+    want = {k[5:]: float(v) for k, v in g.items() if k.startswith("loss.")}
+    assert set(got) == set(want)
+    for k, v in want.items():
+        np.testing.assert_allclose(float(got[k]), v, rtol=1e-6 if k == "loss_reid_aux" else 1e-9, atol=1e-12, err_msg=k)
+
+
 def test_no_objects_in_any_key_frame():
     K, Q = 4, 110
     crit = IDOLCriterion(K, OTAMatcher(), {}, ["labels", "boxes", "masks", "reid"])

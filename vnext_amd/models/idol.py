@@ -193,33 +193,35 @@ class IDOL(nn.Module):
         logits, boxes = self._box_heads(hs[:, 0::2], [r[0::2] for r in refs], range(Ld))      # key frames
         indices_list, matched = self.criterion.matcher.match_all_layers(logits, boxes, det_t)
         feats = self._mask_features([s[0::2] for s in srcs], memory[0::2])
-        params, points, image = [], [], []
-        for l in range(Ld):
-            for i, (sel, _) in enumerate(indices_list[l]):
-                q = torch.nonzero(sel).flatten().to(self.device, non_blocking=True)
-                scale = scale_tensor([sizes[i][1], sizes[i][0]], self.device)
-                params.append(self.detr.controller(hs[l, 2 * i, q]))
-                points.append(refs[l][2 * i, q, :2].sigmoid() * scale)
-                image.append(torch.full((len(q),), i, device=self.device, dtype=torch.int32))
-        masks = dynamic_mask_head(feats, torch.cat(points).float(), torch.cat(params).float(), torch.cat(image), 8)
+        # the selected queries of every decoder layer on every key frame: one gather, one controller
+        # call, one mask-head launch
+        q_host = [[torch.nonzero(sel).flatten() for sel, _ in ind] for ind in indices_list]
+        lay = torch.cat([torch.full_like(q, l) for l, layer in enumerate(q_host) for q in layer]).to(self.device, non_blocking=True)
+        img = torch.cat([torch.full_like(q, i) for layer in q_host for i, q in enumerate(layer)]).to(self.device, non_blocking=True)
+        qry = torch.cat([q for layer in q_host for q in layer]).to(self.device, non_blocking=True)
+        key_hs = hs[:, 0::2]                                                            # [Ld, bz, Q, C]
+        ref_xy = torch.stack([r[0::2, :, :2] for r in refs])                            # [Ld, bz, Q, 2] pre-sigmoid
+        scale = torch.stack([scale_tensor([sizes[i][1], sizes[i][0]], self.device) for i in range(bz)])   # [bz, (w, h)]
+        params = self.detr.controller(key_hs[lay, img, qry])
+        points = ref_xy[lay, img, qry].sigmoid() * scale[img]
+        masks = dynamic_mask_head(feats, points.float(), params.float(), img.to(torch.int32), 8)
         if masks.shape[0] == 0:  # nothing matched: keep the mask branch in the autograd graph
             masks = masks + 0 * (feats.sum() + sum(p.sum() for p in self.detr.controller.parameters()))
-        counts = [sum(int(sel.sum()) for sel, _ in ind) for ind in indices_list]
-        per_layer = [m[:, None] for m in masks.split(counts)]                     # [n, 1, H/4, W/4]
+        masks = masks[:, None]                                                          # [n, 1, H/4, W/4]
         # contrastive sets on the reference frames (last decoder layer), embeddings of both frames
         ref_prob = self.detr.detr.class_embed[-1](hs[-1, 1::2]).sigmoid()
         selections = select_pos_neg_masks(inter_refs[-1, 1::2], ref_prob, ref_t)
         embeds = self.detr.reid_embed_head(hs[-1])
-        outs = [{"pred_logits": logits[l], "pred_boxes": boxes[l], "pred_masks": per_layer[l]} for l in range(Ld)]
-        outputs = dict(outs[-1])
-        outputs["pred_qd"] = reid_terms(embeds[0::2], embeds[1::2], matched, selections, loss_reid)
-        if outputs["pred_qd"]["count"] == 0:
-            outputs["pred_qd"]["anchor"] = embeds.sum() * 0
-        if self.deep_supervision:
-            outputs["aux_outputs"] = outs[:-1]
-        loss = self.criterion(outputs, det_t, ref_t, indices_list)
-        if outputs["pred_qd"]["count"] == 0:     # keep the reid head in the graph (static DDP graph)
-            loss["loss_reid"] = loss["loss_reid"] + outputs["pred_qd"]["anchor"]
+        qd = reid_terms(embeds[0::2], embeds[1::2], matched, selections, loss_reid)
+        if self.deep_supervision:   # every decoder layer's losses in one pass over stacked tensors
+            loss = self.criterion.forward_all_layers(logits, boxes, masks, det_t, indices_list, qd)
+        else:
+            n_last = sum(len(q) for q in q_host[-1])
+            outputs = {"pred_logits": logits[-1], "pred_boxes": boxes[-1], "pred_masks": masks[masks.shape[0] - n_last:],
+                       "pred_qd": qd}
+            loss = self.criterion(outputs, det_t, ref_t, indices_list)
+        if qd["count"] == 0:     # keep the reid head in the graph (static DDP graph)
+            loss["loss_reid"] = loss["loss_reid"] + embeds.sum() * 0
         w = self.criterion.weight_dict
         return {k: v * w[k] if k in w else v for k, v in loss.items()}
 

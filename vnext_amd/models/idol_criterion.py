@@ -255,6 +255,68 @@ class IDOLCriterion(nn.Module):
             return {"loss_reid": zero, "loss_reid_aux": zero}
         return {"loss_reid": qd["contrast"] / qd["count"], "loss_reid_aux": qd["aux"] / qd["count"]}
 
+    # ---- all decoder layers in one pass ------------------------------------------------------
+    def forward_all_layers(self, logits, boxes, masks, targets, indices_list, pred_qd):
+        """`forward` for every decoder layer at once: logits [Ld, bz, Q, K], boxes [Ld, bz, Q, 4], masks
+        [sum over layers of n_l, 1, h, w] (layer-major, images in order, queries ascending -- what the
+        fused mask head returns), indices_list[layer][image] = (selected [Q] bool, gt idx).  simOTA
+        selects a different number of queries per layer, so per-layer sums are segment sums over one
+        flat list.  Same names and numbers as `forward` with deep supervision."""
+        Ld, bz, Q, K = logits.shape
+        dev = logits.device
+        q_host = [[torch.nonzero(sel).flatten() for sel, _ in ind] for ind in indices_list]
+        counts = [sum(len(q) for q in layer) for layer in q_host]
+        lay = torch.cat([torch.full_like(q, l) for l, layer in enumerate(q_host) for q in layer]).to(dev, non_blocking=True)
+        img = torch.cat([torch.full_like(q, i) for layer in q_host for i, q in enumerate(layer)]).to(dev, non_blocking=True)
+        qry = torch.cat([q for layer in q_host for q in layer]).to(dev, non_blocking=True)
+        start = [0]
+        for t in targets:
+            start.append(start[-1] + len(t["labels"]))
+        tgt = torch.cat([gt.long() + start[i] for ind in indices_list for i, (_, gt) in enumerate(ind)]).to(dev, non_blocking=True)
+        denom = torch.tensor([max(c, 1) for c in counts], dtype=logits.dtype, device=dev)
+        present = torch.tensor([1.0 if c else 0.0 for c in counts], dtype=logits.dtype, device=dev)
+
+        def per_layer(values):        # [sum n] -> [Ld] segment sums
+            return torch.zeros(Ld, dtype=values.dtype, device=dev).index_add_(0, lay, values)
+        # labels
+        all_labels = torch.cat([t["labels"] for t in targets]).to(dev)
+        onehot = torch.zeros_like(logits)
+        onehot[lay, img, qry, all_labels[tgt]] = 1
+        p = logits.sigmoid()
+        ce = F.binary_cross_entropy_with_logits(logits, onehot, reduction="none")
+        focal = ce * (1 - (p * onehot + (1 - p) * (1 - onehot))) ** 2.0
+        if self.focal_alpha >= 0:
+            focal = (self.focal_alpha * onehot + (1 - self.focal_alpha) * (1 - onehot)) * focal
+        loss_ce = focal.mean(2).sum((1, 2)) / denom * Q
+        # boxes
+        pred = boxes[lay, img, qry]
+        want = torch.cat([t["boxes"].reshape(-1, 4) for t in targets]).to(pred)[tgt]
+        l1 = per_layer((pred - want).abs().sum(1)) / denom * present
+        giou = per_layer(giou_loss(box_cxcywh_to_xyxy(pred), box_cxcywh_to_xyxy(want))) / denom * present
+        # masks
+        h, w = masks.shape[-2:]
+        s_ = self.mask_out_stride
+        gt_masks = []
+        for t in targets:
+            m = t["masks"][..., s_ // 2::s_, s_ // 2::s_]
+            gt_masks.append(F.pad(m.to(masks.dtype), (0, w - m.shape[-1], 0, h - m.shape[-2])))
+        if sum(counts):
+            gt_m = torch.cat(gt_masks).to(dev)[tgt].flatten(1)
+            src = masks.flatten(1)
+            pm = src.sigmoid()
+            ce_m = F.binary_cross_entropy_with_logits(src, gt_m, reduction="none")
+            fm = (0.25 * gt_m + 0.75 * (1 - gt_m)) * ce_m * (1 - (pm * gt_m + (1 - pm) * (1 - gt_m))) ** 2.0
+            loss_mask = per_layer(fm.mean(1)) / denom * present
+            dice = 1 - (2 * (pm * gt_m).sum(1) + 1) / (pm.sum(1) + gt_m.sum(1) + 1)
+            loss_dice = per_layer(dice) / denom * present
+        else:
+            loss_mask = loss_dice = (masks * 0).sum() + torch.zeros(Ld, dtype=logits.dtype, device=dev)
+        out = self.loss_reid({"pred_qd": pred_qd, "pred_logits": logits[-1]}, None, None, None, None)
+        for l, suffix in enumerate([f"_{l}" for l in range(Ld - 1)] + [""]):
+            out["loss_ce" + suffix], out["loss_bbox" + suffix], out["loss_giou" + suffix] = loss_ce[l], l1[l], giou[l]
+            out["loss_mask" + suffix], out["loss_dice" + suffix] = loss_mask[l], loss_dice[l]
+        return out
+
     def get_loss(self, loss, outputs, targets, ref_targets, indices, num_boxes, **kw):
         table = {"labels": self.loss_labels, "boxes": self.loss_boxes, "masks": self.loss_masks, "reid": self.loss_reid}
         assert loss in table, f"do you really want to compute {loss} loss?"
