@@ -324,9 +324,116 @@ def cpu_baseline(B, Lq, res, budget_s=12.0):
     }
 
 
+def timed_region(run, n, world, device):
+    """EXACTLY n calls of `run` bracketed by barrier + synchronize on both sides; the maximum over
+    ranks of the elapsed seconds (every rank returns the same number)."""
+    import torch.distributed as dist
+    on_gpu = device.type == "cuda"
+    sync = torch.cuda.synchronize if on_gpu else (lambda: None)
+    sync()
+    if world > 1:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        run()
+    sync()
+    if world > 1:
+        dist.barrier()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def headline_line(a, n_gpus, world_readback, ms_per_step, S, nsets, input_bytes, backend):
+    points = 128 * a.batch * a.lq
+    return {
+        "metric": "MSDeformAttn fwd+bwd Gpoints/s (T=5,L=4,Q=300,H=8,K=4)",
+        "value": points * n_gpus / (ms_per_step * 1e-3) / 1e9, "unit": "Gpoints/s", "n_gpus": n_gpus,
+        "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"SeqFormer-R50 T=5 {a.res} clip folded to B={a.batch}: MSDeformAttn "
+                               f"decoder call, Lq={a.lq}, S={S}, M=8, D=32, L=4, K=4, "
+                               f"loc~{'U[0,1)' if a.dist == 'U' else 'model-like'}; 1 step = fwd+bwd",
+                   "points_per_step": points, "input_rotation_sets": nsets,
+                   "input_rotation_MiB": round(nsets * input_bytes / 2**20, 1),
+                   "parallelism": f"dp{n_gpus} (clips sharded, no data-path collective)"},
+        # read back from the process group, not from the command line: 1 when no group exists
+        "rccl_world_size": world_readback, "collective_backend": backend,
+    }
+
+
+def stub_main(a, world, rank):
+    """The multi-rank skeleton of main() on CPU tensors and gloo (see StubOp)."""
+    import torch.distributed as dist
+    device = torch.device("cpu")
+    if world > 1:
+        dist.init_process_group(a.backend)
+    B, Lq = a.batch, a.lq
+    S = sum(h * w for h, w in SHAPES[a.res])
+    g = torch.Generator().manual_seed(rank)
+    s = {"value": torch.randn(B, S, 8, 32, generator=g), "out": torch.empty(B, Lq, 256)}
+    s["gv"] = torch.empty_like(s["value"])
+    op = StubOp()
+
+    def step():
+        op.fwd(s, B, Lq)
+        op.bwd(s, B, Lq)
+    for _ in range(a.warmup):
+        step()
+    elapsed = timed_region(step, a.steps, world, device)
+    readback = dist.get_world_size() if world > 1 else 1
+    if rank == 0:
+        line = headline_line(a, world, readback, elapsed * 1e3 / a.steps, S, 1, s["value"].numel() * 4, a.backend)
+        line["data"] = "stub op on CPU (launcher test only; not a measurement)"
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def self_launch(n, argv):
+    """`python bench.py --gpus N` without a torchrun environment: start N ranks of this script, one
+    process per GPU (the reference: detectron2/engine/launch.py:67-80, mp.spawn of one worker per GPU),
+    through torch.distributed.run on the loopback address; rank 0 of the children prints the line."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this host driver (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n)))
+    return subprocess.call(cmd, env=env)
+
+
+class StubOp:
+    """CPU stand-in used ONLY by the launcher test (tests/test_bench_launcher.py, --stub-op): it moves
+    the same tensors through torch so that the multi-rank plumbing of this script -- spawn, rendezvous,
+    barrier, max-over-ranks timing, rank-0 line -- runs on gloo without a GPU.  Not a fallback: without
+    --stub-op the script refuses to start when there is no GPU."""
+
+    def fwd(self, s, B, Lq):
+        s["out"].copy_(s["value"][:, :Lq].reshape(B, Lq, 256))
+
+    def bwd(self, s, B, Lq):
+        s["gv"].copy_(s["value"])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL (the product); gloo: launcher test")
+    ap.add_argument("--stub-op", action="store_true", help="launcher test on CPU: torch copies instead of the HIP op")
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--res", default="360p", choices=list(SHAPES))
@@ -340,11 +447,19 @@ def main():
                     help="skip the cache-warm forward leg (profiling runs: keeps rocprofv3's per-kernel average cold-only)")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(a.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(1, a.gpus):
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}")
+    if a.stub_op:
+        return stub_main(a, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP library is the only implementation")
+    if torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPUs visible")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
@@ -374,37 +489,10 @@ def main():
     graph = capture(fns)
     for _ in range(math.ceil(a.warmup / chunk)):
         graph.replay()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps // chunk):
-        graph.replay()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = timed_region(graph.replay, a.steps // chunk, world, device)
     ms_per_step = elapsed * 1e3 / a.steps
-    value = points * n_gpus / (ms_per_step * 1e-3) / 1e9
-
-    line = {
-        "metric": "MSDeformAttn fwd+bwd Gpoints/s (T=5,L=4,Q=300,H=8,K=4)",
-        "value": value, "unit": "Gpoints/s", "n_gpus": n_gpus, "steps": a.steps,
-        "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"SeqFormer-R50 T=5 {res} clip folded to B={B}: MSDeformAttn "
-                               f"decoder call, Lq={Lq}, S={S}, M=8, D=32, L=4, K=4, "
-                               f"loc~{'U[0,1)' if a.dist == 'U' else 'model-like'}; 1 step = fwd+bwd",
-                   "points_per_step": points, "input_rotation_sets": nsets,
-                   "input_rotation_MiB": round(nsets * input_bytes / 2**20, 1),
-                   "parallelism": f"dp{n_gpus} (clips sharded, no data-path collective)"},
-    }
+    line = headline_line(a, n_gpus, dist.get_world_size() if world > 1 else 1, ms_per_step, S, nsets, input_bytes,
+                         "nccl (RCCL)")
 
     # ---- model-level leg: SeqFormer-R50 T=5 360p training step under DDP (all ranks) ----------
     model_leg = None

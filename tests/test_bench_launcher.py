@@ -1,0 +1,39 @@
+"""bench.py --gpus N must start N ranks by itself (it used to ignore --gpus) -- the
+reference's launcher, detectron2/engine/launch.py:67-126, spawns one worker per GPU.  The launcher
+path runs here on gloo with the CPU stub op; the numbers mean nothing, the plumbing is the test."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(*args, env_extra=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True,
+                       timeout=600, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, f"expected ONE JSON line from rank 0, got {len(lines)}:\n{p.stdout[-2000:]}"
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("n", [1, 2])
+def test_gpus_flag_starts_that_many_ranks(n):
+    line = run_bench("--gpus", str(n), "--backend", "gloo", "--stub-op", "--steps", "3", "--warmup", "1")
+    assert line["n_gpus"] == n
+    assert line["rccl_world_size"] == n            # read back from the process group
+    assert line["steps"] == 3 and line["warmup"] == 1 and line["scaling"] == "weak"
+    assert line["config"]["parallelism"].startswith(f"dp{n}")
+    assert line["value"] > 0 and line["ms_per_step"] > 0
+
+
+def test_world_size_mismatch_is_refused():
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--stub-op"], capture_output=True,
+                       text=True, timeout=300, env=env, cwd=ROOT)
+    assert p.returncode != 0 and "WORLD_SIZE=2" in (p.stderr + p.stdout)

@@ -108,10 +108,17 @@ def test_unsupported_cases_are_reported_not_guessed():
     dev = "cuda:0"
     value, offsets, logits, ref, _ = [t.to(dev) for t in make(2, 9, 2, 1, seed=1)]
     shapes_t, lsi = level_tensors(dev)
-    assert msda_ext.fused_supported(value, offsets, logits, ref, lsi)
-    assert not msda_ext.fused_supported(value, offsets, logits, ref, lsi.clone())          # not tagged as packed
-    assert not msda_ext.fused_supported(value.double(), offsets, logits, ref, lsi)
-    assert not msda_ext.fused_supported(value[..., :16].contiguous(), offsets, logits, ref, lsi)
+    assert msda_ext.fused_supported(value, shapes_t, offsets, logits, ref, lsi)
+    assert not msda_ext.fused_supported(value, shapes_t, offsets, logits, ref, lsi.clone())          # not tagged as packed
+    # a tagged pair built for ANOTHER pyramid must not be trusted (grad_value would stay uninitialised)
+    from vnext_amd.ops.functions import level_tensors as lt
+    other_shapes, other_lsi = lt([(5, 7), (3, 3), (2, 2), (1, 1)], dev)
+    assert not msda_ext.fused_supported(value, other_shapes, offsets, logits, ref, other_lsi)
+    with pytest.raises(RuntimeError, match="packed levels"):
+        msda_ext.ms_deform_attn_fused_backward(value, other_shapes, other_lsi, offsets, logits, ref,
+                                               torch.zeros(value.shape[0], offsets.shape[1], 256, device=dev))
+    assert not msda_ext.fused_supported(value.double(), shapes_t, offsets, logits, ref, lsi)
+    assert not msda_ext.fused_supported(value[..., :16].contiguous(), shapes_t, offsets, logits, ref, lsi)
     with pytest.raises(RuntimeError, match="built for 32-channel heads"):
         msda_ext.ms_deform_attn_fused_forward(value[..., :16].contiguous(), shapes_t, lsi, offsets, logits, ref)
 

@@ -84,8 +84,11 @@ def dynamic_k_matching(cost, iou, n_candidate_k):
     """-> matching [Q, n] (0/1); `cost` is modified in place exactly as the reference does
     (matcher.py:126-160, pos_neg_select.py:154-185)."""
     ks = torch.topk(iou, n_candidate_k, dim=0)[0].sum(0).int().clamp(min=1)
-    rank = cost.argsort(dim=0).argsort(dim=0)
-    M = (rank < ks[None]).to(cost.dtype)                  # the k cheapest queries of every box
+    # per box, the reference's own call (matcher.py:138-141): torch.topk's choice among tied costs is
+    # what decides the assignment there, so it is what runs here (host tensors, a handful of columns)
+    M = torch.zeros_like(cost)
+    for g in range(cost.shape[1]):
+        M[torch.topk(cost[:, g], k=int(ks[g]), largest=False)[1], g] = 1.0
     multi = M.sum(1) > 1                                   # queries claimed by several boxes
     if multi.any():
         keep = cost[multi].argmin(1)
@@ -159,30 +162,28 @@ def select_pos_neg_masks(ref_boxes, ref_prob, ref_targets, rng=_random):
     `rng.sample` (host RNG, same call sequence as the reference)."""
     out = []
     ref_boxes, ref_prob = _host32(ref_boxes), _host32(ref_prob)
-    threads = _one_thread()
-    threads.__enter__()
-    for i, t in enumerate(ref_targets):
-        valid = t["valid"].cpu().bool()
-        Q = ref_boxes.shape[1]
-        inst = torch.nonzero(valid).flatten()
-        I = len(inst)
-        pos = torch.zeros(Q, I, dtype=torch.bool)
-        neg = torch.zeros(Q, I, dtype=torch.bool)
-        aux = torch.zeros(Q, I, dtype=torch.bool)
-        if I > 0:
-            gt = t["boxes"].cpu().reshape(-1, 4)[valid].to(ref_boxes)
-            cost, iou = ota_cost(ref_boxes[i], ref_prob[i], gt, t["labels"].cpu()[valid])
-            pos = dynamic_k_matching(cost, iou, 10) > 0
-            neg = ~(dynamic_k_matching(cost, iou, 100) > 0)       # same (already repaired) cost matrix
-            for c in range(I):
-                P, N = int(pos[:, c].sum()), int(neg[:, c].sum())
-                k = 10 if P == 0 else (N if P * 10 >= N else P * 10)
-                picked = rng.sample(list(range(N)), k)
-                neg_rows = torch.nonzero(neg[:, c]).flatten()
-                aux[:, c] = pos[:, c]
-                aux[neg_rows[picked], c] = True
-        out.append((inst, pos, neg, aux))
-    threads.__exit__()
+    with _one_thread():
+        for i, t in enumerate(ref_targets):
+            valid = t["valid"].cpu().bool()
+            Q = ref_boxes.shape[1]
+            inst = torch.nonzero(valid).flatten()
+            I = len(inst)
+            pos = torch.zeros(Q, I, dtype=torch.bool)
+            neg = torch.zeros(Q, I, dtype=torch.bool)
+            aux = torch.zeros(Q, I, dtype=torch.bool)
+            if I > 0:
+                gt = t["boxes"].cpu().reshape(-1, 4)[valid].to(ref_boxes)
+                cost, iou = ota_cost(ref_boxes[i], ref_prob[i], gt, t["labels"].cpu()[valid])
+                pos = dynamic_k_matching(cost, iou, 10) > 0
+                neg = ~(dynamic_k_matching(cost, iou, 100) > 0)       # same (already repaired) cost matrix
+                for c in range(I):
+                    P, N = int(pos[:, c].sum()), int(neg[:, c].sum())
+                    k = 10 if P == 0 else (N if P * 10 >= N else P * 10)
+                    picked = rng.sample(list(range(N)), k)
+                    neg_rows = torch.nonzero(neg[:, c]).flatten()
+                    aux[:, c] = pos[:, c]
+                    aux[neg_rows[picked], c] = True
+            out.append((inst, pos, neg, aux))
     return out
 
 

@@ -134,7 +134,18 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
 
 
 # ---------------------------------------------------------------------------------- fused prologue
-def fused_supported(value, sampling_offsets, attention_logits, reference_points, level_start_index):
+def packed_promise_holds(spatial_shapes, level_start_index, spatial_size) -> bool:
+    """The record-fed grad_value kernel writes every row exactly once only when the levels tile
+    [0, S) back to back; with the promise flag set the library does not re-check on the device.  So
+    the promise is only passed down when it can be verified on the HOST: both tensors must carry the
+    tags `level_tensors` leaves on them and the level sizes must add up to THIS value's length (a
+    tagged pair built for another S would otherwise leave grad_value uninitialised)."""
+    hw = getattr(spatial_shapes, "_vnx_hw", None)
+    return bool(getattr(level_start_index, "_vnx_levels_packed", False)) and hw is not None and \
+        sum(h * w for h, w in hw) == int(spatial_size)
+
+
+def fused_supported(value, spatial_shapes, sampling_offsets, attention_logits, reference_points, level_start_index):
     """True when vnx_msda_fused_* can take these tensors (else: compose the unfused op)."""
     if not (value.is_cuda and value.dim() == 4 and value.shape[-1] == 32):
         return False
@@ -142,13 +153,21 @@ def fused_supported(value, sampling_offsets, attention_logits, reference_points,
         return False
     if sampling_offsets.shape[0] != value.shape[0] or reference_points.shape[-1] not in (2, 4):
         return False
-    if not getattr(level_start_index, "_vnx_levels_packed", False):
+    if not packed_promise_holds(spatial_shapes, level_start_index, value.shape[1]):
         return False
     q = sampling_offsets.dtype
     if attention_logits.dtype != q or reference_points.dtype != q:
         return False
     return (value.dtype == torch.float32 and q == torch.float32) or \
         (value.dtype == torch.bfloat16 and q in (torch.float32, torch.bfloat16))
+
+
+def _require_packed(spatial_shapes, level_start_index, spatial_size):
+    if not packed_promise_holds(spatial_shapes, level_start_index, spatial_size):
+        raise RuntimeError(
+            "ms_deform_attn_fused: the fused kernels need packed levels whose sizes add up to value.shape[1], verifiable "
+            "on the host -- pass the (spatial_shapes, level_start_index) pair of vnext_amd.ops.functions.level_tensors "
+            "built for this feature pyramid (or use the unfused op)")
 
 
 def _fused_dims(value, sampling_offsets, reference_points):
@@ -169,6 +188,7 @@ def ms_deform_attn_fused_forward(value, spatial_shapes, level_start_index, sampl
                ("reference_points", reference_points)]
     _check_inputs(tensors)
     B, S, M, D, L, Lq, P, ref_dim, ref_div = _fused_dims(value, sampling_offsets, reference_points)
+    _require_packed(spatial_shapes, level_start_index, S)
     out = torch.empty((B, Lq, M * D), dtype=value.dtype, device=value.device)
     with torch.cuda.device(value.device):
         st = _lib.lib().vnx_msda_fused_forward(
@@ -188,6 +208,7 @@ def ms_deform_attn_fused_backward(value, spatial_shapes, level_start_index, samp
                ("reference_points", reference_points), ("grad_output", grad_output)]
     _check_inputs(tensors)
     B, S, M, D, L, Lq, P, ref_dim, ref_div = _fused_dims(value, sampling_offsets, reference_points)
+    _require_packed(spatial_shapes, level_start_index, S)
     gv = torch.empty_like(value)
     goff = torch.empty_like(sampling_offsets)
     glog = torch.empty_like(attention_logits)

@@ -27,8 +27,9 @@ class MSDeformAttnFunction(Function):
         ctx.im2col_step = im2col_step
         # Callers that built level_start_index as the running sum of H*W (every caller in
         # the reference does) may tag the tensor; the backward then skips the general-path
-        # launches.  Untagged tensors stay correct: the library checks on the device.
-        ctx.levels_packed = bool(getattr(value_level_start_index, "_vnx_levels_packed", False))
+        # launches.  Untagged tensors -- or tagged ones whose sizes do not add up to THIS value's
+        # length -- stay correct: the library checks on the device.
+        ctx.levels_packed = MSDA.packed_promise_holds(value_spatial_shapes, value_level_start_index, value.shape[1])
         output = MSDA.ms_deform_attn_forward(
             value, value_spatial_shapes, value_level_start_index, sampling_locations,
             attention_weights, ctx.im2col_step)

@@ -97,7 +97,7 @@ class _MSDeformAttnBase(nn.Module):
             # with fp32 offsets / logits / references.
             offsets, logits, reference = offsets.float(), logits.float(), reference.float()
         reference = reference.contiguous()
-        if not msda_ext.fused_supported(value, offsets, logits, reference, level_start_index):
+        if not msda_ext.fused_supported(value, spatial_shapes, offsets, logits, reference, level_start_index):
             return None
         return MSDeformAttnFusedFunction.apply(value.contiguous(), spatial_shapes, level_start_index,
                                                offsets.contiguous(), logits.contiguous(), reference)
