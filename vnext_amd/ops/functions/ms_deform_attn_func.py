@@ -18,6 +18,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from ... import msda_ext as MSDA
+from ...msda_ext import packed_promise_holds
 
 
 class MSDeformAttnFunction(Function):
@@ -29,7 +30,7 @@ class MSDeformAttnFunction(Function):
         # the reference does) may tag the tensor; the backward then skips the general-path
         # launches.  Untagged tensors -- or tagged ones whose sizes do not add up to THIS value's
         # length -- stay correct: the library checks on the device.
-        ctx.levels_packed = MSDA.packed_promise_holds(value_spatial_shapes, value_level_start_index, value.shape[1])
+        ctx.levels_packed = packed_promise_holds(value_spatial_shapes, value_level_start_index, value.shape[1])
         output = MSDA.ms_deform_attn_forward(
             value, value_spatial_shapes, value_level_start_index, sampling_locations,
             attention_weights, ctx.im2col_step)
