@@ -37,22 +37,59 @@ def _stale() -> bool:
     return any(os.path.getmtime(p) > t for p in deps)
 
 
+OBJ_DIR = os.path.join(LIB_DIR, "obj")
+COMPILE_FLAGS = [f for f in HIPCC_FLAGS if f != "-shared"]
+
+
+def _headers() -> list[str]:
+    return glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "..", "include", "*.h")) + \
+        [os.path.abspath(__file__)]
+
+
 def build_hip(force: bool = False, verbose: bool = False, out: str | None = None, defines=()) -> str:
-    """`out` / `defines` build an experiment copy (e.g. -DVNX_FWD_WPE=4) beside the product library;
-    `VNX_HIP_LIB=<path>` makes vnext_amd._lib load it (development aid, tools/wpe_sweep.py)."""
+    """One object per source file, compiled in parallel and cached by mtime (a one-file edit rebuilds
+    in seconds), then linked.  `out` / `defines` build an experiment copy (e.g. -DVNX_FWD_WPE=4) beside
+    the product library; `VNX_HIP_LIB=<path>` makes vnext_amd._lib load it (development aid)."""
+    from concurrent.futures import ThreadPoolExecutor
     target = out or LIB_PATH
     if out is None and not force and not _stale():
         return LIB_PATH
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    os.makedirs(os.path.dirname(target), exist_ok=True)
+    obj_dir = OBJ_DIR if not defines else OBJ_DIR + "_" + "_".join(d.replace("=", "-") for d in defines)
+    os.makedirs(obj_dir, exist_ok=True)
+    hdr_time = max(os.path.getmtime(h) for h in _headers())
+
+    def compile_one(src):
+        obj = os.path.join(obj_dir, os.path.basename(src) + ".o")
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), hdr_time):
+            return obj
+        cmd = [hipcc] + COMPILE_FLAGS + [f"-D{d}" for d in defines] + ["-c", "-o", obj, src]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+        return obj
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, sources()))
     tmp = target + ".tmp"
-    cmd = [hipcc] + HIPCC_FLAGS + [f"-D{d}" for d in defines] + ["-o", tmp] + sources()
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd)
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs)
     os.replace(tmp, target)
     return target
 
 
+def build_kbench(verbose: bool = False) -> str:
+    """tools/kbench.bin: the stand-alone timing / cross-check harness (development tool)."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    src = os.path.join(HERE, "..", "tools", "kbench.hip")
+    out = os.path.join(HERE, "..", "tools", "kbench.bin")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-o", out, src, "-L" + LIB_DIR, "-lvnext_hip",
+           "-Wl,-rpath,$ORIGIN/../vnext_amd/lib"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == "__main__":
     print(build_hip(force="--force" in sys.argv, verbose=True))
+    if "--kbench" in sys.argv:
+        print(build_kbench(verbose=True))

@@ -43,6 +43,9 @@ int msda_backward_gv_d32(int, int, const int64_t*, const int64_t*, const void*, 
                          const void*, void*, MsdaDims, int variant, hipStream_t);
 int zero_if_not_packed(const int64_t*, const int64_t*, int, int, void*, size_t, hipStream_t);
 bool msda_d32_fwd_supported(int vdt, int ldt, const MsdaDims& d);
+bool msda_tile_fwd_supported(int vdt, int ldt, const MsdaDims& d);
+int msda_forward_tile(const void*, const int64_t*, const int64_t*, const void*, const void*, void*, MsdaDims,
+                      const FusedArgs*, int debug, hipStream_t);
 bool msda_d32_bwd_supported(int vdt, int ldt, const MsdaDims& d);
 int msda_forward_d32(int, int, const void*, const int64_t*, const int64_t*, const void*,
                      const void*, void*, MsdaDims, int variant, hipStream_t);
@@ -197,6 +200,16 @@ int vnx_debug_wall_clock_khz(void) {
 }
 int vnx_get_kernel_variant(void) { return g_kernel_variant; }
 
+// The spatially tiled, LDS-staged forward (msda_d32_tile.hip) takes the calls whose queries are the
+// pixels of the pyramid -- the encoder's -- which the host can only recognise by Lq == S (the level
+// sizes live on the device); the kernel itself checks the rest and stays correct either way.
+// Variants 700..702 force it (701 / 702: with phase stamps), 710 keeps it off.
+static bool use_tile_forward(int vdt, int ldt, const MsdaDims& d, int variant) {
+  if (!msda_tile_fwd_supported(vdt, ldt, d)) return false;
+  if (variant >= 700 && variant <= 702) return true;
+  return variant == 0 && d.Lq == d.S && d.S >= 1024;
+}
+
 int vnx_msda_forward(int value_dtype, int loc_dtype, const void* value,
                      const int64_t* spatial_shapes, const int64_t* level_start_index,
                      const void* sampling_loc, const void* attn_weight, void* output, int batch,
@@ -213,6 +226,9 @@ int vnx_msda_forward(int value_dtype, int loc_dtype, const void* value,
   }
   hipStream_t stream = (hipStream_t)hip_stream;
   const int variant = g_kernel_variant;
+  if (use_tile_forward(value_dtype, loc_dtype, d, variant))
+    return msda_forward_tile(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, output, d, nullptr,
+                             variant >= 700 && variant <= 702 ? variant - 700 : 0, stream);
   if (variant != 1 && msda_d32_fwd_supported(value_dtype, loc_dtype, d))
     return msda_forward_d32(value_dtype, loc_dtype, value, spatial_shapes, level_start_index,
                             sampling_loc, attn_weight, output, d, variant, stream);
@@ -413,6 +429,11 @@ int vnx_msda_fused_forward(int value_dtype, int query_dtype, const void* value, 
       !reference_points || !output) {
     set_error("vnx_msda_fused_forward: null pointer argument");
     return VNX_ERR_INVALID_ARGUMENT;
+  }
+  if (use_tile_forward(value_dtype, query_dtype, d, g_kernel_variant)) {
+    const FusedArgs fa{reference_points, nullptr, ref_dim, reference_batch_div};
+    return msda_forward_tile(value, spatial_shapes, level_start_index, sampling_offsets, attention_logits, output, d, &fa, 0,
+                             (hipStream_t)hip_stream);
   }
   return msda_fused_d32(false, value_dtype, query_dtype, value, spatial_shapes, level_start_index, sampling_offsets,
                         attention_logits, nullptr, output, nullptr, d, nullptr, reference_points, nullptr, ref_dim,

@@ -35,20 +35,6 @@ typedef float float4_t __attribute__((ext_vector_type(4)));
 typedef uint32_t uint4_t __attribute__((ext_vector_type(4)));
 typedef uint32_t uint2_t __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes) {
-  // wave-uniform inputs only (callers pass readfirstlane'd values)
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, int(bytes), 0x00020000);
-}
-
-// Descriptor over [base, base+bytes) whose words the compiler can prove wave-uniform
-// (readfirstlane of both pointer halves; through uint32_t so nothing sign-extends).
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* base, uint32_t bytes) {
-  const uint32_t lo = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(uintptr_t(base)))));
-  const uint32_t hi = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(uintptr_t(base) >> 32))));
-  const uint32_t n = uint32_t(__builtin_amdgcn_readfirstlane(int(bytes)));
-  return make_rsrc(reinterpret_cast<const void*>(uintptr_t(lo) | (uintptr_t(hi) << 32)), n);
-}
-
 // 4 consecutive channels of one tap as fp32
 template <typename TV>
 __device__ __forceinline__ float4_t load_tap(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off);
@@ -139,13 +125,6 @@ __device__ __forceinline__ int gv_rows_per_unit(int n, int units_min) {
 // two Linear outputs and the reference points instead: `loc` = raw offsets, `attn` = raw
 // logits, and the softmax (a 16-lane row per (query, head): L*P == 16) and the location
 // arithmetic happen in the one-lane-per-sample phase that decoded them anyway.
-struct FusedArgs {
-  const void* reference;   // [B / ref_div, Lq, L, ref_dim], same element type as the offsets
-  float* grad_reference;   // [B, Lq, L, 2] fp32, zero-filled, accumulated over heads; or null
-  int ref_dim;             // 2 or 4
-  int ref_div;             // consecutive batch elements sharing one reference row (frames of a clip)
-};
-
 __device__ __forceinline__ float row16_max(float v) {
 #pragma unroll
   for (int k = 1; k < 16; k <<= 1) v = fmaxf(v, __shfl_xor(v, k, 16));

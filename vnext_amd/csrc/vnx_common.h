@@ -94,6 +94,30 @@ inline size_t gv_unit_ids_offset(const MsdaDims& d) {
 }
 
 
+// ---- buffer descriptors ---------------------------------------------------------------------
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+  // wave-uniform inputs only (callers pass readfirstlane'd values)
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, int(bytes), 0x00020000);
+}
+
+// Descriptor over [base, base+bytes) whose words the compiler can prove wave-uniform
+// (readfirstlane of both pointer halves; through uint32_t so nothing sign-extends).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* base, uint32_t bytes) {
+  const uint32_t lo = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(uintptr_t(base)))));
+  const uint32_t hi = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(uintptr_t(base) >> 32))));
+  const uint32_t n = uint32_t(__builtin_amdgcn_readfirstlane(int(bytes)));
+  return make_rsrc(reinterpret_cast<const void*>(uintptr_t(lo) | (uintptr_t(hi) << 32)), n);
+}
+
+// The fused prologue's extra arguments (msda_d32.hip, msda_d32_tile.hip)
+struct FusedArgs {
+  const void* reference;   // [B / ref_div, Lq, L, ref_dim], same element type as the offsets
+  float* grad_reference;   // [B, Lq, L, 2] fp32, zero-filled, accumulated over heads; or null
+  int ref_dim;             // 2 or 4
+  int ref_div;             // consecutive batch elements sharing one reference row (frames of a clip)
+};
+
+
 inline int elem_size(int dtype) {
   switch (dtype) {
     case VNX_F32: return 4;
