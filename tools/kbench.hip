@@ -134,6 +134,36 @@ __global__ void dma_probe(const float* __restrict__ src, float* __restrict__ dst
   float4_t v = *reinterpret_cast<float4_t*>(smem + threadIdx.x * 16);
   *reinterpret_cast<float4_t*>(dst + threadIdx.x * 4) = v;
 }
+// ---- address-pattern probe: 128-B lines at a fixed offset inside every 1-KiB record (one head's rows of a
+// [B, S, 8, 32] fp32 tensor), read once each in a scattered order, per offset -----------------------------------
+__global__ void stride_probe(const float4_t* __restrict__ base, size_t n_rec, int sub, float* sink, uint32_t seed) {
+  const size_t set = (blockIdx.x * size_t(blockDim.x) + threadIdx.x) >> 3;      // one 8-lane set per record
+  const int ch = threadIdx.x & 7;
+  float4_t acc = {0.f, 0.f, 0.f, 0.f};
+  const size_t sets = (size_t(gridDim.x) * blockDim.x) >> 3;
+  for (size_t i = set; i < n_rec; i += sets) {
+    const size_t rec = (i * 2654435761ull + seed) % n_rec;                        // scattered, every record once
+    acc += base[rec * 64 + sub * 8 + ch];
+  }
+  if (acc.x == 123.456f) sink[0] = acc.y;
+}
+static void run_stride_probe() {
+  const size_t n_rec = size_t(384) << 10;       // 384 Ki records x 1 KiB = 384 MiB (> Infinity Cache)
+  float4_t* buf; float* sink;
+  CK(hipMalloc(&buf, n_rec * 1024)); CK(hipMalloc(&sink, 4));
+  CK(hipMemset(buf, 0, n_rec * 1024));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int rep = 0; rep < 2; ++rep)
+    for (int sub = 0; sub < 8; ++sub) {
+      CK(hipEventRecord(e0));
+      hipLaunchKernelGGL(stride_probe, dim3(4096), dim3(256), 0, 0, buf, n_rec, sub, sink, 12345u + rep);
+      CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      if (rep) printf("[stride-probe] offset %4d B of every 1 KiB: %7.1f us  %5.2f TB/s (128-B lines)\n", sub * 128, ms * 1e3,
+                      n_rec * 128.0 / (ms * 1e-3) / 1e12);
+    }
+  CK(hipFree(buf)); CK(hipFree(sink));
+}
 static void run_dma_probe() {
   const int n = 64 * 32;
   std::vector<float> h(n);
@@ -158,6 +188,9 @@ static void run_dma_probe() {
 }
 
 extern "C" int vnx_debug_read_tile_stamps(unsigned long long* host, int n);
+extern "C" void vnx_debug_arm_stamps(void* buf, long long n_words);
+extern "C" int vnx_debug_stamp_regions(int* kinds, long long* offsets, long long* blocks, int n);
+extern "C" int vnx_debug_read_rec_stamps(unsigned long long* host, int n);
 struct Set {
   float *value, *loc, *attn, *go, *out, *gv, *gl, *ga, *off, *logit;
   void* ws;
@@ -165,8 +198,8 @@ struct Set {
 
 int main(int argc, char** argv) {
   std::string shape = "dec360", dist = "U", op = "fwd", variants = "0";
-  int B = 5, lq = 0, inner = 24, reps = 15;
-  bool check = false, dma = false, stamps = false;
+  int B = 5, lq = 0, inner = 24, reps = 15, voff = 0;   // voff: floats added to every `value` base (alignment experiments)
+  bool check = false, dma = false, stamps = false, timeline = false, hbm = false;
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
     auto next = [&]() { return std::string(i + 1 < argc ? argv[++i] : ""); };
@@ -178,12 +211,16 @@ int main(int argc, char** argv) {
     else if (a == "--lq") lq = atoi(next().c_str());
     else if (a == "--inner") inner = atoi(next().c_str());
     else if (a == "--reps") reps = atoi(next().c_str());
+    else if (a == "--voff") voff = atoi(next().c_str());
     else if (a == "--check") check = true;
     else if (a == "--dma-test") dma = true;
     else if (a == "--stamps") stamps = true;
+    else if (a == "--timeline") timeline = true;
+    else if (a == "--hbm-probe") hbm = true;
     else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 1; }
   }
   if (dma) run_dma_probe();
+  if (hbm) { run_stride_probe(); return 0; }
   const bool p720 = shape.size() >= 3 && shape.substr(shape.size() - 3) == "720";
   const int HW360[4][2] = {{48, 80}, {24, 40}, {12, 20}, {6, 10}}, HW720[4][2] = {{92, 160}, {46, 80}, {23, 40}, {12, 20}};
   Pyr py;
@@ -212,7 +249,7 @@ int main(int argc, char** argv) {
   std::vector<Set> sets(nsets);
   for (int i = 0; i < nsets; ++i) {
     Set& s = sets[i];
-    CK(hipMalloc(&s.value, n_value * 4)); CK(hipMalloc(&s.loc, n_s * 8)); CK(hipMalloc(&s.attn, n_s * 4));
+    CK(hipMalloc(&s.value, n_value * 4 + 4096)); s.value += voff; CK(hipMalloc(&s.loc, n_s * 8)); CK(hipMalloc(&s.attn, n_s * 4));
     CK(hipMalloc(&s.go, n_out * 4)); CK(hipMalloc(&s.out, n_out * 4)); CK(hipMalloc(&s.gv, n_value * 4));
     CK(hipMalloc(&s.gl, n_s * 8)); CK(hipMalloc(&s.ga, n_s * 4)); CK(hipMalloc(&s.ws, std::max<size_t>(ws_bytes, 256)));
     hipLaunchKernelGGL(fill_gauss, dim3(2048), dim3(256), 0, 0, s.value, n_value, 17u + i);
@@ -305,6 +342,81 @@ int main(int argc, char** argv) {
       printf("  variant %4d %s: cold %8.2f us %6.2f TB/s %7.2f Gpt/s | warm %8.2f us %6.2f TB/s%s\n", v, is_bwd ? "bwd" : "fwd", cold,
              by / cold / 1e6, n_s / cold / 1e3, warm, by / warm / 1e6, chk);
       fflush(stdout);
+    }
+  }
+  if (timeline) {   // per-workgroup {start, end} of the forward kernel on cold inputs (100 MHz wall clock, 10 ns ticks)
+    size_t pos2 = 0;
+    while (pos2 < variants.size()) {
+      size_t c = variants.find(',', pos2);
+      if (c == std::string::npos) c = variants.size();
+      const int v = atoi(variants.substr(pos2, c - pos2).c_str());
+      pos2 = c + 1;
+      vnx_set_kernel_variant(v);
+      const long long words = 2ll * 65536 * (nsets + 1);
+      unsigned long long* buf;
+      CK(hipMalloc(&buf, words * 8)); CK(hipMemset(buf, 0, words * 8));
+      vnx_debug_arm_stamps(buf, words);
+      for (int i = 0; i < nsets; ++i) { if (op == "bwd") bwd(sets[i]); else fwd(sets[i]); }
+      CK(hipStreamSynchronize(st));
+      int kinds[64]; long long offs[64], nblk[64];
+      const int nreg = vnx_debug_stamp_regions(kinds, offs, nblk, 64);
+      vnx_debug_arm_stamps(nullptr, 0);
+      if (op == "bwd") {   // grad_value kernel: fixed stamp array, slots 0 (start) and 12 (end), variant 412
+        vnx_set_kernel_variant(412);
+        for (int i = 0; i < nsets; ++i) bwd(sets[i]);
+        CK(hipStreamSynchronize(st));
+        std::vector<unsigned long long> hs(4096 * 16);
+        vnx_debug_read_rec_stamps(hs.data(), 4096 * 16);
+        std::vector<double> st0, dur, en;
+        unsigned long long t0 = ~0ull;
+        for (int w = 0; w < 4096; ++w) if (hs[w * 16 + 12] > hs[w * 16]) t0 = std::min(t0, hs[w * 16]);
+        double hm[8] = {0}, hx[8] = {0}; int hn[8] = {0};
+        for (int w = 0; w < 4096; ++w) if (hs[w * 16 + 12] > hs[w * 16]) {
+          st0.push_back((hs[w * 16] - t0) * 0.01); en.push_back((hs[w * 16 + 12] - t0) * 0.01);
+          dur.push_back((hs[w * 16 + 12] - hs[w * 16]) * 0.01);
+          hm[w % 8] += en.back(); hx[w % 8] = std::max(hx[w % 8], en.back()); ++hn[w % 8];
+        }
+        std::sort(st0.begin(), st0.end()); std::sort(dur.begin(), dur.end()); std::sort(en.begin(), en.end());
+        auto pc = [](const std::vector<double>& x, double p) { return x.empty() ? 0.0 : x[std::min(x.size() - 1, size_t(p * x.size()))]; };
+        printf("  grad_value kernel (%zu workgroups, us): start p50 %.2f p90 %.2f max %.2f | duration p10 %.2f p50 %.2f p90 %.2f max %.2f | end p50 %.2f p90 %.2f max %.2f\n    end by blockIdx %% 8 (mean/max):",
+               st0.size(), pc(st0, .5), pc(st0, .9), st0.empty() ? 0 : st0.back(), pc(dur, .1), pc(dur, .5), pc(dur, .9), dur.empty() ? 0 : dur.back(),
+               pc(en, .5), pc(en, .9), en.empty() ? 0 : en.back());
+        for (int k = 0; k < 8; ++k) printf(" %.1f/%.1f", hm[k] / std::max(hn[k], 1), hx[k]);
+        printf("\n");
+        vnx_set_kernel_variant(v);
+      }
+      if (nreg > 0) {
+        const int r = std::min(nreg, 64) - 1;
+        std::vector<unsigned long long> h(2 * nblk[r]);
+        CK(hipMemcpy(h.data(), buf + offs[r], 16 * nblk[r], hipMemcpyDeviceToHost));
+        std::vector<double> st0, dur, en;
+        unsigned long long t0 = ~0ull;
+        for (long long w = 0; w < nblk[r]; ++w) if (h[2 * w]) t0 = std::min(t0, h[2 * w]);
+        for (long long w = 0; w < nblk[r]; ++w) if (h[2 * w]) {
+          st0.push_back((h[2 * w] - t0) * 0.01); en.push_back((h[2 * w + 1] - t0) * 0.01); dur.push_back((h[2 * w + 1] - h[2 * w]) * 0.01);
+        }
+        std::sort(st0.begin(), st0.end()); std::sort(dur.begin(), dur.end()); std::sort(en.begin(), en.end());
+        auto pc = [](const std::vector<double>& x, double p) { return x.empty() ? 0.0 : x[std::min(x.size() - 1, size_t(p * x.size()))]; };
+        {   // who are the stragglers?  end time by head (blockIdx % 8 = XCD) and by position in the grid
+          double hm[8] = {0}, hx[8] = {0}; int hn[8] = {0};
+          const int nseg = 10; double sm[nseg] = {0}, sx[nseg] = {0}; int sn[nseg] = {0};
+          for (long long w = 0; w < nblk[r]; ++w) if (h[2 * w]) {
+            const double e = (h[2 * w + 1] - t0) * 0.01;
+            const int hd = int(w % 8), sg = int(w * nseg / nblk[r]);   // hd = blockIdx % 8 (the XCD)
+            hm[hd] += e; hx[hd] = std::max(hx[hd], e); ++hn[hd];
+            sm[sg] += e; sx[sg] = std::max(sx[sg], e); ++sn[sg];
+          }
+          printf("    end by head  (mean/max):");
+          for (int k = 0; k < 8; ++k) printf(" %.1f/%.1f", hm[k] / std::max(hn[k], 1), hx[k]);
+          printf("\n    end by grid tenth (mean/max):");
+          for (int k = 0; k < nseg; ++k) printf(" %.1f/%.1f", sm[k] / std::max(sn[k], 1), sx[k]);
+          printf("\n");
+        }
+        printf("  timeline variant %d (%lld workgroups, us): start p10 %.2f p50 %.2f p90 %.2f max %.2f | duration p10 %.2f p50 %.2f p90 %.2f max %.2f | end p10 %.2f p50 %.2f p90 %.2f max %.2f\n",
+               v, nblk[r], pc(st0, .1), pc(st0, .5), pc(st0, .9), st0.back(), pc(dur, .1), pc(dur, .5), pc(dur, .9), dur.back(), pc(en, .1), pc(en, .5),
+               pc(en, .9), en.back());
+      }
+      CK(hipFree(buf));
     }
   }
   for (int which = 701; stamps && which <= 702; ++which) {   // phase stamps of the tiled forward (701: first item of

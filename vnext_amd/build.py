@@ -71,6 +71,7 @@ def build_hip(force: bool = False, verbose: bool = False, out: str | None = None
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
         objs = list(ex.map(compile_one, sources()))
     tmp = target + ".tmp"
+    os.makedirs(os.path.dirname(os.path.abspath(target)), exist_ok=True)
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs)
     os.replace(tmp, target)
     return target

@@ -34,6 +34,7 @@ constexpr uint32_t kTapOutsideElem = 0x20000000u;
 typedef float float4_t __attribute__((ext_vector_type(4)));
 typedef uint32_t uint4_t __attribute__((ext_vector_type(4)));
 typedef uint32_t uint2_t __attribute__((ext_vector_type(2)));
+typedef float float2_t __attribute__((ext_vector_type(2)));
 
 // 4 consecutive channels of one tap as fp32
 template <typename TV>
@@ -168,6 +169,10 @@ __device__ __forceinline__ void fused_decode(const TL* __restrict__ raw_off, con
 
 // VNX_FWD_WPE / VNX_K1_WPE: amdgpu_waves_per_eu hint (second __launch_bounds__ argument); the
 // register-allocation and scheduling heuristics follow it, and the measured best is built in.
+// VNX_FWD_BATCH: samples whose 4 row loads each are issued before the first use (4: 16 loads in flight)
+#ifndef VNX_FWD_BATCH
+#define VNX_FWD_BATCH 4
+#endif
 #ifndef VNX_FWD_WPE
 #define VNX_FWD_WPE 0
 #endif
@@ -184,7 +189,10 @@ __device__ __forceinline__ void fused_decode(const TL* __restrict__ raw_off, con
 #else
 #define VNX_K1_BOUNDS(n) __launch_bounds__(n)
 #endif
-template <typename TV, typename TL, int QPW, int WPB, int LP_T, bool FUSED = false>
+// PF: stream this wave's share of the head's rows towards L2 while the locations are in flight
+// (see "phase 0" below); built for the one-pass case (QPW * L*P <= 64), unfused.
+constexpr int kPfSteps = 3;       // LDS-DMA instructions per wave, 32 rows (2 x 64-B halves) each
+template <typename TV, typename TL, int QPW, int WPB, int LP_T, bool FUSED = false, bool PF = false>
 __global__ void VNX_FWD_BOUNDS(64 * WPB)
 msda_fwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ shapes,
                     const int64_t* __restrict__ lsi, const TL* __restrict__ loc,
@@ -201,9 +209,19 @@ msda_fwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
   const int LP = LP_T > 0 ? LP_T : d.L * d.P;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int m = blockIdx.x % d.M;
+  const int head_rot = (prefetch_rows >> 16) & 0xf;   // A/B record (variants 61..68): which head runs on which XCD
+  prefetch_rows &= 0xffff;
   const int tile = blockIdx.x / d.M;
   const int b = tile / tiles_per_batch;
+  // Which head runs where: blockIdx % heads = the XCD (observed placement), and the head handled there
+  // rotates with the batch element.  Each XCD's L2 still holds one head-slice per batch element, but no
+  // XCD is the only requester of one address class: with `value` rows of head h at byte offset 128 h of
+  // every 1-KiB pixel record, the rows at offset 384 (mod 1 KiB) are served ~35 % slower than the other
+  // seven classes when all eight stream at once from one XCD each (measured: that head's workgroups end
+  // at 8.6 us mean / 11.1 max, all others at 6.3 / 7.9; the slow class follows the ADDRESS when the tensor
+  // is shifted by 128 B, not the XCD; alone it is as fast as the rest).  Spread over the XCDs the same
+  // rows cost the T=5 call 9.1 instead of 11.1 us (B = 8: 11.5 instead of 14.2).  head_rot 14 = fixed map.
+  const int m = (blockIdx.x % d.M + (head_rot == 14 ? 0 : head_rot == 15 || head_rot == 0 ? b : head_rot)) % d.M;
   const int q0 = (tile - b * tiles_per_batch) * (QPW * WPB) + wave * QPW;
 
   // per-wave LDS: [QPW][LP+1] tap offsets (uint4) then [QPW][LP+1] tap weights (float4)
@@ -218,19 +236,44 @@ msda_fwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
   const __amdgpu_buffer_rsrc_t rsrc = uniform_rsrc(head_base, head_bytes);
 
   // ---- phase 0 (optional): stream this wave's share of the head's rows towards L2 --------
-  // When the call samples more taps than the head has rows (decoder call on a small map with
-  // scattered locations) nearly every row is read anyway; touching each row's two 64-B halves
-  // in address order here turns the first-touch HBM reads of the random gathers below into a
-  // sequential stream that runs concurrently with the location loads.  The values are unused.
-  float pf_sink = 0.f;
-  if (prefetch_rows > 0) {
+  // A decoder call with scattered locations on a small map reads nearly every row of `value`
+  // (3.8 taps per row at the T=5 360p shape), but only learns WHICH rows after a first HBM round
+  // trip for the locations -- and then every wave of the grid asks for its taps at the same moment.
+  // Cold, the kernel is the sum of those two phases (10.9 us = 5.6 us cache-warm + 25 MB / 4.7 TB/s),
+  // not their maximum.  With PF the wave first issues its location loads, then touches both 64-B
+  // halves of its share of the head's rows in address order with `buffer_load_dword ... lds` (no
+  // VGPR destination, nothing ever waits for the data; it lands in a 256-B dump behind the tap
+  // records), and only then waits for the locations: HBM streams `value` into L2 while the
+  // locations travel.  The loads are unconditional and counted (kPfSteps), so the compiler's own
+  // s_waitcnt for the locations is vmcnt(kPfSteps), not vmcnt(0).
+  static_assert(!PF || (!FUSED && LP_T > 0 && QPW * LP_T <= 64), "PF: one-pass, unfused configurations only");
+  float pf_x = 0.f, pf_y = 0.f, pf_a = 0.f;
+  if constexpr (PF) {
+    const int qi = lane / LP_T, p = lane - qi * LP_T;
+    const int q = q0 + qi < d.Lq ? q0 + qi : d.Lq - 1;         // clamped: the loads below are unconditional
+    const int64_t wi = ((int64_t(b) * d.Lq + q) * d.M + m) * LP_T + p;
+    // hipcc sinks ordinary loads from `const __restrict__` memory below anything, compiler barriers
+    // included; the location loads therefore go out as asm (issued HERE), and are waited for by hand
+    // below: vmcnt(kPfSteps) = "everything older than the stream has landed".
+    static_assert(sizeof(TL) == 4, "PF: fp32 locations");
+    float2_t pf_xy;
+    asm volatile("global_load_dwordx2 %0, %2, off\n\tglobal_load_dword %1, %3, off"
+                 : "=&v"(pf_xy), "=&v"(pf_a)
+                 : "v"(loc + 2 * wi), "v"(attn + wi)
+                 : "memory");
     const int first = ((tile - b * tiles_per_batch) * WPB + wave) * prefetch_rows;
-    for (int r = lane >> 1; r < prefetch_rows; r += 32) {
+    unsigned char* dump = smem + size_t(WPB) * 2 * ent * 16 + size_t(wave) * 256;
+#pragma unroll
+    for (int i = 0; i < kPfSteps; ++i) {
+      const int r = i * 32 + (lane >> 1);
       const int row = first + r;
-      const uint32_t off = row < d.S ? uint32_t(row) * uint32_t(pixel_bytes) + uint32_t(lane & 1) * (kRowBytes / 2)
-                                     : kTapOutside;
-      pf_sink += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, int(off), 0, 0));
+      const uint32_t off = (r < prefetch_rows && row < d.S)
+                               ? uint32_t(row) * uint32_t(pixel_bytes) + uint32_t(lane & 1) * (kRowBytes / 2)
+                               : kTapOutside;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)dump, 4, off, 0, 0, 0);
     }
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(pf_xy), "+v"(pf_a) : "n"(kPfSteps) : "memory");
+    pf_x = pf_xy.x; pf_y = pf_xy.y;
   }
 
   // ---- phase 1: one (query, sample) pair per lane and step --------------------
@@ -250,12 +293,27 @@ msda_fwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
                        d, valid, x, y, a, sx, sy);
     }
     if (q < d.Lq) {
-      if constexpr (!FUSED) {
+      if constexpr (PF) {
+        x = pf_x; y = pf_y; a = pf_a;
+      } else if constexpr (!FUSED) {
         x = to_acc(loc[2 * wi]); y = to_acc(loc[2 * wi + 1]);
         a = to_acc(attn[wi]);
       }
-      const int H = int(shapes[2 * l]), W = int(shapes[2 * l + 1]);
-      const int start = int(lsi[l]);
+      int H, W, start;
+      if constexpr (PF) {
+        // level geometry through the scalar cache (lgkmcnt): a vector load here would queue behind the
+        // stream above and its s_waitcnt vmcnt(0) would wait for all of it.  PF launches have L <= 4.
+        H = W = 1; start = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (k < d.L) {
+            const int Hk = int(shapes[2 * k]), Wk = int(shapes[2 * k + 1]), sk = int(lsi[k]);
+            if (l == k) { H = Hk; W = Wk; start = sk; }
+          }
+      } else {
+        H = int(shapes[2 * l]); W = int(shapes[2 * l + 1]);
+        start = int(lsi[l]);
+      }
       const float h = y * float(H) - 0.5f, w = x * float(W) - 0.5f;
       if (h > -1.f && w > -1.f && h < float(H) && w < float(W)) {
         const float hf = floorf(h), wf = floorf(w);
@@ -293,7 +351,7 @@ msda_fwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
     // The gathers are latency-bound (two dependent HBM round trips per wave: locations, then
     // taps), so put a whole batch of 4 samples = 16 row loads in flight before the first use.
     constexpr int kPer = LP_T / PG;
-    constexpr int kBatch = kPer < 4 ? kPer : 4;
+    constexpr int kBatch = kPer < VNX_FWD_BATCH ? kPer : VNX_FWD_BATCH;
 #pragma unroll
     for (int i0 = 0; i0 < kPer; i0 += kBatch) {
       uint4_t o[kBatch];
@@ -348,8 +406,6 @@ msda_fwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
     TV* o = out + ((int64_t(b) * d.Lq + q) * d.M + m) * D + ch * 4;
     store_row4<TV>(o, acc);
   }
-  // keeps the phase-0 loads from being eliminated; the values never reach the output
-  asm volatile("" ::"v"(pf_sink));
   stamp_end(stamps);
 }
 
@@ -360,6 +416,7 @@ static FwdCfg pick_fwd_cfg(const MsdaDims& d, int variant) {
   const int LP = d.L * d.P;
   FwdCfg c{8, 4};
   if (variant >= 20 && variant < 60) variant = (variant - 20) % 20;  // prefetch on/off wrappers
+  if (variant >= 60 && variant < 69) variant = 13;
   if (variant >= 2 && variant <= 5) c = FwdCfg{8 >> (variant - 2), 4};
   else if (variant >= 12 && variant <= 15) c = FwdCfg{8 >> (variant - 12), 1};
   else {
@@ -387,14 +444,28 @@ static int launch_fwd_cfg(const void* value, const int64_t* shapes, const int64_
   // Measured (tools/time_variants.py, T=5 decoder call): cold 10.5 vs 11.1 us with uniform
   // locations, but 10.9 vs 9.3 us with model-like ones and 6.7 vs 5.7 us cache-warm -> off by default.
   (void)dense;
-  const bool want_prefetch = (variant >= 20 && variant < 40);
-  const int prefetch_rows = want_prefetch ? (d.S + tiles_per_batch * WPB - 1) / (tiles_per_batch * WPB) : 0;
+  bool want_prefetch = (variant >= 20 && variant < 40);
+  if constexpr (!(QPW * 16 <= 64)) want_prefetch = false;
+  if (LP != 16 || sizeof(TL) != 4 || d.L > 4) want_prefetch = false;
+  int prefetch_rows = want_prefetch ? (d.S + tiles_per_batch * WPB - 1) / (tiles_per_batch * WPB) : 0;
+  if (prefetch_rows > 32 * kPfSteps) prefetch_rows = 32 * kPfSteps;     // a larger share is streamed in part
+  if (variant >= 60 && variant < 68) prefetch_rows |= (variant - 60) << 16;
+  if (variant == 68) prefetch_rows |= 14 << 16;      // the fixed head -> XCD map (A/B record)
   const int64_t blocks = int64_t(d.B) * tiles_per_batch * d.M;
   if (blocks >= (int64_t(1) << 31)) {
     set_error("msda_forward: %lld workgroups exceed the grid limit", (long long)blocks);
     return VNX_ERR_UNSUPPORTED;
   }
-  const size_t lds = size_t(WPB) * 2 * QPW * (LP + 1) * 16;
+  const size_t lds = size_t(WPB) * 2 * QPW * (LP + 1) * 16 + (want_prefetch ? size_t(WPB) * 256 : 0);
+  if constexpr (QPW * 16 <= 64 && sizeof(TL) == 4) {
+    if (want_prefetch) {
+      hipLaunchKernelGGL((msda_fwd_d32_kernel<TV, TL, QPW, WPB, 16, false, true>), dim3(uint32_t(blocks)),
+                         dim3(64 * WPB), lds, stream, (const TV*)value, shapes, lsi,
+                         (const TL*)loc, (const TL*)attn, (TV*)out, d, tiles_per_batch, prefetch_rows,
+                         take_stamp_region(kStampFwd, blocks), FusedArgs{});
+      return check_launch("msda_fwd_d32_pf");
+    }
+  }
   if (LP == 16)
     hipLaunchKernelGGL((msda_fwd_d32_kernel<TV, TL, QPW, WPB, 16>), dim3(uint32_t(blocks)),
                        dim3(64 * WPB), lds, stream, (const TV*)value, shapes, lsi,
@@ -516,9 +587,9 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
   const int LP = LP_T > 0 ? LP_T : d.L * d.P;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int m = blockIdx.x % d.M;
   const int tile = blockIdx.x / d.M;
   const int b = tile / tiles_per_batch;
+  const int m = (blockIdx.x % d.M + b) % d.M;      // head <-> XCD map rotates with the batch element (see the forward)
   const int q0 = (tile - b * tiles_per_batch) * (QPW * WPB) + wave * QPW;
 
   // per-wave LDS: tap offsets, geometry, results
@@ -531,6 +602,7 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
 
   // ---- phase 1 ------------------------------------------------------------------
   const int pairs = QPW * LP;
+  int keep_H = 1, keep_W = 1;      // level size of this lane's sample: reused by phase 3 when pairs <= 64
   for (int e = lane; e < pairs; e += 64) {
     const int qi = e / LP, p = e - qi * LP;
     const int q = q0 + qi;
@@ -553,6 +625,7 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
       }
       const int H = int(shapes[2 * l]), W = int(shapes[2 * l + 1]);
       const int start = int(lsi[l]);
+      keep_H = H; keep_W = W;
       const float h = y * float(H) - 0.5f, w = x * float(W) - 0.5f;
       uint4_t record = {0xffffffffu, 0u, 0u, 0u};  // sample outside the map: no taps
       if (h > -1.f && w > -1.f && h < float(H) && w < float(W)) {
@@ -618,17 +691,11 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
   const float4_t* g_geo = s_geo + qi * (LP + 1) + pg * per_group;
   float4_t* g_res = s_res + qi * (LP + 1) + pg * per_group;
 
-  constexpr int kUnroll = LP_T > 0 ? (LP_T / PG >= 4 ? 4 : LP_T / PG) : 1;
-#pragma unroll kUnroll
-  for (int i = 0; i < per_group; ++i) {
-    const uint4_t o = g_off[i];
-    const float4_t geo = g_geo[i];
+  // one sample: the three scalar gradients from its four taps (+ the grad_value atomics of the general path)
+  auto one_sample = [&](int i, const uint4_t o, const float4_t geo, const float4_t v1, const float4_t v2,
+                        const float4_t v3, const float4_t v4) {
     const float lh = geo.x, lw = geo.y, a = geo.z;
     const float hh = 1.f - lh, hw = 1.f - lw;
-    const float4_t v1 = load_tap<TV>(vsrc, o.x * uint32_t(sizeof(TV)) + ch * kLaneBytes);
-    const float4_t v2 = load_tap<TV>(vsrc, o.y * uint32_t(sizeof(TV)) + ch * kLaneBytes);
-    const float4_t v3 = load_tap<TV>(vsrc, o.z * uint32_t(sizeof(TV)) + ch * kLaneBytes);
-    const float4_t v4 = load_tap<TV>(vsrc, o.w * uint32_t(sizeof(TV)) + ch * kLaneBytes);
     const float4_t tg = top * a;
     if (ATOMICS) {
       const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
@@ -657,6 +724,34 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
       float4_t r = {s_gx, s_gy, s_ga, 0.f};
       g_res[i] = r;
     }
+  };
+  auto tap = [&](uint32_t elem_off) { return load_tap<TV>(vsrc, elem_off * uint32_t(sizeof(TV)) + ch * kLaneBytes); };
+  if constexpr (LP_T > 0 && !ATOMICS) {
+    // As in the forward: the row loads of a whole batch of samples are issued before the first use.  (Left
+    // to the compiler this loop waited for four loads at a time, eight dependent memory round trips per
+    // wave at the decoder shape: 10.9 us per workgroup against the forward's 6.2.)
+    constexpr int kPer = LP_T / PG;
+    constexpr int kBatch = kPer < 4 ? kPer : 4;
+#pragma unroll
+    for (int i0 = 0; i0 < kPer; i0 += kBatch) {
+      uint4_t o[kBatch];
+      float4_t geo[kBatch];
+      float4_t v[kBatch][4];
+#pragma unroll
+      for (int j = 0; j < kBatch; ++j) { o[j] = g_off[i0 + j]; geo[j] = g_geo[i0 + j]; }
+#pragma unroll
+      for (int j = 0; j < kBatch; ++j) {
+        v[j][0] = tap(o[j].x); v[j][1] = tap(o[j].y); v[j][2] = tap(o[j].z); v[j][3] = tap(o[j].w);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < kBatch; ++j) one_sample(i0 + j, o[j], geo[j], v[j][0], v[j][1], v[j][2], v[j][3]);
+    }
+  } else {
+    for (int i = 0; i < per_group; ++i) {
+      const uint4_t o = g_off[i];
+      one_sample(i, o, g_geo[i], tap(o.x), tap(o.y), tap(o.z), tap(o.w));
+    }
   }
   if (WPB > 1) __syncthreads(); else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -669,7 +764,9 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
       const int l = p / d.P;
       const int64_t wi = ((int64_t(b) * d.Lq + q3) * d.M + m) * LP + p;
       const float4_t r = s_res[qi3 * (LP + 1) + p];
-      const float Hf = float(int(shapes[2 * l])), Wf = float(int(shapes[2 * l + 1]));
+      // (a vector load of the level size here is one more dependent memory round trip at the end of the wave)
+      const float Hf = pairs <= 64 ? float(keep_H) : float(int(shapes[2 * l]));
+      const float Wf = pairs <= 64 ? float(keep_W) : float(int(shapes[2 * l + 1]));
       if constexpr (!FUSED) {
         store_loc<TL>(grad_loc + 2 * wi, Wf * r.x);       // cuh:157
         store_loc<TL>(grad_loc + 2 * wi + 1, Hf * r.y);   // cuh:158

@@ -134,7 +134,6 @@ msda_bwd_gv_tile_kernel(const int64_t* __restrict__ shapes, const int64_t* __res
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
   const int m = blockIdx.x % d.M;
   const int rest = blockIdx.x / d.M;
   const int unit = rest % units_bound;

@@ -125,10 +125,18 @@ msda_bwd_gv_rec_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
 
   const int P = P_T > 0 ? P_T : d.P;
   const int tid = threadIdx.x, lane = tid & 63;
-  const int m = blockIdx.x % d.M;
+  // Dispatch order = cost order: the unit index is the slow axis and units are numbered from the LAST
+  // level back (below), so the coarse levels' units -- three sort chunks each at the decoder shape against
+  // one for a fine-level unit, 12-15 us against 6-7 -- start first instead of last (they used to start up
+  // to 7 us into the kernel and set its end: 20 us for 8.5 us of mean work per workgroup).
+  // Tried on top of it: splitting the coarse levels' units by query range as well (one sort chunk per piece),
+  // the pieces meeting in grad_value through agent-scope fp32 atomics on rows zeroed by the grad_loc kernel.
+  // Correct, and slower: 48.7 vs 32.2 us per decoder backward -- 1.15 M contended L2-bypassing atomics cost
+  // the pieces 12-25 us each.  Reverted.
   const int rest = blockIdx.x / d.M;
-  const int unit = rest % units_bound;
-  const int b = rest / units_bound;
+  const int unit = rest / d.B;
+  const int b = rest - unit * d.B;
+  const int m = (blockIdx.x % d.M + b) % d.M;      // head <-> XCD map rotates with the batch element (msda_d32.hip)
   VNX_STAMP(0);
 
   // level table: lane l works out level l's unit split once (two integer divisions per level)
@@ -157,10 +165,12 @@ msda_bwd_gv_rec_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
     bool packed = true;
     int u = unit;
     for (int l = 0; l < d.L; ++l) {
+      packed = packed && (meta[4 * l + 2] == running);
+      running += meta[4 * l] * meta[4 * l + 1];
+    }
+    for (int l = d.L - 1; l >= 0; --l) {       // units are numbered from the last (coarsest) level back
       const int H = meta[4 * l], W = meta[4 * l + 1], st = meta[4 * l + 2], ur = meta[4 * l + 3];
       const int n = H * W, units = ur & 0xfff, rpu = ur >> 12;
-      packed = packed && (st == running);
-      running += n;
       if (lvl < 0) {
         if (u < units) {
           lvl = l; Hl = H; Wl = W; start = st;
@@ -390,10 +400,14 @@ msda_bwd_gv_sel_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int m = blockIdx.x % d.M;
+  // Dispatch order = cost order: the unit index is the slow axis and units are numbered from the LAST
+  // level back (below), so the coarse levels' units -- three sort chunks each at the decoder shape against
+  // one for a fine-level unit, 12-15 us against 6-7 -- start first instead of last (they used to start up
+  // to 7 us into the kernel and set its end: 20 us for 8.5 us of mean work per workgroup).
   const int rest = blockIdx.x / d.M;
-  const int unit = rest % units_bound;
-  const int b = rest / units_bound;
+  const int unit = rest / d.B;
+  const int b = rest - unit * d.B;
+  const int m = (blockIdx.x % d.M + b) % d.M;      // head <-> XCD map rotates with the batch element (msda_d32.hip)
   VNX_STAMP(0);
 
   if (tid < d.L) {
@@ -420,10 +434,12 @@ msda_bwd_gv_sel_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
     bool packed = true;
     int u = unit;
     for (int l = 0; l < d.L; ++l) {
+      packed = packed && (meta[4 * l + 2] == running);
+      running += meta[4 * l] * meta[4 * l + 1];
+    }
+    for (int l = d.L - 1; l >= 0; --l) {       // units are numbered from the last (coarsest) level back
       const int H = meta[4 * l], W = meta[4 * l + 1], st = meta[4 * l + 2], ur = meta[4 * l + 3];
       const int n = H * W, units = ur & 0xfff, rpu = ur >> 12;
-      packed = packed && (st == running);
-      running += n;
       if (lvl < 0) {
         if (u < units) {
           lvl = l; Hl = H; Wl = W; start = st; u_lvl = u;

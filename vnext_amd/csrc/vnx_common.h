@@ -117,7 +117,6 @@ struct FusedArgs {
   int ref_div;             // consecutive batch elements sharing one reference row (frames of a clip)
 };
 
-
 inline int elem_size(int dtype) {
   switch (dtype) {
     case VNX_F32: return 4;
