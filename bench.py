@@ -98,14 +98,14 @@ class Op:
 
     def fwd(self, s, B, Lq):
         st = self.lib.vnx_msda_forward(
-            0, 0, s["value"].data_ptr(), s["shapes"].data_ptr(), s["lsi"].data_ptr(),
+            s.get("vdt", 0), 0, s["value"].data_ptr(), s["shapes"].data_ptr(), s["lsi"].data_ptr(),
             s["loc"].data_ptr(), s["attn"].data_ptr(), s["out"].data_ptr(),
             B, s["S"], 8, 32, 4, Lq, 4, torch.cuda.current_stream().cuda_stream)
         self._lib.check(st)
 
     def bwd(self, s, B, Lq):
         st = self.lib.vnx_msda_backward(
-            0, 0, s["value"].data_ptr(), s["shapes"].data_ptr(), s["lsi"].data_ptr(),
+            s.get("vdt", 0), 0, s["value"].data_ptr(), s["shapes"].data_ptr(), s["lsi"].data_ptr(),
             s["loc"].data_ptr(), s["attn"].data_ptr(), s["grad_out"].data_ptr(),
             s["gv"].data_ptr(), s["gl"].data_ptr(), s["ga"].data_ptr(),
             B, s["S"], 8, 32, 4, Lq, 4, 1, s["ws"].data_ptr(), s["ws_bytes"],
@@ -248,10 +248,10 @@ def extra_model_legs(device):
     return out
 
 
-def latest_pmc_profile():
-    """The newest committed PMC summary (tools/summarize_prof.py), or None."""
+def latest_profile(suffix):
+    """The newest committed summary profiles/rNN_<suffix> (tools/summarize_prof.py), or None."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_pmc_hbm.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_" + suffix)))
     if not files:
         return None
     try:
@@ -268,8 +268,198 @@ def largest_divisor_leq(n, cap):
     return 1
 
 
-def cpu_baseline(B, Lq, res, budget_s=12.0):
-    """Oracle ("port") on the host cores, same workload; plus the grid_sample technique."""
+# ------------------------------------------------------------------------------------------------
+# op-level rooflines beyond the headline (rank 0, N = 1): every BASELINE shape, both location
+# distributions, the bf16 case of config 3, and the two other kernel families
+# ------------------------------------------------------------------------------------------------
+def pixel_centres(res, device):
+    refs = []
+    for h, w in SHAPES[res]:
+        ys, xs = torch.meshgrid(torch.arange(h, device=device) + 0.5, torch.arange(w, device=device) + 0.5, indexing="ij")
+        refs.append(torch.stack([xs.reshape(-1) / w, ys.reshape(-1) / h], -1))
+    return torch.cat(refs, 0)
+
+
+def make_case(res, B, Lq, dist, vdtype, seed, device):
+    """One input set of an op-level case.  dist "U": locations uniform in [0,1)^2 (ops/test.py:34);
+    "M": model-like -- reference point per query (encoder, Lq == S: the pixel centres of the pyramid,
+    deformable_transformer.py:183-190; decoder: random box centres) + (head direction x (k+1) + N(0,1))
+    pixels of every level (the module's initialisation, ops/modules/ms_deform_attn.py:65-73)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    if (res, str(device)) not in _LEVELS:
+        sh = torch.tensor(SHAPES[res], dtype=torch.long, device=device)
+        _LEVELS[(res, str(device))] = (sh, torch.cat((sh.new_zeros((1,)), sh.prod(1).cumsum(0)[:-1])))
+    shapes, lsi = _LEVELS[(res, str(device))]
+    S = int(shapes.prod(1).sum())
+    value = torch.randn(B, S, 8, 32, device=device, generator=g).to(vdtype)
+    if dist == "U":
+        loc = torch.rand(B, Lq, 8, 4, 4, 2, device=device, generator=g)
+    else:
+        ref = pixel_centres(res, device).view(1, S, 1, 1, 1, 2) if Lq == S else \
+            torch.rand(B, Lq, 1, 1, 1, 2, device=device, generator=g)
+        th = torch.arange(8, device=device) * (2 * math.pi / 8)
+        d = torch.stack([th.cos(), th.sin()], -1)
+        d = d / d.abs().max(-1, keepdim=True)[0]
+        k = torch.arange(1, 5, device=device).view(1, 1, 1, 1, 4, 1)
+        offs = d.view(1, 1, 8, 1, 1, 2) * k + torch.randn(B, Lq, 8, 4, 4, 2, device=device, generator=g)
+        wh = torch.stack([shapes[:, 1], shapes[:, 0]], -1).float().view(1, 1, 1, 4, 1, 2)
+        loc = (ref + offs / wh).contiguous()
+    attn = torch.softmax(torch.randn(B, Lq, 8, 16, device=device, generator=g), -1).view(B, Lq, 8, 4, 4).contiguous()
+    grad_out = torch.randn(B, Lq, 256, device=device, generator=g).to(vdtype)
+    out = torch.empty(B, Lq, 256, device=device, dtype=vdtype)
+    gv, gl, ga = torch.empty_like(value), torch.empty_like(loc), torch.empty_like(attn)
+    from vnext_amd import _lib
+    vdt = _lib.VNX_F32 if vdtype == torch.float32 else _lib.VNX_BF16
+    ws_bytes = _lib.lib().vnx_msda_backward_workspace_bytes(vdt, _lib.VNX_F32, B, S, 8, 32, 4, Lq, 4, 1)
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=device)
+    return dict(ws=ws, ws_bytes=ws_bytes, shapes=shapes, lsi=lsi, value=value, loc=loc, attn=attn, grad_out=grad_out,
+                out=out, gv=gv, gl=gl, ga=ga, S=S, vdt=vdt)
+
+
+OP_CASES = [
+    # key, resolution, B, Lq (None = S: the encoder shape), distribution, value dtype, what it is
+    ("decoder_360p_M", "360p", 5, 300, "M", torch.float32, "headline shape with model-like locations"),
+    ("decoder_360p_U_B10", "360p", 10, 300, "U", torch.float32, "two clips per GPU folded (the reference's per-GPU batch)"),
+    ("decoder_720p_U", "720p", 5, 300, "U", torch.float32, "decoder call, 720p"),
+    ("decoder_720p_U_bf16", "720p", 5, 300, "U", torch.bfloat16, "config 3: bf16 value / grad, fp32 locations"),
+    ("encoder_360p_M", "360p", 5, None, "M", torch.float32, "encoder call (94 % of a model's points), 360p"),
+    ("encoder_720p_M", "720p", 2, None, "M", torch.float32, "encoder call, 720p, two frames"),
+]
+
+
+def op_case_rooflines(op, device):
+    out = {}
+    for key, res, B, Lq, dist, vdtype, what in OP_CASES:
+        S = sum(h * w for h, w in SHAPES[res])
+        Lq = Lq or S
+        e = 4 if vdtype == torch.float32 else 2
+        probe = make_case(res, B, Lq, dist, vdtype, 1, device)
+        in_bytes = sum(probe[k].numel() * probe[k].element_size() for k in ("value", "loc", "attn", "grad_out"))
+        nsets = max(2, min(12, math.ceil(320 * 2**20 / in_bytes)))
+        sets = [probe] + [make_case(res, B, Lq, dist, vdtype, 1 + i, device) for i in range(1, nsets)]
+        inner = max(nsets, 8)
+        bytes_fwd, bytes_bwd = algorithmic_bytes(B, S, Lq, e=e)
+        g_fwd = capture([(lambda s=sets[i % nsets]: op.fwd(s, B, Lq)) for i in range(inner)])
+        g_bwd = capture([(lambda s=sets[i % nsets]: op.bwd(s, B, Lq)) for i in range(inner)])
+        us_f, us_b = event_time_us(g_fwd, inner, reps=9), event_time_us(g_bwd, inner, reps=9)
+        points = 128 * B * Lq
+        out[key] = {
+            "what": what, "B": B, "Lq": Lq, "S": S, "loc": dist, "value_dtype": "f32" if e == 4 else "bf16",
+            "points": points, "input_rotation_sets": nsets,
+            "fwd": {"us_per_launch": us_f, "algorithmic_bytes": bytes_fwd, "achieved_GBs": bytes_fwd / us_f / 1e3,
+                    "frac_of_hbm_peak": bytes_fwd / us_f / 1e3 / HBM_PEAK_GBS, "gpoints_per_s": points / us_f / 1e3},
+            "bwd": {"us_per_launch": us_b, "algorithmic_bytes": bytes_bwd, "achieved_GBs": bytes_bwd / us_b / 1e3,
+                    "frac_of_hbm_peak": bytes_bwd / us_b / 1e3 / HBM_PEAK_GBS},
+            "fwd_bwd_gpoints_per_s": points / (us_f + us_b) / 1e3,
+        }
+        del sets, probe, g_fwd, g_bwd
+        torch.cuda.empty_cache()
+    return out
+
+
+def gather_ceiling(device):
+    """What this memory system delivers for the forward's access pattern with no kernel around it: random
+    128-B rows, 8 lanes x 16 B each (vnx_debug_row_gather_probe), cold (a 384 MiB table, > Infinity Cache)
+    and from a 24 MiB table (the size of the headline `value`; L2 / Infinity Cache resident)."""
+    from vnext_amd import _lib
+    lib = _lib.lib()
+    res = {}
+    sink = torch.zeros(4, device=device)
+    for name, mib in (("cold_384MiB", 384), ("cache_resident_24MiB", 24)):
+        n_rows = mib * 2**20 // 128
+        table = torch.empty(n_rows * 32, device=device).normal_()
+        n_idx = 4 * 2**20
+        idx = torch.randint(0, n_rows, (n_idx,), device=device, dtype=torch.int64).to(torch.int32)
+        best = None
+        for nf in (4, 8):
+            def run(nf=nf):
+                _lib.check(lib.vnx_debug_row_gather_probe(table.data_ptr(), n_rows, idx.data_ptr(), n_idx, nf,
+                                                          sink.data_ptr(), torch.cuda.current_stream().cuda_stream))
+            g = capture([run] * 4)
+            us = event_time_us(g, 4, reps=7)
+            gbs = n_idx * 128 / us / 1e3
+            if best is None or gbs > best[0]:
+                best = (gbs, nf, us)
+        res[name] = {"GBs": best[0], "rows_in_flight_per_lane": best[1], "us": best[2], "rows": n_idx}
+        del table, idx
+        torch.cuda.empty_cache()
+    return res
+
+
+def head_rooflines(device):
+    """The other two kernel families of the path: the fused dynamic mask head (output-write bound,
+    bytes = 4 (8 HW + 171 n + 4 n HW) per frame) and the reid similarity on the matrix cores."""
+    from vnext_amd import _lib
+    from vnext_amd.heads import dynamic_mask_with_coords
+    from vnext_amd.heads import reid as R
+    lib = _lib.lib()
+    out = {}
+    for name, (H, W) in (("360p", (48, 80)), ("720p", (92, 160))):
+        n = 300
+        sets = []
+        for i in range(8):
+            g = torch.Generator(device=device).manual_seed(i)
+            feats = torch.randn(1, 8, H, W, device=device, generator=g)
+            ref = torch.rand(1, n, 2, device=device, generator=g) * torch.tensor([W * 8.0, H * 8.0], device=device)
+            params = 0.3 * torch.randn(1, n, 169, device=device, generator=g)
+            sets.append((feats, ref, params))
+        with torch.no_grad():
+            fns = [(lambda s=s: dynamic_mask_with_coords(s[0], s[1], s[2], [n], 8)) for s in sets] * 3
+            us = event_time_us(capture(fns), len(fns), reps=9)
+        nbytes = 4 * (8 * H * W + n * 171 + n * 4 * H * W)
+        out[f"mask_head_fwd_{name}_n300"] = {
+            "bound": "hbm", "kernel": "dynamic_mask_head_kernel", "us_per_launch": us, "algorithmic_bytes": nbytes,
+            "achieved": nbytes / us / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / us / 1e3 / HBM_PEAK_GBS,
+            "what": f"one {name} frame, 300 instances -> logits [300, {2 * H}, {2 * W}] fp32"}
+    # training shape: T = 5 frames x 6 decoder layers x 4 matched instances, forward + backward
+    H, W, n_img, per = 48, 80, 5, 24
+    n = n_img * per
+    g = torch.Generator(device=device).manual_seed(5)
+    feats = torch.randn(n_img, 8, H, W, device=device, generator=g).requires_grad_(True)
+    ref = (torch.rand(1, n, 2, device=device, generator=g) * torch.tensor([W * 8.0, H * 8.0], device=device)).requires_grad_(True)
+    params = (0.3 * torch.randn(1, n, 169, device=device, generator=g)).requires_grad_(True)
+    gout = torch.randn(1, n, 2 * H, 2 * W, device=device, generator=g)
+
+    def step():
+        o = dynamic_mask_with_coords(feats, ref, params, [per] * n_img, 8)
+        o.backward(gout)
+        feats.grad = ref.grad = params.grad = None
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        step()
+    e1.record()
+    e1.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / 20
+    nbytes = 4 * (2 * 8 * n_img * H * W + 2 * n * 171 + 2 * n * 4 * H * W)      # forward traffic + the same for the gradients
+    out["mask_head_fwd_bwd_train_360p_n120"] = {
+        "bound": "hbm", "kernel": "dynamic_mask_head_kernel + dynamic_mask_head_bwd_kernel (through autograd, eager)",
+        "us_per_step": us, "algorithmic_bytes": nbytes, "achieved": nbytes / us / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": nbytes / us / 1e3 / HBM_PEAK_GBS, "what": "5 frames x 24 matched instances (6 decoder layers x 4 tracks), 360p"}
+    # reid: 300 detections x 300 memory embeddings x 256 channels, dot and cosine, + bi-softmax
+    a = torch.randn(300, 256, device=device)
+    b = torch.randn(300, 256, device=device)
+    with torch.no_grad():
+        fns = [lambda: R.similarity(a, b)] * 16
+        us_dot = event_time_us(capture(fns), 16, reps=9)
+        fns = [lambda: R.match_scores(a, b, "bisoftmax")] * 16
+        us_match = event_time_us(capture(fns), 16, reps=9)
+    flops = 2.0 * 300 * 300 * 256
+    out["reid_similarity_300x300x256"] = {
+        "bound": "mfma", "kernel": "reid_similarity_kernel (v_mfma_f32_16x16x4_f32)", "us_per_launch": us_dot, "flops": flops,
+        "achieved": flops / us_dot / 1e6, "peak": 157.3, "unit": "TFLOP/s", "frac": flops / us_dot / 1e6 / 157.3,
+        "us_match_scores_bisoftmax": us_match,
+        "what": "46 MFLOP: launch / latency bound by construction; MFMA utilisation is not the point, one launch per image is"}
+    return out
+
+
+def cpu_baseline(B, Lq, res, budget_s=14.0):
+    """The reference's pure-PyTorch fallback technique (grid_sample + autograd, oracle/msda_torch_fallback.py
+    restating ops/functions/ms_deform_attn_func.py:42-62) on the host cores, same workload; the C oracle
+    (oracle/msda_oracle.c) nested beside it."""
     import numpy as np
     from oracle import msda_oracle as O
     from oracle.msda_torch_fallback import msda_grid_sample
@@ -284,11 +474,24 @@ def cpu_baseline(B, Lq, res, budget_s=12.0):
     go = rng.standard_normal((B, Lq, 256)).astype(np.float32)
     points = 128 * B * Lq
     cores = os.cpu_count() or 1
+    tthreads = min(cores, 16)  # grid_sample does not scale past a few threads; avoid oversubscription
+    torch.set_num_threads(tthreads)
+    tv, tl, ta = (torch.from_numpy(x).requires_grad_(True) for x in (value, loc, attn))
+    tg = torch.from_numpy(go)
+    ts = []
+    t_start = time.perf_counter()
+    while len(ts) < 3 or (time.perf_counter() - t_start < budget_s / 2 and len(ts) < 25):
+        t0 = time.perf_counter()
+        out = msda_grid_sample(tv, shapes, tl, ta)
+        out.backward(tg)
+        ts.append(time.perf_counter() - t0)
+        tv.grad = tl.grad = ta.grad = None
+    gmed, gn = sorted(ts)[len(ts) // 2], len(ts)
     best = None
-    for nt in sorted({1, cores}):
+    for nt in sorted({1, min(cores, 32)}):
         ts = []
         t_start = time.perf_counter()
-        while len(ts) < 3 or (time.perf_counter() - t_start < budget_s / 3 and len(ts) < 25):
+        while len(ts) < 3 or (time.perf_counter() - t_start < budget_s / 4 and len(ts) < 25):
             t0 = time.perf_counter()
             O.msda_forward(value, shapes, lsi, loc, attn, nthreads=nt)
             O.msda_backward(value, shapes, lsi, loc, attn, go, nthreads=nt)
@@ -297,30 +500,15 @@ def cpu_baseline(B, Lq, res, budget_s=12.0):
         if best is None or med < best[0]:
             best = (med, nt, len(ts))
     med, nt, n = best
-    # the reference's fallback technique (grid_sample + autograd), all host threads
-    tthreads = min(cores, 16)  # grid_sample does not scale past a few threads; avoid oversubscription
-    torch.set_num_threads(tthreads)
-    tv, tl, ta = (torch.from_numpy(x).requires_grad_(True) for x in (value, loc, attn))
-    tg = torch.from_numpy(go)
-    ts = []
-    t_start = time.perf_counter()
-    while len(ts) < 3 or (time.perf_counter() - t_start < budget_s / 3 and len(ts) < 25):
-        t0 = time.perf_counter()
-        out = msda_grid_sample(tv, shapes, tl, ta)
-        out.backward(tg)
-        ts.append(time.perf_counter() - t0)
-        tv.grad = tl.grad = ta.grad = None
-    gmed = sorted(ts)[len(ts) // 2]
     return {
-        "value": points / med / 1e9, "unit": "Gpoints/s", "cores": nt, "kind": "port",
-        "sample": f"{n} x (fwd+bwd) of the same B={B},Lq={Lq},{res} fp32 workload through "
-                  f"oracle/msda_oracle.c, median; host has {cores} cores",
-        "ms_per_step": med * 1e3,
-        "torch_grid_sample_fallback": {
-            "value": points / gmed / 1e9, "unit": "Gpoints/s", "cores": tthreads,
-            "ms_per_step": gmed * 1e3,
-            "note": "grid_sample + autograd statement of the reference's pure-PyTorch path "
-                    "(oracle/msda_torch_fallback.py), torch intra-op threads = min(host cores, 16)"},
+        "value": points / gmed / 1e9, "unit": "Gpoints/s", "cores": tthreads, "kind": "port",
+        "sample": f"{gn} x (fwd+bwd) of the same B={B},Lq={Lq},{res} fp32 workload through the reference's pure-PyTorch "
+                  f"fallback technique (grid_sample + autograd; oracle/msda_torch_fallback.py), median; torch intra-op "
+                  f"threads = min(host cores, 16); host has {cores} cores",
+        "ms_per_step": gmed * 1e3,
+        "c_oracle": {"value": points / med / 1e9, "unit": "Gpoints/s", "cores": nt, "ms_per_step": med * 1e3,
+                     "sample": f"{n} x (fwd+bwd) through oracle/msda_oracle.c (OpenMP over (batch, head)), the faster of 1 and "
+                               f"{min(cores, 32)} threads"},
     }
 
 
@@ -443,6 +631,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-model", action="store_true", help="skip the model-level DDP step (clips/s) leg")
     ap.add_argument("--model-steps", type=int, default=10)
+    ap.add_argument("--no-cases", action="store_true", help="skip the other op-level shapes and the mask-head / reid legs")
     ap.add_argument("--no-warm", action="store_true",
                     help="skip the cache-warm forward leg (profiling runs: keeps rocprofv3's per-kernel average cold-only)")
     a = ap.parse_args()
@@ -512,27 +701,20 @@ def main():
             if world == 1:
                 line["other_configs"] = extra_model_legs(device)
         # ---- per-kernel rooflines, measured live --------------------------------------------
-        # (a) HIP events around a hipGraph of back-to-back launches: includes the ~2-3 us
-        #     dependent-kernel gap, so it over-states a 10 us kernel;
-        # (b) kernel-span stamps: every launch of a tuned kernel leaves {first wave start, last
-        #     wave end} in constant-rate wall-clock ticks (s_memrealtime) -- the kernel's own
-        #     duration on the device, what rocprofv3 --kernel-trace reports.  (b) feeds `achieved`.
+        # `us_per_launch` (what `achieved` and `frac` are computed from): HIP events on the launch stream
+        # around a hipGraph of back-to-back launches over the rotating (cold) input sets -- the figure the
+        # committed rocprofv3 --kernel-trace --stats average of this same command agrees with (it includes
+        # the ~1 us between dependent launches, so it never flatters the kernel).
+        # `frac_kernel_span`: the same launches timed from inside (first wave start -> last wave end,
+        # s_memrealtime stamps), a secondary figure.
         import ctypes
         inner = max(nsets, 24)
         L = op.lib
-        L.vnx_debug_arm_stamps.argtypes = [ctypes.c_void_p, ctypes.c_longlong]
-        L.vnx_debug_arm_stamps.restype = None
-        L.vnx_debug_stamp_regions.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_longlong),
-                                              ctypes.POINTER(ctypes.c_longlong), ctypes.c_int]
-        L.vnx_debug_stamp_regions.restype = ctypes.c_int
-        L.vnx_debug_wall_clock_khz.restype = ctypes.c_int
         n_words = (6 * inner + 96) * 2 * 8192    # <= 8 Ki workgroups per stamped launch
         stamps = torch.zeros(n_words, dtype=torch.int64, device=device)
         L.vnx_debug_arm_stamps(stamps.data_ptr(), n_words)
         g_fwd = capture([(lambda s=sets[i % nsets]: op.fwd(s, B, Lq)) for i in range(inner)])
         g_bwd = capture([(lambda s=sets[i % nsets]: op.bwd(s, B, Lq)) for i in range(inner)])
-        # forward + grad_loc kernels (grad_value: see below); capture() also runs its functions
-        # eagerly first -- those launches take regions too, which stay zero in the measured replays
         max_regions = 6 * inner + 96
         kinds = (ctypes.c_int * max_regions)()
         offs = (ctypes.c_longlong * max_regions)()
@@ -548,7 +730,7 @@ def main():
         if g_fwd_warm is not None:
             us_fwd_warm = event_time_us(g_fwd_warm, inner)
         khz = L.vnx_debug_wall_clock_khz()
-        span = {1: [], 2: [], 3: [], "warm": []}
+        span = {1: [], 2: [], "warm": []}
         if khz > 0 and 0 < n_regions <= max_regions:
             for _ in range(10):
                 stamps.zero_()
@@ -560,68 +742,54 @@ def main():
                 for i in range(n_regions):
                     t = stamps[offs[i]:offs[i] + 2 * nblk[i]].view(-1, 2)
                     ran = t[:, 0] > 0                   # placeholder workgroups that returned at once still stamp
-                    if bool(ran.any()):
+                    if bool(ran.any()) and (i >= n_cold or kinds[i] in span):
                         span["warm" if i >= n_cold else kinds[i]].append(float(t[ran, 1].max() - t[ran, 0].min()) / khz * 1e3)
-        # the grad_value kernel takes no stamp-region argument (register budget, see
-        # msda_d32_gvrec.hip): its workgroups stamp a fixed device array when launched with
-        # variant 412 -- single launches, rotating inputs, read back after each
-        n_rec = 4096 * 16
-        host = (ctypes.c_ulonglong * n_rec)()
-        L.vnx_debug_read_rec_stamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
-        L.vnx_debug_read_rec_stamps.restype = ctypes.c_int
-        if khz > 0:
-            L.vnx_set_kernel_variant(412)
-            try:
-                for rep in range(24):
-                    op.bwd(sets[rep % nsets], B, Lq)
-                    torch.cuda.synchronize()
-                    if L.vnx_debug_read_rec_stamps(host, n_rec) != 0:
-                        break
-                    t = torch.frombuffer(host, dtype=torch.int64).view(4096, 16)
-                    ran = t[:, 12] > t[:, 0]
-                    if rep >= 4 and bool(ran.any()):
-                        span[3].append(float(t[ran, 12].max() - t[ran, 0].min()) / khz * 1e3)
-            finally:
-                L.vnx_set_kernel_variant(0)
         k_us = {k: (sum(v) / len(v) if v else None) for k, v in span.items()}
-        print(f"[bench] stamp regions {n_regions}/{max_regions}, wall clock {khz} kHz, spans "
-              f"{ {k: len(v) for k, v in span.items()} }", file=sys.stderr)
 
-        def roof(nbytes, us_kernel, us_events, what):
-            us = us_kernel if us_kernel else us_events
-            gbs = nbytes / us / 1e3
-            return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": gbs / HBM_PEAK_GBS, "traffic": None, "kernel": what,
-                    "algorithmic_bytes_per_launch": nbytes, "us_per_launch": us,
-                    "us_per_launch_events": us_events,
-                    "timing": ("kernel-span stamps (first wave start to last wave end, s_memrealtime), mean over "
-                               "launches on rotating inputs (cold)" if us_kernel else
-                               "HIP events around a hipGraph of back-to-back launches (cold); includes the gap")
-                              + "; us_per_launch_events = HIP events around the same graph, incl. the inter-kernel gap"}
+        def roof(nbytes, us_events, us_span, what):
+            gbs = nbytes / us_events / 1e3
+            r = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                 "traffic": None, "kernel": what, "algorithmic_bytes_per_launch": nbytes, "us_per_launch": us_events,
+                 "timing": "HIP events on the launch stream around a hipGraph of back-to-back launches on rotating inputs "
+                           "(cold); agrees with the rocprofv3 --kernel-trace average of this command (profiles/)"}
+            if us_span:
+                r["us_kernel_span"] = us_span
+                r["frac_kernel_span"] = nbytes / us_span / 1e3 / HBM_PEAK_GBS
+            return r
 
-        line["roofline"] = roof(bytes_fwd, k_us[1], us_fwd, "msda_fwd_d32_kernel (ms_deform_attn_forward)")
+        line["roofline"] = roof(bytes_fwd, us_fwd, k_us[1], "msda_fwd_d32_kernel (ms_deform_attn_forward)")
         if us_fwd_warm:
-            warm = k_us.get("warm") or us_fwd_warm       # kernel span like the cold number; events as fallback
-            line["roofline"]["warm_us_per_launch"] = warm
-            line["roofline"]["warm_us_per_launch_events"] = us_fwd_warm
-            line["roofline"]["warm_frac"] = bytes_fwd / warm / 1e3 / HBM_PEAK_GBS
-        line["roofline_bwd"] = roof(bytes_bwd, (k_us[2] + k_us[3]) if (k_us[2] and k_us[3]) else None, us_bwd,
+            line["roofline"]["warm_us_per_launch"] = us_fwd_warm
+            line["roofline"]["warm_frac"] = bytes_fwd / us_fwd_warm / 1e3 / HBM_PEAK_GBS
+            line["roofline"]["warm_note"] = "one input set replayed: value and locations stay in L2 / Infinity Cache; not an HBM fraction"
+        line["roofline_bwd"] = roof(bytes_bwd, us_bwd, None,
                                     "msda_bwd_d32_kernel (grad_loc, grad_attn, sample records) + "
                                     "msda_bwd_gv_sel_kernel (grad_value), one ms_deform_attn_backward call")
-        # HBM bytes per launch cannot be counted from inside this process: they come from the
-        # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command
-        # (profiles/rNN_bench_pmc_hbm.json, corrected as MI355X_MICROARCH.md section HBM says).
-        pmc = latest_pmc_profile()
+        if k_us[2]:
+            line["roofline_bwd"]["us_grad_loc_kernel_span"] = k_us[2]
+        # the ceiling of this access pattern on this memory system, measured in the same run
+        ceil = gather_ceiling(device)
+        line["roofline"]["gather_ceiling_GBs"] = ceil["cold_384MiB"]["GBs"]
+        line["roofline"]["gather_ceiling"] = ceil
+        line["roofline"]["frac_of_gather_ceiling"] = line["roofline"]["achieved"] / ceil["cold_384MiB"]["GBs"]
+        # HBM bytes per launch cannot be counted from inside this process: they come from the committed
+        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command (profiles/rNN_bench_pmc_hbm.json,
+        # corrected as MI355X_MICROARCH.md section HBM says); the rocprofv3 kernel averages ride along
+        pmc = latest_profile("bench_pmc_hbm.json")
         if pmc is not None and (B, Lq, res, a.dist) == (5, 300, "360p", "U"):
             for key, names in (("roofline", ["msda_fwd_d32_kernel"]),
                                ("roofline_bwd", ["msda_bwd_d32_kernel", "msda_bwd_gv_rec_kernel", "msda_bwd_gv_sel_kernel"])):
-                vals = [v.get("hbm_bytes_per_launch_corrected") for k, v in pmc["data"].items()
-                        if any(n in k for n in names)]
+                vals = [v.get("hbm_bytes_per_launch_corrected") for k, v in pmc["data"].items() if any(n in k for n in names)]
                 if vals and all(v is not None for v in vals):
                     line[key]["traffic"] = sum(vals)
                     line[key]["traffic_source"] = pmc["file"]
-        line["roofline_bwd"]["us_grad_loc_kernel"], line["roofline_bwd"]["us_grad_value_kernel"] = k_us[2], k_us[3]
+        prof = latest_profile("bench_kernel_avg_us.json")
+        if prof is not None:
+            line["rocprofv3_kernel_avg_us"] = {"source": prof["file"], **prof["data"]}
         line["fwd_gpoints_per_s"] = points / us_fwd / 1e3
+        if not a.no_cases and world == 1:
+            line["op_cases"] = op_case_rooflines(op, device)
+            line.update({"roofline_" + k: v for k, v in head_rooflines(device).items()})
         if not a.no_cpu and world == 1:     # the CPU leg runs at N = 1 only
             line["cpu_baseline"] = cpu_baseline(B, Lq, res)
         print(json.dumps(line), flush=True)

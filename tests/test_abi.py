@@ -33,7 +33,20 @@ def test_library_exports_every_declared_symbol(hip_lib):
 
 def test_ctypes_table_matches_header():
     from vnext_amd import _lib
-    assert sorted(_lib.SIGNATURES) == declared_functions()
+    assert sorted({**_lib.SIGNATURES, **_lib.DEBUG_SIGNATURES}) == declared_functions()
+    # the drop-in boundary itself is vnext_hip.h; the debug header only adds vnx_debug_* names
+    assert all(n.startswith("vnx_debug_") for n in _lib.DEBUG_SIGNATURES)
+    assert not any(n.startswith("vnx_debug_") for n in _lib.SIGNATURES)
+
+
+def test_library_exports_nothing_undeclared():
+    """The other direction: every C symbol the product library exports is declared in include/."""
+    import subprocess
+    from vnext_amd import _lib
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted(line.split()[-1] for line in out.splitlines()
+                      if len(line.split()) == 3 and line.split()[1] == "T" and not line.split()[2].startswith("_"))
+    assert exported == declared_functions()
 
 
 def test_abi_version_and_status_strings(hip_lib):

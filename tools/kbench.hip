@@ -383,6 +383,22 @@ int main(int argc, char** argv) {
                pc(en, .5), pc(en, .9), en.empty() ? 0 : en.back());
         for (int k = 0; k < 8; ++k) printf(" %.1f/%.1f", hm[k] / std::max(hn[k], 1), hx[k]);
         printf("\n");
+        {   // phase stamps (diagnostic library builds with -DVNX_SEL_STAMPS fill slots 1..11), light vs heavy workgroups
+          const char* nm[13] = {"", "table", "tags", "bar", "compact", "stage", "sort", "apply", "bar", "", "", "rest", "store"};
+          for (int heavy = 0; heavy < 2; ++heavy) {
+            double sum[13] = {0}; int n = 0;
+            for (int w = 0; w < 4096; ++w) {
+              const unsigned long long* t = &hs[w * 16];
+              if (!(t[12] > t[0]) || t[1] == 0) continue;
+              const double d = (t[12] - t[0]) * 0.01;
+              if ((d > 11.0) != bool(heavy)) continue;
+              ++n;
+              unsigned long long prev = t[0];
+              for (int k = 1; k <= 12; ++k) if (t[k] >= prev && t[k] != 0) { sum[k] += (t[k] - prev) * 0.01; prev = t[k]; }
+            }
+            if (n) { printf("    %s workgroups (%d): ", heavy ? "heavy (> 11 us)" : "light", n); for (int k = 1; k <= 12; ++k) if (nm[k][0]) printf(" %s %.2f", nm[k], sum[k] / n); printf("\n"); }
+          }
+        }
         vnx_set_kernel_variant(v);
       }
       if (nreg > 0) {

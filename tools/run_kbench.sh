@@ -1,4 +1,3 @@
 cd $GRAFT_REPO_ROOT
 K=$GRAFT_REPO_ROOT/tools/kbench.bin
-$K --shape dec360 --dist U --op both --variants 0 --inner 24 --reps 9 --check
-$K --shape enc360 --dist M --op bwd --variants 0 --inner 8 --reps 7 --check
+LD_LIBRARY_PATH=$GRAFT_REPO_ROOT/vnext_amd/lib/expst $K --shape dec360 --dist U --op bwd --variants 0 --inner 24 --reps 5 --timeline

@@ -23,6 +23,10 @@ with open(dst + "_kernel_stats.csv", "w") as f:
         w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"],
                     r["MinNs"], r["MaxNs"], r["StdDev"]])
 
+# kernel -> average microseconds of the traced command (what bench.py's roofline figures must agree with)
+avg = {short(r["Name"]): {"avg_us": float(r["AverageNs"]) / 1e3, "calls": int(r["Calls"])} for r in rows if "vnx::" in r["Name"]}
+json.dump(avg, open(dst + "_kernel_avg_us.json", "w"), indent=1, sort_keys=True)
+
 pmc = {}
 for tag, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     path = os.path.join(src, f"{tag}_counter_collection.csv")

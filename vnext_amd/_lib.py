@@ -37,6 +37,16 @@ SIGNATURES = {
     "vnx_set_kernel_variant": (None, [_i]),
     "vnx_get_kernel_variant": (_i, []),
 }
+# measurement aids of include/vnext_hip_debug.h (bench.py, tools/): not part of the drop-in boundary
+_ll = ctypes.c_longlong
+DEBUG_SIGNATURES = {
+    "vnx_debug_arm_stamps": (None, [_vp, _ll]),
+    "vnx_debug_stamp_regions": (_i, [ctypes.POINTER(_i), ctypes.POINTER(_ll), ctypes.POINTER(_ll), _i]),
+    "vnx_debug_wall_clock_khz": (_i, []),
+    "vnx_debug_read_rec_stamps": (_i, [ctypes.POINTER(ctypes.c_ulonglong), _i]),
+    "vnx_debug_read_tile_stamps": (_i, [ctypes.POINTER(ctypes.c_ulonglong), _i]),
+    "vnx_debug_row_gather_probe": (_i, [_vp, _sz, _vp, _sz, _i, _vp, _vp]),
+}
 
 _lib = None
 
@@ -57,7 +67,7 @@ def lib() -> ctypes.CDLL:
         # the HIP runtime torch's allocator and streams live in.
         import torch  # noqa: F401
         cdll = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
-        for name, (res, args) in SIGNATURES.items():
+        for name, (res, args) in {**SIGNATURES, **DEBUG_SIGNATURES}.items():
             fn = getattr(cdll, name)
             fn.restype = res
             fn.argtypes = args

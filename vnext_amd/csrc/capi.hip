@@ -7,6 +7,7 @@
 #include <mutex>
 
 #include "vnx_common.h"
+#include "../../include/vnext_hip_debug.h"
 
 namespace vnx {
 
@@ -200,14 +201,18 @@ int vnx_debug_wall_clock_khz(void) {
 }
 int vnx_get_kernel_variant(void) { return g_kernel_variant; }
 
-// The spatially tiled, LDS-staged forward (msda_d32_tile.hip) takes the calls whose queries are the
-// pixels of the pyramid -- the encoder's -- which the host can only recognise by Lq == S (the level
+// The spatially tiled, LDS-staged forward (msda_d32_tile.hip) is built for the calls whose queries are
+// the pixels of the pyramid -- the encoder's -- which the host can only recognise by Lq == S (the level
 // sizes live on the device); the kernel itself checks the rest and stays correct either way.
-// Variants 700..702 force it (701 / 702: with phase stamps), 710 keeps it off.
+// Measured on MI355X against the per-query gather kernel (B = 5, model-like locations, cold): 720p
+// 257-274 vs 266-289 us (it wins, 3-5 %), 360p 70 vs 62 us (it loses: it is bound by VALU issue -- 7 vector
+// instructions per FMA pair once decode, records, staging and bounding boxes are counted -- where the
+// gather kernel is bound by the L1/TA rate), uniform random locations 95 vs 77 us.  So automatic selection
+// takes it from 12 288 pixels up only.  Variants 700..702 force it (701 / 702: phase stamps), 710 keeps it off.
 static bool use_tile_forward(int vdt, int ldt, const MsdaDims& d, int variant) {
   if (!msda_tile_fwd_supported(vdt, ldt, d)) return false;
   if (variant >= 700 && variant <= 702) return true;
-  return variant == 0 && d.Lq == d.S && d.S >= 1024;
+  return variant == 0 && d.Lq == d.S && d.S >= 12288;
 }
 
 int vnx_msda_forward(int value_dtype, int loc_dtype, const void* value,
@@ -492,3 +497,37 @@ int vnx_msda_fused_backward(int value_dtype, int query_dtype, const void* value,
 }
 
 }  // extern "C"
+
+// ---- row-gather probe (include/vnext_hip_debug.h) ---------------------------------------------------
+namespace vnx {
+typedef float probe_f4 __attribute__((ext_vector_type(4)));
+template <int NF>
+__global__ void __launch_bounds__(256) row_gather_probe_kernel(const probe_f4* __restrict__ rows, const uint32_t* __restrict__ idx,
+                                                                size_t n_idx, float* __restrict__ sink) {
+  const size_t set = (blockIdx.x * size_t(blockDim.x) + threadIdx.x) >> 3, sets = (size_t(gridDim.x) * blockDim.x) >> 3;
+  const int ch = threadIdx.x & 7;
+  probe_f4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (size_t i = set * NF; i + NF <= n_idx; i += sets * NF) {
+    probe_f4 v[NF];
+#pragma unroll
+    for (int j = 0; j < NF; ++j) v[j] = rows[size_t(idx[i + j]) * 8 + ch];
+#pragma unroll
+    for (int j = 0; j < NF; ++j) acc += v[j];
+  }
+  if (acc.x == 1.2345e-31f) { sink[0] = acc.x; sink[1] = acc.y; sink[2] = acc.z; sink[3] = acc.w; }
+}
+}  // namespace vnx
+
+extern "C" int vnx_debug_row_gather_probe(const void* rows, size_t n_rows, const uint32_t* idx, size_t n_idx, int in_flight,
+                                          float* sink, void* hip_stream) {
+  if (!rows || !idx || !sink || n_rows == 0) {
+    vnx::set_error("vnx_debug_row_gather_probe: null pointer argument");
+    return VNX_ERR_INVALID_ARGUMENT;
+  }
+  hipStream_t st = (hipStream_t)hip_stream;
+  const dim3 grid(8192), block(256);
+#define VNX_PROBE(NF) hipLaunchKernelGGL((vnx::row_gather_probe_kernel<NF>), grid, block, 0, st, (const vnx::probe_f4*)rows, idx, n_idx, sink)
+  if (in_flight >= 8) VNX_PROBE(8); else if (in_flight >= 4) VNX_PROBE(4); else if (in_flight >= 2) VNX_PROBE(2); else VNX_PROBE(1);
+#undef VNX_PROBE
+  return vnx::check_launch("row_gather_probe");
+}

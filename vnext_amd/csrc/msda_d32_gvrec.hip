@@ -102,6 +102,13 @@ __device__ unsigned long long g_rec_stamps[4096 * 16];
           debug == 5 ? (unsigned long long)wall_clock64() : __builtin_readcyclecounter(); \
   } while (0)
 
+// More stamps inside the selection kernel cost it ~20 spilled registers: diagnostic builds only (-DVNX_SEL_STAMPS)
+#ifdef VNX_SEL_STAMPS
+#define VNX_SEL_STAMP(k) VNX_STAMP(k)
+#else
+#define VNX_SEL_STAMP(k) do { } while (0)
+#endif
+
 // RS (register slab): the rows a group owns accumulate in its registers (4 VGPRs per row)
 // instead of a 40 KiB LDS slab -- no slab zero-fill, no read-modify-write in the apply phase, and
 // the LDS left (staged rows + tap list + counters, 37 KiB) lets 3 units share a CU at <= 80 VGPRs
@@ -427,6 +434,7 @@ msda_bwd_gv_sel_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
   for (int i = tid; i < 2 * kRowsMax; i += kThreads) cnt2[i] = 0;
   if (tid == 0) alloc[0] = 0;
   __syncthreads();
+  VNX_SEL_STAMP(1);
 
   int lvl = -1, r0 = 0, r1 = 0, Hl = 0, Wl = 0, start = 0, u_lvl = 0;
   {
@@ -490,7 +498,9 @@ msda_bwd_gv_sel_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
       hitbits |= uint32_t(hit) << r | uint32_t(first) << (8 + r);
       if (lane == 0) { part_s[r * kWaves + wave] = uint32_t(__popcll(bh)); part_q[r * kWaves + wave] = uint32_t(__popcll(bf)); }
     }
+    if (win0 == 0) VNX_SEL_STAMP(2);
     __syncthreads();
+    if (win0 == 0) VNX_SEL_STAMP(3);
     if (tid < 64) {                                   // one wave scans the 32 (round, wave) pieces
       const uint32_t ns = tid < kSelParts ? part_s[tid] : 0u, nq = tid < kSelParts ? part_q[tid] : 0u;
       const uint32_t is = wave_inclusive_scan(ns), iq = wave_inclusive_scan(nq);
@@ -521,6 +531,7 @@ msda_bwd_gv_sel_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
     const int n_chunks = (n_q + kQcMax - 1) / kQcMax;
     if (tid == 0) cs[n_chunks] = uint32_t(n_sel);
     __syncthreads();
+    if (win0 == 0) VNX_SEL_STAMP(4);
 
     // ---- chunks of <= 128 distinct queries over the kept samples -----------------------------
     const int q_win = win0 >> 2;
@@ -547,6 +558,7 @@ msda_bwd_gv_sel_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
       const uint32_t slot = uint32_t(next_slot);
       grows[g0] = pg0;
       grows[g1] = pg1;
+      if (win0 == 0 && c == 0) VNX_SEL_STAMP(5);
       if (c + 1 < n_chunks) prefetch(c + 1);
       uint32_t mask = 0;
       int row00 = 0;
@@ -585,6 +597,7 @@ msda_bwd_gv_sel_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
       for (int t = 0; t < 4; ++t)
         if (mask & (1u << t)) list[offs[row00 + dr[t]] + rank[t]] = uint2_t{slot, __float_as_uint(wt[t])};
       __syncthreads();
+      if (win0 == 0 && c == 0) VNX_SEL_STAMP(6);
       if (tid == 0) alloc[0] = 0;
       uint32_t rn[kRpg], ro[kRpg];
 #pragma unroll
@@ -614,9 +627,12 @@ msda_bwd_gv_sel_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
         }
         racc[k] += a1;
       }
+      if (win0 == 0 && c == 0) VNX_SEL_STAMP(7);
       __syncthreads();
+      if (win0 == 0 && c == 0) VNX_SEL_STAMP(8);
     }
   }
+  VNX_SEL_STAMP(11);
 
   TV* out = grad_value + ((int64_t(b) * d.S + start + r0) * d.M + m) * D;
 #pragma unroll
