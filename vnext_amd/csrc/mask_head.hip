@@ -33,6 +33,10 @@ constexpr int kMhStripH = 5;      // stored rows per wave (+1 halo row, all held
 static_assert(kMhParams == 169, "parameter vector layout");
 
 typedef float float2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t sgpr2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t sgpr4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t sgpr8_t __attribute__((ext_vector_type(8)));
+typedef uint32_t sgpr16_t __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ float lane_below(float v) {
   // lane l receives lane l-1 (wave_shr:1); lane 0 keeps its own value, which is never used
@@ -40,45 +44,68 @@ __device__ __forceinline__ float lane_below(float v) {
                                                                 0x138, 0xF, 0xF, false));
 }
 
-__global__ void __launch_bounds__(256)
+// d += w * x for a row pair, w = the low (HI = false) or high half of an SGPR pair broadcast to both rows.
+// Written as asm: given `float2{w, w}` hipcc copies every weight into a fresh SGPR pair and, three row pairs
+// later, spills those copies to VGPR lanes (536 v_readlane + 262 v_writelane beside 440 FMAs per wave).
+template <bool HI>
+__device__ __forceinline__ void pk_fma_bcast(float2_t& d, uint64_t w_pair, float2_t x) {
+  if (HI) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(d) : "s"(w_pair), "v"(x));
+  else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(d) : "s"(w_pair), "v"(x));
+}
+
+// HALVES = 1: the wave is one strip of 63 columns (+ halo lane 0).  HALVES = 2: two strips of 31 columns
+// (+ halo lanes 0 and 32) stacked vertically -- lanes 32..63 take the kMhStripH rows below those of lanes
+// 0..31.  The launcher picks whichever wastes fewer lanes on the frame's width: at 80 columns (360p) one
+// 63-wide strip pair leaves 46 of 126 lanes idle, three 31-wide ones 13 of 93.
+template <int HALVES>
+__global__ void __launch_bounds__(256)      // (256, 5) -- 96 VGPRs, 4 500 waves of a 360p frame resident at once -- spills 13 registers: 16.5 vs 14.6 us
 dynamic_mask_head_kernel(const float* __restrict__ feats, const float* __restrict__ ref,
                          const float* __restrict__ params, const int* __restrict__ inst_image,
                          float* __restrict__ out, int H, int W, int n_inst, int stride,
                          int strips_x, int strips_y) {
   const int lane = threadIdx.x & 63;
   const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t wave_id = int64_t(blockIdx.x) * 4 + wave_in_block;
-  const int strips = strips_x * strips_y;
+  const uint32_t wave_id = blockIdx.x * 4u + uint32_t(wave_in_block);     // the launcher keeps this below 2^31
+  const uint32_t strips = uint32_t(strips_x * strips_y);
   const int j = int(wave_id / strips);  // instance
   if (j >= n_inst) return;
-  const int s = int(wave_id - int64_t(j) * strips);
+  const int s = int(wave_id - uint32_t(j) * strips);
   const int sy = s / strips_x, sx = s - sy * strips_x;
-  const int x = sx * kMhStripW - 1 + lane;          // lane 0 is the left halo
+  constexpr int kLanes = 64 / HALVES, kCols = kLanes - 1;
+  const int lane_in = lane & (kLanes - 1), half_id = lane / kLanes;
+  const int x = sx * kCols - 1 + lane_in;           // lane 0 of a strip is its left halo
   const int xc = x < 0 ? 0 : (x > W - 1 ? W - 1 : x);
-  const int y0 = sy * kMhStripH;
+  const int y0 = (sy * HALVES + half_id) * kMhStripH;
 
-  // The instance's 169 parameters are wave-uniform: scalar loads, SGPR operands of the packed
-  // FMAs.  Alternatives measured on MI355X at 300 instances x 48x80 (tools/mask_head_scaling.py):
-  // lane-parked copy + v_readlane 24.0 us (617 readlanes + 221 s_nops per wave), LDS broadcast
-  // reads 31.6 us (the scheduler hoists all 169 reads: 256 VGPRs or spills), this form 24-26 us.
-  // The kernel is VALU-issue bound (~1300 issued instructions per wave at ~4 clk each), not
-  // memory bound; the HBM roofline (18.4 MB of logits, ~3 us) is 8x away.
+  // The instance's 169 parameters are wave-uniform: scalar loads, SGPR operands of the packed FMAs
+  // (v_pk_fma_f32 takes one SGPR pair and broadcasts either half with op_sel).  What decides the speed is
+  // HOW MANY of them are live: left to itself hipcc hoists all eleven s_load_dwordx16 to the top of the
+  // kernel, 169 values meet ~100 SGPRs, and the rest lives in VGPR lanes -- 655 v_readlane + 371
+  // v_writelane beside 432 v_pk_fma_f32 per wave (27 us per 360p frame at 300 instances).  Here the
+  // parameters arrive in groups of two output channels (asm s_load, at most two groups in flight, waited
+  // for by hand), so none of them ever leaves the scalar file: 14.6 us.  Other forms measured on MI355X
+  // (tools/time_heads.py): the parameters parked across the lanes of three VGPRs and read back pair by pair
+  // with v_readlane where consumed (no scalar loads inside the layers, 169 more instructions per wave) 15.4 us;
+  // LDS broadcast reads 31.6 us.  PMC of this form: 868 vector instructions per wave (440 packed FMAs, 192
+  // v_max -- gfx950 has no packed max --, the rest bias moves, addresses and the up-sampling), VALU busy 48 %
+  // of the kernel at ~1.9 GHz; the output write (18.4 MB) would take 3 us.
   const float* P = params + int64_t(j) * kMhParams;
-  auto param = [&](int k) -> float { return P[k]; };
   constexpr int W0 = 0, W1 = 80, W2 = 144, B0 = 152, B1 = 160, B2 = 168;
   const float refx = ref[2 * j], refy = ref[2 * j + 1];
   const int img = inst_image[j];
-  const float* F = feats + int64_t(img) * kMhChannels * H * W;
+  // the frame's 8 feature planes through one buffer descriptor: per-lane offset = the pixel, scalar offset =
+  // the plane -- 8 scalars instead of a 64-bit base address per (plane, row) pair (96 SGPRs, spilled)
+  const __amdgpu_buffer_rsrc_t fsrc = uniform_rsrc(feats + int64_t(img) * kMhChannels * H * W,
+                                                   uint32_t(kMhChannels) * uint32_t(H * W) * 4u);
+  const uint32_t plane_bytes = uint32_t(H * W) * 4u;
   const float half = float(stride / 2);
   const float relx = refx - (float(xc * stride) + half);
 
   float* O = out + int64_t(j) * (2 * H) * (2 * W);
 
-  // All rows of the strip (plus the halo row above it) live in registers, so every one of the
-  // 169 parameters is fetched (scalar load) exactly once per wave and the 8 x (R+1) feature
-  // loads are all in flight together.  Rows are processed in PAIRS held as float2 so the layer
-  // arithmetic compiles to v_pk_fma_f32 (two FMAs per issued instruction): the kernel is
-  // VALU-issue bound (PMC: SQ_ACTIVE_INST_VALU ~ 80 % of the kernel), not memory bound.
+  // All rows of the strip (plus the halo row above it) live in registers, so every parameter is fetched
+  // exactly once per wave and the 8 x (R+1) feature loads are all in flight together.  Rows are processed
+  // in PAIRS held as float2 so the layer arithmetic is v_pk_fma_f32 (two FMAs per issued instruction).
   constexpr int R1 = kMhStripH + 1;        // rows computed
   static_assert(R1 % 2 == 0, "rows are processed in pairs");
   constexpr int RP = R1 / 2;
@@ -92,64 +119,121 @@ dynamic_mask_head_kernel(const float* __restrict__ feats, const float* __restric
       const int yc = y < 0 ? 0 : (y > H - 1 ? H - 1 : y);
       v[h][0] = relx;
       v[h][1] = refy - (float(yc * stride) + half);
+      const uint32_t pix = uint32_t(yc * W + xc) * 4u;
 #pragma unroll
-      for (int c = 0; c < kMhChannels; ++c) v[h][2 + c] = F[(int64_t(c) * H + yc) * W + xc];
+      for (int c = 0; c < kMhChannels; ++c)
+        v[h][2 + c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(fsrc, int(pix), int(uint32_t(c) * plane_bytes), 0));
     }
 #pragma unroll
     for (int i = 0; i < kMhChannels + 2; ++i) x0[p][i] = float2_t{v[0][i], v[1][i]};
   }
   const float2_t zero2 = {0.f, 0.f};
+
+  // a group of parameters in the scalar file: 20 (or 16) weights of two output channels + their two biases
+  struct Group { sgpr16_t w; sgpr4_t w2; sgpr2_t b; };
+  auto fetch20 = [&](Group& g, int w_at, int b_at) {   // 20 consecutive weights, 2 consecutive biases
+    asm volatile("s_load_dwordx16 %0, %3, %4\n\ts_load_dwordx4 %1, %3, %5\n\ts_load_dwordx2 %2, %3, %6"
+                 : "=&s"(g.w), "=&s"(g.w2), "=&s"(g.b)
+                 : "s"(P), "n"(w_at * 4), "n"(w_at * 4 + 64), "n"(b_at * 4)
+                 : "memory");
+  };
+  auto fetch16 = [&](Group& g, int w_at, int b_at) {   // 16 consecutive weights, 2 consecutive biases
+    asm volatile("s_load_dwordx16 %0, %2, %3\n\ts_load_dwordx2 %1, %2, %4"
+                 : "=&s"(g.w), "=&s"(g.b)
+                 : "s"(P), "n"(w_at * 4), "n"(b_at * 4)
+                 : "memory");
+  };
+  auto landed = [&](Group& g) {   // everything issued so far is in its registers (the loads are invisible to hipcc's own counting)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(g.w), "+s"(g.w2), "+s"(g.b)::"memory");
+  };
+  auto wpair = [](const Group& g, int k) -> uint64_t {   // weights 2k, 2k + 1 of the group as one SGPR pair
+    return k < 8 ? (uint64_t(g.w[2 * k + 1]) << 32) | g.w[2 * k] : (uint64_t(g.w2[2 * (k - 8) + 1]) << 32) | g.w2[2 * (k - 8)];
+  };
+
   float2_t x1[RP][kMhHidden];
-#pragma unroll
-  for (int o = 0; o < kMhHidden; ++o) {
-    float w[kMhChannels + 2];
-#pragma unroll
-    for (int i = 0; i < kMhChannels + 2; ++i) w[i] = param(W0 + o * (kMhChannels + 2) + i);
-    const float bias = param(B0 + o);
-#pragma unroll
-    for (int p = 0; p < RP; ++p) {
-      float2_t a = {bias, bias};
-#pragma unroll
-      for (int i = 0; i < kMhChannels + 2; ++i) a = __builtin_elementwise_fma(float2_t{w[i], w[i]}, x0[p][i], a);
-      x1[p][o] = __builtin_elementwise_max(a, zero2);
+  {
+    Group ga, gb;
+    ga.w2 = sgpr4_t{0u, 0u, 0u, 0u}; gb.w2 = ga.w2;
+#define VNX_L1(G, o0)                                                                                          \
+    _Pragma("unroll") for (int oo = 0; oo < 2; ++oo) {   /* weight outer, row pairs inner: a broadcast weight */   \
+      const float bias = __uint_as_float(G.b[oo]);         /* is used three times at once and never kept          */   \
+      float2_t a[RP];                                                                                            \
+      _Pragma("unroll") for (int p = 0; p < RP; ++p) a[p] = float2_t{bias, bias};                                \
+      _Pragma("unroll") for (int i = 0; i < kMhChannels + 2; i += 2) {                                           \
+        const uint64_t w2 = wpair(G, (oo * (kMhChannels + 2) + i) / 2);                                          \
+        _Pragma("unroll") for (int p = 0; p < RP; ++p) pk_fma_bcast<false>(a[p], w2, x0[p][i]);                  \
+        _Pragma("unroll") for (int p = 0; p < RP; ++p) pk_fma_bcast<true>(a[p], w2, x0[p][i + 1]);               \
+      }                                                                                                          \
+      _Pragma("unroll") for (int p = 0; p < RP; ++p) x1[p][(o0) + oo] = __builtin_elementwise_max(a[p], zero2);  \
     }
+    // (sched_barrier: without it the machine scheduler sinks every FMA block below the last fetch -- the asm
+    //  statements only order each other -- and all 169 values are live at once again)
+#define VNX_FENCE __builtin_amdgcn_sched_barrier(0);
+    fetch20(ga, W0, B0);
+    landed(ga); fetch20(gb, W0 + 20, B0 + 2); VNX_FENCE
+    VNX_L1(ga, 0) VNX_FENCE
+    landed(gb); fetch20(ga, W0 + 40, B0 + 4); VNX_FENCE
+    VNX_L1(gb, 2) VNX_FENCE
+    landed(ga); fetch20(gb, W0 + 60, B0 + 6); VNX_FENCE
+    VNX_L1(ga, 4) VNX_FENCE
+    landed(gb); VNX_FENCE
+    VNX_L1(gb, 6) VNX_FENCE
+#undef VNX_L1
   }
   float2_t x2[RP][kMhHidden];
-#pragma unroll
-  for (int o = 0; o < kMhHidden; ++o) {
-    float w[kMhHidden];
-#pragma unroll
-    for (int i = 0; i < kMhHidden; ++i) w[i] = param(W1 + o * kMhHidden + i);
-    const float bias = param(B1 + o);
-#pragma unroll
-    for (int p = 0; p < RP; ++p) {
-      float2_t a = {bias, bias};
-#pragma unroll
-      for (int i = 0; i < kMhHidden; ++i) a = __builtin_elementwise_fma(float2_t{w[i], w[i]}, x1[p][i], a);
-      x2[p][o] = __builtin_elementwise_max(a, zero2);
-    }
-  }
   float logit[R1];
   {
-    float w[kMhHidden];
-#pragma unroll
-    for (int i = 0; i < kMhHidden; ++i) w[i] = param(W2 + i);
-    const float bias = param(B2);
-#pragma unroll
-    for (int p = 0; p < RP; ++p) {
-      float2_t a = {bias, bias};
-#pragma unroll
-      for (int i = 0; i < kMhHidden; ++i) a = __builtin_elementwise_fma(float2_t{w[i], w[i]}, x2[p][i], a);
-      logit[2 * p] = a.x;
-      logit[2 * p + 1] = a.y;
+    Group ga, gb;
+    ga.w2 = sgpr4_t{0u, 0u, 0u, 0u}; gb.w2 = ga.w2;
+#define VNX_L2(G, o0)                                                                                          \
+    _Pragma("unroll") for (int oo = 0; oo < 2; ++oo) {                                                           \
+      const float bias = __uint_as_float(G.b[oo]);                                                               \
+      float2_t a[RP];                                                                                            \
+      _Pragma("unroll") for (int p = 0; p < RP; ++p) a[p] = float2_t{bias, bias};                                \
+      _Pragma("unroll") for (int i = 0; i < kMhHidden; i += 2) {                                                 \
+        const uint64_t w2 = wpair(G, (oo * kMhHidden + i) / 2);                                                  \
+        _Pragma("unroll") for (int p = 0; p < RP; ++p) pk_fma_bcast<false>(a[p], w2, x1[p][i]);                  \
+        _Pragma("unroll") for (int p = 0; p < RP; ++p) pk_fma_bcast<true>(a[p], w2, x1[p][i + 1]);               \
+      }                                                                                                          \
+      _Pragma("unroll") for (int p = 0; p < RP; ++p) x2[p][(o0) + oo] = __builtin_elementwise_max(a[p], zero2);  \
     }
+    fetch16(ga, W1, B1);
+    landed(ga); fetch16(gb, W1 + 16, B1 + 2); VNX_FENCE
+    VNX_L2(ga, 0) VNX_FENCE
+    landed(gb); fetch16(ga, W1 + 32, B1 + 4); VNX_FENCE
+    VNX_L2(gb, 2) VNX_FENCE
+    landed(ga); fetch16(gb, W1 + 48, B1 + 6); VNX_FENCE
+    VNX_L2(ga, 4) VNX_FENCE
+    landed(gb);
+    // the last layer's 8 weights + bias (W2 .. B2 are NOT contiguous: 144..151 and 168)
+    sgpr8_t w3; uint32_t b3;
+    asm volatile("s_load_dwordx8 %0, %2, %3\n\ts_load_dword %1, %2, %4" : "=&s"(w3), "=&s"(b3) : "s"(P), "n"(W2 * 4), "n"(B2 * 4) : "memory");
+    VNX_FENCE
+    VNX_L2(gb, 6) VNX_FENCE
+#undef VNX_L2
+#undef VNX_FENCE
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(w3), "+s"(b3)::"memory");
+    const float bias = __uint_as_float(b3);
+    float2_t a[RP];
+#pragma unroll
+    for (int p = 0; p < RP; ++p) a[p] = float2_t{bias, bias};
+#pragma unroll
+    for (int i = 0; i < kMhHidden; i += 2) {
+      const uint64_t w2 = (uint64_t(w3[i + 1]) << 32) | w3[i];
+#pragma unroll
+      for (int p = 0; p < RP; ++p) pk_fma_bcast<false>(a[p], w2, x2[p][i]);
+#pragma unroll
+      for (int p = 0; p < RP; ++p) pk_fma_bcast<true>(a[p], w2, x2[p][i + 1]);
+    }
+#pragma unroll
+    for (int p = 0; p < RP; ++p) { logit[2 * p] = a[p].x; logit[2 * p + 1] = a[p].y; }
   }
 #pragma unroll
   for (int r = 1; r < R1; ++r) {
     const int y = y0 + r - 1;
     const float cur = logit[r], prev = logit[r - 1];
     const float left = lane_below(cur), prev_left = lane_below(prev);
-    if (y < H && lane > 0 && x < W) {
+    if (y < H && lane_in > 0 && x < W) {
       const float2_t top = {0.25f * ((prev_left + prev) + (left + cur)), 0.5f * (prev + cur)};
       const float2_t bot = {0.5f * (left + cur), cur};
       *reinterpret_cast<float2_t*>(O + int64_t(2 * y) * (2 * W) + 2 * x) = top;
@@ -389,18 +473,27 @@ extern "C" int vnx_dynamic_mask_head_forward(int dtype, const void* mask_feats,
     set_error("vnx_dynamic_mask_head_forward: null pointer argument");
     return VNX_ERR_INVALID_ARGUMENT;
   }
-  const int strips_x = (width + kMhStripW - 1) / kMhStripW;
-  const int strips_y = (height + kMhStripH - 1) / kMhStripH;
+  // lanes spent per useful pixel by the two strip shapes (see the kernel): choose the tighter one
+  const int sx1 = (width + 62) / 63, sy1 = (height + kMhStripH - 1) / kMhStripH;
+  const int sx2 = (width + 30) / 31, sy2 = (height + 2 * kMhStripH - 1) / (2 * kMhStripH);
+  const bool halves = int64_t(sx2) * sy2 < int64_t(sx1) * sy1;
+  const int strips_x = halves ? sx2 : sx1, strips_y = halves ? sy2 : sy1;
   const int64_t waves = int64_t(num_insts) * strips_x * strips_y;
   const int64_t blocks = (waves + 3) / 4;
-  if (blocks >= (int64_t(1) << 31)) {
-    set_error("vnx_dynamic_mask_head_forward: %lld workgroups exceed the grid limit", (long long)blocks);
+  if (waves >= (int64_t(1) << 31)) {
+    set_error("vnx_dynamic_mask_head_forward: %lld waves exceed the grid limit", (long long)waves);
     return VNX_ERR_UNSUPPORTED;
   }
-  hipLaunchKernelGGL(dynamic_mask_head_kernel, dim3(uint32_t(blocks)), dim3(256), 0,
-                     (hipStream_t)hip_stream, (const float*)mask_feats, (const float*)reference_points,
-                     (const float*)params, (const int*)inst_image, (float*)out, height, width,
-                     num_insts, stride, strips_x, strips_y);
+  if (halves)
+    hipLaunchKernelGGL(dynamic_mask_head_kernel<2>, dim3(uint32_t(blocks)), dim3(256), 0,
+                       (hipStream_t)hip_stream, (const float*)mask_feats, (const float*)reference_points,
+                       (const float*)params, (const int*)inst_image, (float*)out, height, width,
+                       num_insts, stride, strips_x, strips_y);
+  else
+    hipLaunchKernelGGL(dynamic_mask_head_kernel<1>, dim3(uint32_t(blocks)), dim3(256), 0,
+                       (hipStream_t)hip_stream, (const float*)mask_feats, (const float*)reference_points,
+                       (const float*)params, (const int*)inst_image, (float*)out, height, width,
+                       num_insts, stride, strips_x, strips_y);
   return check_launch("dynamic_mask_head");
 }
 
