@@ -57,7 +57,7 @@ bool msda_d32_fused_supported(int vdt, int ldt, const MsdaDims& d);
 int msda_fused_d32(bool backward, int vdt, int ldt, const void* value, const int64_t* shapes, const int64_t* lsi,
                    const void* raw_off, const void* raw_logit, const void* grad_out, void* out_or_grad_off,
                    void* grad_logit, MsdaDims d, void* records, const void* reference, float* grad_reference,
-                   int ref_dim, int ref_div, hipStream_t stream);
+                   int ref_dim, int ref_div, void* grad_value_f32, hipStream_t stream);
 bool msda_d32_gvrec_supported(int vdt, int ldt, const MsdaDims& d);
 size_t msda_gvrec_record_bytes(const MsdaDims& d);
 int msda_backward_gvrec_d32(int vdt, const int64_t*, const int64_t*, const void* records, const void*,
@@ -335,8 +335,11 @@ int vnx_msda_backward(int value_dtype, int loc_dtype, const void* value,
         (void)hipGetLastError();  // fall back to one stream
     }
     if (!only_gv || with_rec) {
+      // records mode: the accumulation-image argument carries fp32 grad_value itself, whose rows of the
+      // query-split levels the kernel zeroes (gv_query_splits)
       st = msda_backward_d32(value_dtype, loc_dtype, value, spatial_shapes, level_start_index,
-                             sampling_loc, attn_weight, grad_output, nullptr, grad_sampling_loc,
+                             sampling_loc, attn_weight, grad_output,
+                             (with_rec && value_dtype == VNX_F32) ? grad_value : nullptr, grad_sampling_loc,
                              grad_attn_weight, d, only_gl ? variant : 100 + (variant < 100 ? variant : 0),
                              records, stream);
       if (st != VNX_OK) return st;
@@ -436,13 +439,13 @@ int vnx_msda_fused_forward(int value_dtype, int query_dtype, const void* value, 
     return VNX_ERR_INVALID_ARGUMENT;
   }
   if (use_tile_forward(value_dtype, query_dtype, d, g_kernel_variant)) {
-    const FusedArgs fa{reference_points, nullptr, ref_dim, reference_batch_div};
+    const FusedArgs fa{reference_points, nullptr, ref_dim, reference_batch_div, nullptr};
     return msda_forward_tile(value, spatial_shapes, level_start_index, sampling_offsets, attention_logits, output, d, &fa, 0,
                              (hipStream_t)hip_stream);
   }
   return msda_fused_d32(false, value_dtype, query_dtype, value, spatial_shapes, level_start_index, sampling_offsets,
                         attention_logits, nullptr, output, nullptr, d, nullptr, reference_points, nullptr, ref_dim,
-                        reference_batch_div, (hipStream_t)hip_stream);
+                        reference_batch_div, nullptr, (hipStream_t)hip_stream);
 }
 
 size_t vnx_msda_fused_backward_workspace_bytes(int batch, int num_heads, int num_levels, int num_query,
@@ -490,7 +493,8 @@ int vnx_msda_fused_backward(int value_dtype, int query_dtype, const void* value,
   // the records.  Packed levels are required (the records-fed kernel is a no-op on the device otherwise).
   st = msda_fused_d32(true, value_dtype, query_dtype, value, spatial_shapes, level_start_index, sampling_offsets,
                       attention_logits, grad_output, grad_sampling_offsets, grad_attention_logits, d, workspace,
-                      reference_points, grad_reference_points, ref_dim, reference_batch_div, stream);
+                      reference_points, grad_reference_points, ref_dim, reference_batch_div,
+                      value_dtype == VNX_F32 ? grad_value : nullptr, stream);
   if (st != VNX_OK) return st;
   return msda_backward_gvrec_d32(value_dtype, spatial_shapes, level_start_index, workspace, grad_output,
                                  grad_value, d, g_kernel_variant, stream);

@@ -173,6 +173,9 @@ __device__ __forceinline__ void fused_decode(const TL* __restrict__ raw_off, con
 #ifndef VNX_FWD_BATCH
 #define VNX_FWD_BATCH 4
 #endif
+#ifndef VNX_K1_BATCH
+#define VNX_K1_BATCH 4
+#endif
 #ifndef VNX_FWD_WPE
 #define VNX_FWD_WPE 0
 #endif
@@ -600,6 +603,24 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
 
   const uint32_t pixel_elems = uint32_t(d.M * D);
 
+  // ---- phase 0: zero the grad_value rows of the query-split levels (gv_query_splits) of this (batch, head):
+  //      the tiles of a batch element share the rows, eight rows per wave and step -----------------------
+  if constexpr (!ATOMICS && sizeof(TV) == 4) {
+    if (fa.qsplit_zero != nullptr && sample_units != nullptr && d.Lq >= 1024 && levels_packed(shapes, lsi, d.L, d.S)) {
+      const int t_in_b = tile - b * tiles_per_batch;
+      for (int l = 0; l < d.L; ++l) {
+        const int n = int(shapes[2 * l]) * int(shapes[2 * l + 1]);
+        int units = (n + kGvRowsMax - 1) / kGvRowsMax;
+        if (units < units_min) units = units_min;
+        if (gv_query_splits(units, d.Lq, d.P, true) > 1) {
+          float* rows = fa.qsplit_zero + ((int64_t(b) * d.S + int(lsi[l])) * d.M + m) * D;
+          for (int r = (t_in_b * WPB + wave) * 8 + (lane >> 3); r < n; r += tiles_per_batch * WPB * 8)
+            *reinterpret_cast<float4_t*>(rows + int64_t(r) * d.M * D + (lane & 7) * 4) = float4_t{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+    }
+  }
+
   // ---- phase 1 ------------------------------------------------------------------
   const int pairs = QPW * LP;
   int keep_H = 1, keep_W = 1;      // level size of this lane's sample: reused by phase 3 when pairs <= 64
@@ -730,8 +751,12 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
     // As in the forward: the row loads of a whole batch of samples are issued before the first use.  (Left
     // to the compiler this loop waited for four loads at a time, eight dependent memory round trips per
     // wave at the decoder shape: 10.9 us per workgroup against the forward's 6.2.)
+    // Batch: 4 samples (16 loads, 118 VGPRs) for the small, latency-bound calls (one wave per workgroup);
+    // 2 for the large ones (4 waves per workgroup, rows > 4096), which are bound by how many waves fit:
+    // encoder shape 106 vs 112 us.
     constexpr int kPer = LP_T / PG;
-    constexpr int kBatch = kPer < 4 ? kPer : 4;
+    constexpr int kWant = WPB == 1 ? VNX_K1_BATCH : 2;
+    constexpr int kBatch = kPer < kWant ? kPer : kWant;
 #pragma unroll
     for (int i0 = 0; i0 < kPer; i0 += kBatch) {
       uint4_t o[kBatch];
@@ -807,6 +832,9 @@ static int launch_bwd_cfg(const void* value, const int64_t* shapes, const int64_
                           const void* loc, const void* attn, const void* grad_out, void* gv,
                           void* grad_loc, void* grad_attn, const MsdaDims& d, bool atomics,
                           void* records, hipStream_t stream) {
+  // records mode: `gv` is not an accumulation image but fp32 grad_value itself (or null), whose rows of the
+  // query-split levels this kernel zeroes for the grad_value kernel's atomics
+  void* qsplit_zero = (!atomics && records != nullptr && sizeof(TV) == 4) ? gv : nullptr;
   const int LP = d.L * d.P;
   const int tiles_per_batch = (d.Lq + QPW * WPB - 1) / (QPW * WPB);
   const int64_t blocks = int64_t(d.B) * tiles_per_batch * d.M;
@@ -824,7 +852,7 @@ static int launch_bwd_cfg(const void* value, const int64_t* shapes, const int64_
                      dim3(64 * WPB), lds, stream, (const TV*)value, shapes, lsi, (const TL*)loc, \
                      (const TL*)attn, (const TV*)grad_out, (float*)gv, (TL*)grad_loc,            \
                      (TL*)grad_attn, d, tiles_per_batch, (uint4_t*)records, (uint32_t*)unit_ids, units_min,       \
-                     take_stamp_region(kStampGradLoc, blocks), FusedArgs{})
+                     take_stamp_region(kStampGradLoc, blocks), FusedArgs{nullptr, nullptr, 0, 0, (float*)qsplit_zero})
   if (!atomics) { if (LP == 16) VNX_LAUNCH(16, false); else VNX_LAUNCH(0, false); }
   else { if (LP == 16) VNX_LAUNCH(16, true); else VNX_LAUNCH(0, true); }
 #undef VNX_LAUNCH
@@ -936,8 +964,9 @@ bool msda_d32_fused_supported(int vdt, int ldt, const MsdaDims& d) {
 int msda_fused_d32(bool backward, int vdt, int ldt, const void* value, const int64_t* shapes, const int64_t* lsi,
                    const void* raw_off, const void* raw_logit, const void* grad_out, void* out_or_grad_off,
                    void* grad_logit, MsdaDims d, void* records, const void* reference, float* grad_reference,
-                   int ref_dim, int ref_div, hipStream_t stream) {
-  const FusedArgs fa{reference, grad_reference, ref_dim, ref_div};
+                   int ref_dim, int ref_div, void* grad_value_f32, hipStream_t stream) {
+  const FusedArgs fa{reference, grad_reference, ref_dim, ref_div,
+                     (backward && vdt == VNX_F32) ? static_cast<float*>(grad_value_f32) : nullptr};
 #define VNX_ARGS backward, value, shapes, lsi, raw_off, raw_logit, grad_out, out_or_grad_off, grad_logit, d, records, fa, stream
   if (vdt == VNX_F32) return fused_dispatch<float, float>(VNX_ARGS);
   if (vdt == VNX_BF16 && ldt == VNX_F32) return fused_dispatch<bf16_t, float>(VNX_ARGS);

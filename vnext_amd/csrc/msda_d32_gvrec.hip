@@ -136,10 +136,11 @@ msda_bwd_gv_rec_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
   // level back (below), so the coarse levels' units -- three sort chunks each at the decoder shape against
   // one for a fine-level unit, 12-15 us against 6-7 -- start first instead of last (they used to start up
   // to 7 us into the kernel and set its end: 20 us for 8.5 us of mean work per workgroup).
-  // Tried on top of it: splitting the coarse levels' units by query range as well (one sort chunk per piece),
-  // the pieces meeting in grad_value through agent-scope fp32 atomics on rows zeroed by the grad_loc kernel.
-  // Correct, and slower: 48.7 vs 32.2 us per decoder backward -- 1.15 M contended L2-bypassing atomics cost
-  // the pieces 12-25 us each.  Reverted.
+  // (The coarse levels' units are also split by query range from 1024 queries up: gv_query_splits.)
+  // Tried: a per-(level, window) table of the unit range its samples touch, filled by the grad_loc kernel with
+  // atomicMin, so that a unit skips empty selection windows.  The 400 K same-address atomics took the
+  // grad_loc kernel from 108 to 700 us at the encoder shape (12 to 160 at the decoder shape) and the skipped
+  // windows bought this kernel 5 us of 130: a window that selects nothing costs a tag load and a ballot.
   const int rest = blockIdx.x / d.M;
   const int unit = rest / d.B;
   const int b = rest - unit * d.B;
@@ -428,15 +429,16 @@ msda_bwd_gv_sel_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
       rpu = (n + units - 1) / units;
       units = (n + rpu - 1) / rpu;
     }
+    const int qs = gv_query_splits(units, d.Lq, P, sizeof(TV) == 4);
     meta[4 * tid] = H; meta[4 * tid + 1] = W; meta[4 * tid + 2] = int(lsi[tid]);
-    meta[4 * tid + 3] = units | (rpu << 12);
+    meta[4 * tid + 3] = units | (rpu << 12) | (qs << 24);     // units <= 4000, rpu <= 320, qs <= 8
   }
   for (int i = tid; i < 2 * kRowsMax; i += kThreads) cnt2[i] = 0;
   if (tid == 0) alloc[0] = 0;
   __syncthreads();
   VNX_SEL_STAMP(1);
 
-  int lvl = -1, r0 = 0, r1 = 0, Hl = 0, Wl = 0, start = 0, u_lvl = 0;
+  int lvl = -1, r0 = 0, r1 = 0, Hl = 0, Wl = 0, start = 0, u_lvl = 0, qsplit = 1, qpiece = 0;
   {
     int running = 0;
     bool packed = true;
@@ -447,14 +449,15 @@ msda_bwd_gv_sel_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
     }
     for (int l = d.L - 1; l >= 0; --l) {       // units are numbered from the last (coarsest) level back
       const int H = meta[4 * l], W = meta[4 * l + 1], st = meta[4 * l + 2], ur = meta[4 * l + 3];
-      const int n = H * W, units = ur & 0xfff, rpu = ur >> 12;
+      const int n = H * W, units = ur & 0xfff, rpu = (ur >> 12) & 0xfff, qs = ur >> 24;
       if (lvl < 0) {
-        if (u < units) {
-          lvl = l; Hl = H; Wl = W; start = st; u_lvl = u;
-          r0 = u * rpu;
+        if (u < units * qs) {        // a level's workgroups: row-unit major, query piece minor
+          lvl = l; Hl = H; Wl = W; start = st; qsplit = qs;
+          u_lvl = u / qs; qpiece = u - u_lvl * qs;
+          r0 = u_lvl * rpu;
           r1 = r0 + rpu < n ? r0 + rpu : n;
         } else {
-          u -= units;
+          u -= units * qs;
         }
       }
     }
@@ -480,8 +483,11 @@ msda_bwd_gv_sel_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
   const uint32_t below = uint32_t(lane & 3);
   int gchunk = 0;                                    // parity of the double-buffered row counters
 
-  for (int win0 = 0; win0 < n_samples; win0 += kWin) {
-    const int n_w = n_samples - win0 < kWin ? n_samples - win0 : kWin;
+  // the queries this workgroup takes: all of them, or one piece of a query-split level
+  const int q_per = (d.Lq + qsplit - 1) / qsplit;
+  const int s_lo = qpiece * q_per * P, s_hi = (qpiece + 1) * q_per * P < n_samples ? (qpiece + 1) * q_per * P : n_samples;
+  for (int win0 = s_lo; win0 < s_hi; win0 += kWin) {
+    const int n_w = s_hi - win0 < kWin ? s_hi - win0 : kWin;
     // ---- selection: which samples of this window touch my rows -----------------------------
     unsigned long long bal[kSelRounds], balf[kSelRounds];
     uint32_t hitbits = 0;
@@ -635,6 +641,21 @@ msda_bwd_gv_sel_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
   VNX_SEL_STAMP(11);
 
   TV* out = grad_value + ((int64_t(b) * d.S + start + r0) * d.M + m) * D;
+  if constexpr (sizeof(TV) == 4) {
+    if (qsplit > 1) {   // pieces of a query-split level meet through fp32 atomics (rows zeroed by the grad_loc kernel);
+                        // a group's 8 lanes x 4 dwords = one row's 32 consecutive dwords per instruction group
+#pragma unroll
+      for (int k = 0; k < kRpg; ++k) {
+        const int row = grp + k * kGroups;
+        if (row < rows) {
+          float* p = reinterpret_cast<float*>(out) + int64_t(row) * d.M * D + ch4 * 4;
+          atomic_add(p, racc[k].x); atomic_add(p + 1, racc[k].y); atomic_add(p + 2, racc[k].z); atomic_add(p + 3, racc[k].w);
+        }
+      }
+      VNX_STAMP(12);
+      return;
+    }
+  }
 #pragma unroll
   for (int k = 0; k < kRpg; ++k) {
     const int row = grp + k * kGroups;
@@ -646,7 +667,9 @@ msda_bwd_gv_sel_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
 }  // namespace rec
 
 int msda_gvrec_units_bound(const MsdaDims& d, int units_min) {
-  return d.L * (units_min + 1) + (d.S + rec::kRowsMax - 1) / rec::kRowsMax;
+  // row-units of all levels, plus the extra pieces of the query-split levels (at most two row-units each)
+  const int qs = gv_query_splits(1, d.Lq, d.P, true);
+  return d.L * (units_min + 1) + (d.S + rec::kRowsMax - 1) / rec::kRowsMax + d.L * 4 * (qs - 1);
 }
 
 size_t msda_gvrec_record_bytes(const MsdaDims& d) {   // records + (aligned) unit ranges

@@ -115,7 +115,31 @@ struct FusedArgs {
   float* grad_reference;   // [B, Lq, L, 2] fp32, zero-filled, accumulated over heads; or null
   int ref_dim;             // 2 or 4
   int ref_div;             // consecutive batch elements sharing one reference row (frames of a clip)
+  float* qsplit_zero;      // backward, fp32 grad_value: rows of the query-split levels are zeroed here (or null)
 };
+
+// Query split of the grad_value units (msda_d32_gvrec.hip).  A level of at most two row-units (the coarse
+// levels: 240 and 60 pixels at 360p) receives taps from EVERY query, so each of its units sorts one chunk
+// per 128 queries -- forty at the encoder shape (Lq = 5100), against a dozen for a fine-level unit: the
+// kernel's critical path (a level-3 unit ran ~100 us of the 190).  From 1024 queries up such a level is
+// therefore also split by query range into pieces of about ten chunks, each its own workgroup, and the
+// pieces meet in grad_value through fp32 atomics (1.5 M dwords per 360p encoder call) on rows the
+// grad_loc kernel zeroed.  NOT at the decoder shape: there the kernel lasts 15 us, the contended,
+// L2-bypassing atomics cost each piece 12-25 us, and the backward went from 32 to 49 us.
+// fp32 grad_value and 4 points per level only (the selection kernel); 1 = no split.
+#ifndef VNX_QS_COARSE
+#define VNX_QS_COARSE 8
+#endif
+#ifndef VNX_QS_MID
+#define VNX_QS_MID 2
+#endif
+__host__ __device__ inline int gv_query_splits(int row_units, int Lq, int P, bool f32) {
+  if (!f32 || P != 4 || row_units > 4 || Lq < 1024) return 1;
+  const int chunks = (Lq + 127) / 128;
+  const int qs = (chunks + 9) / 10;
+  const int cap = row_units > 2 ? VNX_QS_MID : VNX_QS_COARSE;   // middle levels: 3-4 row-units (960 pixels at 360p)
+  return qs < 1 ? 1 : (qs > cap ? cap : qs);
+}
 
 inline int elem_size(int dtype) {
   switch (dtype) {
