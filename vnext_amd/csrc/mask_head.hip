@@ -29,7 +29,10 @@ constexpr int kMhChannels = 8;    // mask feature channels (hidden_dim / 32)
 constexpr int kMhHidden = 8;      // dynamic_mask_channels
 constexpr int kMhParams = (kMhChannels + 2) * kMhHidden + kMhHidden * kMhHidden + kMhHidden + kMhHidden + kMhHidden + 1;
 constexpr int kMhStripW = 63;     // stored columns per wave (64 lanes - 1 halo lane)
-constexpr int kMhStripH = 5;      // stored rows per wave (+1 halo row, all held in registers)
+#ifndef VNX_MH_ROWS
+#define VNX_MH_ROWS 5
+#endif
+constexpr int kMhStripH = VNX_MH_ROWS;   // stored rows per wave (+1 halo row, all held in registers)
 static_assert(kMhParams == 169, "parameter vector layout");
 
 typedef float float2_t __attribute__((ext_vector_type(2)));
@@ -228,6 +231,10 @@ dynamic_mask_head_kernel(const float* __restrict__ feats, const float* __restric
 #pragma unroll
     for (int p = 0; p < RP; ++p) { logit[2 * p] = a[p].x; logit[2 * p + 1] = a[p].y; }
   }
+  // Stores: a lane owns 2 x 2 outputs, 8 bytes in each of two rows.  (Measured, round 2: without the stores
+  // the kernel takes 10.5 of its 14.6 us at 360p; pairing neighbouring lanes by column parity so that each
+  // writes one dwordx4 instead of two dwordx2 -- 4 shuffles per row -- gave 14.65 us, no gain: the cost is
+  // the 18 MB of write traffic not the store instruction count.)
 #pragma unroll
   for (int r = 1; r < R1; ++r) {
     const int y = y0 + r - 1;
