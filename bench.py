@@ -454,7 +454,56 @@ def head_rooflines(device):
         "achieved": flops / us_dot / 1e6, "peak": 157.3, "unit": "TFLOP/s", "frac": flops / us_dot / 1e6 / 157.3,
         "us_match_scores_bisoftmax_50x50": us_match,
         "what": "46 MFLOP: launch / latency bound by construction; MFMA utilisation is not the point, one launch per image is"}
+    out["tracker_frame_360p_n20"] = tracker_frame_times(device)
     return out
+
+
+def tracker_frame_times(device, n=20, frames=40):
+    """IDOL's per-frame association on a synthetic video of `frames` frames with n
+    detections each at the 360p mask size (90 x 160): wall-clock per frame of the device-resident tracker
+    (vnx_tracker_frame: no host copy; ids read once at the end) against the host-steered IDOL_Tracker of round 1
+    (two device->host copies per frame), same inputs, same ids."""
+    from vnext_amd.models.tracker import DeviceTracker, IDOL_Tracker
+    args = dict(init_score_thr=0.2, obj_score_thr=0.1, nms_thr_pre=0.5, nms_thr_post=0.05, addnew_score_thr=0.2,
+                memo_tracklet_frames=10, memo_momentum=0.8, long_match=True, frame_weight=True, temporal_weight=True,
+                memory_len=3)
+    g = torch.Generator(device=device).manual_seed(11)
+    ident = 3.0 * torch.randn(n, 256, device=device, generator=g)
+    ys = torch.arange(90, device=device)[:, None]
+    xs = torch.arange(160, device=device)[None, :]
+    video = []
+    for t in range(frames):
+        masks = torch.stack([torch.where((xs >= 7 * k + t) & (xs < 7 * k + t + 12) & (ys >= 4 * k) & (ys < 4 * k + 9), 3.0, -3.0)
+                             for k in range(n)])[:, None] + 0.5 * torch.randn(n, 1, 90, 160, device=device, generator=g)
+        score = torch.linspace(0.95, 0.4, n, device=device)
+        video.append((torch.cat([torch.rand(n, 4, device=device, generator=g), score[:, None]], 1),
+                      torch.zeros(n, dtype=torch.long, device=device), masks,
+                      ident + 0.4 * torch.randn(n, 256, device=device, generator=g)))
+    res = {}
+    ids = {}
+    for name, cls in (("device", DeviceTracker), ("host_steered", IDOL_Tracker)):
+        best = None
+        for _ in range(3):
+            tr = cls(**args)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            if name == "device":
+                out = [tr.match_device(b, l, m, e, t) for t, (b, l, m, e) in enumerate(video)]
+                out = torch.stack(out).cpu()
+            else:
+                out = torch.full((frames, n), -3, dtype=torch.long)
+                for t, (b, l, m, e) in enumerate(video):
+                    _, _, got, kept = tr.match(b, l, m, e, t, list(range(n)))
+                    out[t, kept] = got
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / frames * 1e6
+            best = dt if best is None else min(best, dt)
+        res[f"us_per_frame_{name}"] = best
+        ids[name] = out
+    res["same_ids"] = bool(ids["device"].shape == ids["host_steered"].shape and torch.equal(ids["device"], ids["host_steered"]))
+    res["host_copies_per_frame"] = {"device": 0, "host_steered": 2}
+    res["what"] = f"{frames} frames x {n} detections, masks 90 x 160, 256-channel embeddings; wall clock incl. Python"
+    return res
 
 
 def cpu_baseline(B, Lq, res, budget_s=14.0):

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define VNX_ABI_VERSION 6
+#define VNX_ABI_VERSION 7
 
 /* element types */
 enum {
@@ -229,6 +229,63 @@ int vnx_reid_similarity(int dtype, const void* a, const void* b, void* out, int 
  */
 int vnx_reid_bisoftmax(int dtype, const void* sim, void* out, int n, int k, int lds, int ldo,
                        void* hip_stream);
+
+/*
+ * Pairwise intersections of binarised masks:  inter[i, j] = |{p : logit_i[p] > 0 and logit_j[p] > 0}|
+ * (sigmoid > 0.5 is logit > 0), exact int32, symmetric, diagonal = areas.  mask_logits [num_masks,
+ * mask_pixels] fp32 contiguous.  Replaces the pairwise mask_iou launches of
+ * projects/IDOL/idol/models/tracker.py:17-46 (the IoU is (inter + 1e-6) / (area_i + area_j - inter + 1e-6)).
+ * Masks become bit words (one ballot per 64 pixels), intersections are popcounts.
+ */
+size_t vnx_mask_intersections_workspace_bytes(int num_masks, int mask_pixels);
+int vnx_mask_intersections(const float* mask_logits, int num_masks, int mask_pixels, int32_t* inter,
+                           void* workspace, size_t workspace_bytes, void* hip_stream);
+
+/*
+ * IDOL's online tracker with the memory bank on the device: IDOL_Tracker.match + update_memo + memo
+ * (projects/IDOL/idol/models/tracker.py:103-298), one call per frame, no host round trip.
+ * The fields are the constructor arguments of the reference class (tracker.py:52-98) plus the sizes
+ * of the device-resident memory.
+ */
+typedef struct vnx_tracker_config {
+  int capacity;              /* tracklet slots alive at a time, 1..2048 */
+  int channels;              /* embedding width, multiple of 4 */
+  int memory_len;            /* remembered embeddings per tracklet (long_embed / long_score), 1..16 */
+  int memo_tracklet_frames;  /* a tracklet unseen for this many frames is dropped */
+  int match_metric;          /* 0 bisoftmax, 1 softmax, 2 cosine */
+  int long_match;            /* match against the score-weighted mean of the remembered embeddings */
+  int frame_weight;          /* several candidates above 0.5: prefer the longer-lived tracklet */
+  int temporal_weight;       /* long_match weights += 1/L, 2/L, ..., 1 (newest) */
+  float nms_thr_pre;
+  float nms_thr_post;
+  float init_score_thr;
+  float addnew_score_thr;
+  float match_score_thr;
+  float memo_momentum;
+} vnx_tracker_config;
+
+/*
+ * state: a caller-owned device blob of vnx_tracker_state_bytes(cfg) bytes, 16-byte aligned;
+ * vnx_tracker_reset empties it (start of a video).  The library keeps no pointer to it.
+ * Its first three int32 are {tracklets created so far, tracklets that found no free slot (should stay 0:
+ * raise `capacity`), frames processed}.
+ */
+size_t vnx_tracker_state_bytes(const vnx_tracker_config* cfg);
+int vnx_tracker_reset(const vnx_tracker_config* cfg, void* state, void* hip_stream);
+size_t vnx_tracker_frame_workspace_bytes(const vnx_tracker_config* cfg, int num_dets, int mask_pixels);
+/*
+ * One frame.  Detections in descending score order, as the reference's caller passes them:
+ *   mask_logits [num_dets, mask_pixels] fp32, embeds [num_dets, channels] fp32 (16-byte aligned),
+ *   det_scores [num_dets] fp32 (bboxes[:, 4]), labels [num_dets] int64, num_dets <= 512.
+ * ids_out [num_dets] int64, for EVERY input detection: the tracklet id (>= 0), -1 = back-drop,
+ * -2 = unassigned duplicate (the reference's values), -3 = removed by the mask NMS (the reference
+ * drops those rows from its return value: `valids`, tracker.py:212-219).
+ * Enqueues four kernels on hip_stream; no synchronisation, no allocation.  num_dets == 0 is a no-op.
+ */
+int vnx_tracker_frame(const vnx_tracker_config* cfg, void* state, const float* mask_logits,
+                      const float* embeds, const float* det_scores, const int64_t* labels,
+                      int num_dets, int mask_pixels, int frame_id, int64_t* ids_out,
+                      void* workspace, size_t workspace_bytes, void* hip_stream);
 
 /*
  * Kernel selection override for A/B measurements and tests (process-wide):

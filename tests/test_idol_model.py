@@ -90,7 +90,7 @@ def test_inference_output_format(cpu_stand_ins):
         assert len(track) == 3 and all(m is None or (tuple(m.shape) == (70, 100) and m.dtype == torch.bool) for m in track)
 
 
-def _associate_from_golden(g, v, device):
+def _associate_from_golden(g, v, device, tracker_cls=None):
     model = build_model(get_idol_cfg(**{"MODEL.DEVICE": device, **TINY})).eval()
     logits = torch.from_numpy(g[f"v{v}.pred_logits"]).to(device)
     boxes = torch.from_numpy(g[f"v{v}.pred_boxes"]).to(device)
@@ -103,9 +103,10 @@ def _associate_from_golden(g, v, device):
         per_frame.append({"indices": c.tolist(), "logits": logits[f, q], "boxes": boxes[f, q], "embeds": embeds[f, q],
                           "masks": masks[f, q]})
     oh, ow, ih, iw = (int(x) for x in g[f"v{v}.sizes"])
-    tracker = trk.IDOL_Tracker(init_score_thr=0.2, obj_score_thr=0.1, nms_thr_pre=0.5, nms_thr_post=0.05,
-                               addnew_score_thr=0.2, memo_tracklet_frames=10, memo_momentum=0.8, long_match=True,
-                               frame_weight=True, temporal_weight=True, memory_len=3)
+    tracker = (tracker_cls or trk.IDOL_Tracker)(
+        init_score_thr=0.2, obj_score_thr=0.1, nms_thr_pre=0.5, nms_thr_post=0.05, addnew_score_thr=0.2,
+        memo_tracklet_frames=10, memo_momentum=0.8, long_match=True, frame_weight=True, temporal_weight=True,
+        memory_len=3)
     res = model.associate(per_frame, tracker, (oh, ow), (ih, iw))
     np.testing.assert_array_equal(np.array(res["pred_labels"]), g[f"v{v}.labels"])
     np.testing.assert_allclose(np.array(res["pred_scores"]), g[f"v{v}.scores"], rtol=1e-5)
@@ -128,6 +129,13 @@ def test_video_postprocessing_equals_reference_cpu(v, cpu_stand_ins):
 @pytest.mark.parametrize("v", [0, 1])
 def test_video_postprocessing_equals_reference_on_gpu(v):
     _associate_from_golden(dict(np.load(os.path.join(GOLDEN_DIR, "inference_idol.npz"))), v, "cuda:0")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("v", [0, 1])
+def test_video_postprocessing_with_the_tracker_on_the_device(v):
+    """The same fixtures through DeviceTracker: ids stay on the device, one copy per video (models/idol.py:associate)."""
+    _associate_from_golden(dict(np.load(os.path.join(GOLDEN_DIR, "inference_idol.npz"))), v, "cuda:0", trk.DeviceTracker)
 
 
 @pytest.mark.gpu

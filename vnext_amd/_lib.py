@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libvnext_hip.so")
 
 VNX_F32, VNX_F64, VNX_BF16, VNX_F16 = 0, 1, 2, 3
 VNX_OK = 0
-ABI_VERSION = 6
+ABI_VERSION = 7
 MSDA_LEVELS_PACKED = 1
 
 _vp, _i, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
@@ -34,6 +34,12 @@ SIGNATURES = {
     "vnx_dynamic_mask_head_backward": (_i, [_i] + [_vp] * 8 + [_i] * 7 + [_vp]),
     "vnx_reid_similarity": (_i, [_i] + [_vp] * 3 + [_i] * 7 + [_vp]),
     "vnx_reid_bisoftmax": (_i, [_i] + [_vp] * 2 + [_i] * 4 + [_vp]),
+    "vnx_mask_intersections_workspace_bytes": (_sz, [_i, _i]),
+    "vnx_mask_intersections": (_i, [_vp, _i, _i, _vp, _vp, _sz, _vp]),
+    "vnx_tracker_state_bytes": (_sz, [_vp]),
+    "vnx_tracker_reset": (_i, [_vp, _vp, _vp]),
+    "vnx_tracker_frame_workspace_bytes": (_sz, [_vp, _i, _i]),
+    "vnx_tracker_frame": (_i, [_vp] * 6 + [_i] * 3 + [_vp, _vp, _sz, _vp]),
     "vnx_set_kernel_variant": (None, [_i]),
     "vnx_get_kernel_variant": (_i, []),
 }
@@ -47,6 +53,16 @@ DEBUG_SIGNATURES = {
     "vnx_debug_read_tile_stamps": (_i, [ctypes.POINTER(ctypes.c_ulonglong), _i]),
     "vnx_debug_row_gather_probe": (_i, [_vp, _sz, _vp, _sz, _i, _vp, _vp]),
 }
+
+
+
+class TrackerConfig(ctypes.Structure):
+    """`vnx_tracker_config` of include/vnext_hip.h, field by field."""
+    _fields_ = [(k, _i) for k in ("capacity", "channels", "memory_len", "memo_tracklet_frames", "match_metric",
+                                  "long_match", "frame_weight", "temporal_weight")] + \
+               [(k, ctypes.c_float) for k in ("nms_thr_pre", "nms_thr_post", "init_score_thr", "addnew_score_thr",
+                                              "match_score_thr", "memo_momentum")]
+
 
 _lib = None
 
@@ -82,6 +98,12 @@ def check(status: int) -> None:
         l = lib()
         raise VnextHipError(
             f"{l.vnx_status_string(status).decode()}: {l.vnx_last_error().decode()}")
+
+
+def current_stream(tensor) -> int:
+    """hipStream_t of torch's current stream on the tensor's device."""
+    import torch
+    return torch.cuda.current_stream(tensor.device).cuda_stream
 
 
 def set_kernel_variant(v: int) -> None:

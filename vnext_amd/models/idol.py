@@ -35,7 +35,7 @@ from .idol_criterion import IDOLCriterion, OTAMatcher, reid_terms, select_pos_ne
 from .idol_transformer import DeformableTransformer
 from .seqformer import MLP, DeformableDETR, MaskHeadSmallConv, ResNet50Trunk, scale_tensor, sine_position
 from .seqformer_transformer import inverse_sigmoid
-from .tracker import IDOL_Tracker
+from .tracker import DeviceTracker, IDOL_Tracker
 
 
 class CondInstSegmIDOL(nn.Module):
@@ -326,31 +326,52 @@ class IDOL(nn.Module):
         per_frame = []
         for s in range(0, len(video), self.batch_infer_len):
             per_frame.extend(self.inference_forward(video[s:s + self.batch_infer_len]))
-        tracker = IDOL_Tracker(init_score_thr=0.2, obj_score_thr=0.1, nms_thr_pre=self.nms_pre, nms_thr_post=0.05,
-                               addnew_score_thr=self.add_new_score, memo_tracklet_frames=10, memo_momentum=0.8,
-                               long_match=self.inference_tw, frame_weight=(self.inference_tw | self.inference_fw),
-                               temporal_weight=self.inference_tw, memory_len=self.memory_len)
+        make = DeviceTracker if self.device.type == "cuda" else IDOL_Tracker
+        tracker = make(init_score_thr=0.2, obj_score_thr=0.1, nms_thr_pre=self.nms_pre, nms_thr_post=0.05,
+                       addnew_score_thr=self.add_new_score, memo_tracklet_frames=10, memo_momentum=0.8,
+                       long_match=self.inference_tw, frame_weight=(self.inference_tw | self.inference_fw),
+                       temporal_weight=self.inference_tw, memory_len=self.memory_len)
         ih, iw = video[0].shape[-2:]
         oh, ow = batched_inputs[0].get("height", ih), batched_inputs[0].get("width", iw)
         return self.associate(per_frame, tracker, (oh, ow), (ih, iw))
 
     @torch.no_grad()
     def associate(self, per_frame, tracker, ori_size, image_size):
-        """IDOL.inference (idol.py:313-471) on the pre-selected candidates of every frame."""
-        video, n_frames = {}, len(per_frame)
+        """IDOL.inference (idol.py:313-471) on the pre-selected candidates of every frame.
+
+        With a `DeviceTracker` the association of the whole video is enqueued without a host round trip:
+        every frame leaves its ids in device memory, they are read ONCE after the last frame, and the
+        per-track bookkeeping (which only needs the ids) runs on that copy.  With the host-side
+        `IDOL_Tracker` (CPU, differential tests) the ids arrive frame by frame, as in the reference."""
+        n_frames = len(per_frame)
+        on_device = isinstance(tracker, DeviceTracker)
+        probs, frame_ids = [], []
         for t, fr in enumerate(per_frame):
             prob = fr["logits"].sigmoid()
             score, label = prob.max(1)
             det = torch.cat([fr["boxes"], score[:, None]], 1)
-            _, _, ids, kept = tracker.match(bboxes=det, labels=label, masks=fr["masks"], track_feats=fr["embeds"],
-                                            frame_id=t, indices=list(range(len(fr["indices"]))))
-            prob_host = prob.cpu()
-            for row, k in zip(kept, ids.tolist()):
+            probs.append(prob)
+            if on_device:
+                frame_ids.append(tracker.match_device(det, label, fr["masks"], fr["embeds"], t))
+            else:
+                _, _, ids, kept = tracker.match(bboxes=det, labels=label, masks=fr["masks"], track_feats=fr["embeds"],
+                                                frame_id=t, indices=list(range(len(fr["indices"]))))
+                full = torch.full((det.shape[0],), -3, dtype=torch.long)
+                full[torch.tensor(kept, dtype=torch.long)] = ids
+                frame_ids.append(full)
+        if on_device and frame_ids:
+            sizes = [len(x) for x in frame_ids]
+            frame_ids = list(torch.cat(frame_ids).cpu().split(sizes))      # the one copy of the video
+            if tracker.counters()[1]:
+                raise RuntimeError("DeviceTracker: more simultaneous tracklets than slots; raise `capacity`")
+        video = {}
+        for t, (fr, ids) in enumerate(zip(per_frame, frame_ids)):
+            for row, k in enumerate(ids.tolist()):
                 if k < 0:
                     continue
                 v = video.setdefault(k, {"masks": [None] * t, "scores": [None] * t, "valid": 0})
                 v["masks"].append(fr["masks"][row])
-                v["scores"].append(prob_host[row])
+                v["scores"].append(probs[t][row])
                 v["valid"] += 1
             for v in video.values():
                 if len(v["masks"]) < t + 1:

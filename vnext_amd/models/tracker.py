@@ -18,6 +18,12 @@ call and the same decisions as projects/IDOL/idol/models/tracker.py:50-298.  Wha
 
 Box scores, labels, ids, frame counters live on the host (they only steer control flow);
 embeddings and masks never leave the device.
+
+`DeviceTracker` (round 2) goes the rest of the way: the memory bank itself is a device blob and a frame
+is one `vnx_tracker_frame` call -- mask bits + popcount intersections, the similarity against all slots,
+and one workgroup for the greedy passes (vnext_amd/csrc/tracker.hip) -- with NO host copy: `match_device`
+returns the frame's ids as a device tensor, and the model reads all frames' ids once per video.
+`IDOL_Tracker` stays as the host-side statement of the same decisions (CPU tests, differential tests).
 """
 from __future__ import annotations
 
@@ -37,16 +43,33 @@ def _match_scores(embeds, memo_embeds, metric):
     return match_scores(embeds, memo_embeds, metric)
 
 
+def mask_intersections(mask_logits):
+    """[n, pixels] logits -> [n, n] fp32 |mask_i & mask_j| of the binarised masks (exact integers).
+    On the GPU: bit words + popcount (`vnx_mask_intersections`); tests on the CPU patch `_pairwise_dot`."""
+    n = mask_logits.shape[0]
+    if mask_logits.is_cuda:
+        from .. import _lib
+        logits = mask_logits.float().contiguous()
+        inter = torch.empty(n, n, dtype=torch.int32, device=logits.device)
+        ws = torch.empty(_lib.lib().vnx_mask_intersections_workspace_bytes(n, logits.shape[1]), dtype=torch.uint8,
+                         device=logits.device)
+        with torch.cuda.device(logits.device):
+            _lib.check(_lib.lib().vnx_mask_intersections(logits.data_ptr(), n, logits.shape[1], inter.data_ptr(),
+                                                         ws.data_ptr(), ws.numel(), _lib.current_stream(logits)))
+        return inter.float()
+    b = (mask_logits > 0).float()
+    pad = (-b.shape[1]) % 4
+    if pad:
+        b = torch.nn.functional.pad(b, (0, pad))
+    return _pairwise_dot(b, b)
+
+
 def mask_iou_matrix(mask_logits):
     """[n, 1, h, w] or [n, h, w] logits -> [n, n] IoU of the binarised masks (sigmoid > 0.5),
     with the reference's +1e-6 on both terms (tracker.py:17-25)."""
     n = mask_logits.shape[0]
-    b = (mask_logits.reshape(n, -1) > 0).float()
-    pad = (-b.shape[1]) % 4
-    if pad:
-        b = torch.nn.functional.pad(b, (0, pad))
-    inter = _pairwise_dot(b, b)
-    area = b.sum(1)
+    inter = mask_intersections(mask_logits.reshape(n, -1))
+    area = inter.diagonal()
     return (inter + 1e-6) / (area[:, None] + area[None, :] - inter + 1e-6)
 
 
@@ -198,3 +221,93 @@ class IDOL_Tracker(object):
                 ids[i] = -1
         self.update_memo(ids, score, embeds, label, frame_id)
         return bboxes, labels, torch.from_numpy(ids), indices
+
+
+METRICS = {"bisoftmax": 0, "softmax": 1, "cosine": 2}
+
+
+class DeviceTracker(object):
+    """IDOL_Tracker with the tracklets in device memory (vnext_amd/csrc/tracker.hip; reference
+    projects/IDOL/idol/models/tracker.py:50-298).  Same constructor arguments plus `capacity`
+    (tracklet slots alive at a time) and `channels` (embedding width, fixed by the first frame if None).
+
+    match_device(...) -> ids [n] int64 ON THE DEVICE for every input detection: tracklet id, -1 back-drop,
+                         -2 duplicate, -3 removed by the mask NMS.  No host synchronisation.
+    match(...)        -> the reference's (bboxes, labels, ids, indices) of the detections the NMS kept;
+                         costs the one device->host copy of `ids` that signature implies.
+    """
+
+    def __init__(self, nms_thr_pre=0.7, nms_thr_post=0.3, init_score_thr=0.2, addnew_score_thr=0.5,
+                 obj_score_thr=0.1, match_score_thr=0.5, memo_tracklet_frames=10, memo_backdrop_frames=1,
+                 memo_momentum=0.5, nms_conf_thr=0.5, nms_backdrop_iou_thr=0.5, nms_class_iou_thr=0.7,
+                 with_cats=True, match_metric='bisoftmax', long_match=False, frame_weight=False,
+                 temporal_weight=False, memory_len=10, capacity=1024, channels=None):
+        assert 0 <= memo_momentum <= 1.0
+        assert memo_tracklet_frames >= 0
+        assert memo_backdrop_frames >= 0
+        assert match_metric in METRICS
+        self._args = dict(capacity=int(capacity), memory_len=int(memory_len),
+                          memo_tracklet_frames=int(memo_tracklet_frames), match_metric=METRICS[match_metric],
+                          long_match=int(bool(long_match)), frame_weight=int(bool(frame_weight)),
+                          temporal_weight=int(bool(temporal_weight)), nms_thr_pre=nms_thr_pre,
+                          nms_thr_post=nms_thr_post, init_score_thr=init_score_thr,
+                          addnew_score_thr=addnew_score_thr, match_score_thr=match_score_thr,
+                          memo_momentum=memo_momentum)
+        self.channels = channels
+        self.cfg = None
+        self.state = None
+
+    def _start(self, device, channels):
+        import ctypes
+        from .. import _lib
+        self.channels = int(channels)
+        self.cfg = _lib.TrackerConfig(channels=self.channels, **self._args)
+        self._cfg_ptr = ctypes.addressof(self.cfg)
+        size = _lib.lib().vnx_tracker_state_bytes(self._cfg_ptr)
+        if size == 0:
+            raise _lib.VnextHipError(_lib.lib().vnx_last_error().decode())
+        self.state = torch.empty(size, dtype=torch.uint8, device=device)
+        with torch.cuda.device(device):
+            _lib.check(_lib.lib().vnx_tracker_reset(self._cfg_ptr, self.state.data_ptr(), _lib.current_stream(self.state)))
+
+    def counters(self):
+        """(tracklets created, tracklets that found no free slot, frames processed) -- one host copy."""
+        if self.state is None:
+            return 0, 0, 0
+        return tuple(self.state[:12].view(torch.int32).tolist())
+
+    @property
+    def num_tracklets(self):
+        return self.counters()[0]
+
+    def match_device(self, bboxes, labels, masks, track_feats, frame_id):
+        from .. import _lib
+        n = bboxes.shape[0]
+        if not bboxes.is_cuda:
+            raise RuntimeError("DeviceTracker: no CPU implementation (HIP library only); IDOL_Tracker is the host form")
+        if self.state is None:
+            self._start(bboxes.device, track_feats.shape[1])
+        ids = torch.empty(n, dtype=torch.int64, device=bboxes.device)
+        if n == 0:
+            return ids
+        logits = masks.reshape(n, -1).float().contiguous()
+        embeds = track_feats.float().contiguous()
+        scores = bboxes[:, 4].float().contiguous()
+        labels = labels.to(torch.int64).contiguous()
+        lib = _lib.lib()
+        ws = torch.empty(lib.vnx_tracker_frame_workspace_bytes(self._cfg_ptr, n, logits.shape[1]), dtype=torch.uint8,
+                         device=bboxes.device)
+        with torch.cuda.device(bboxes.device):
+            _lib.check(lib.vnx_tracker_frame(self._cfg_ptr, self.state.data_ptr(), logits.data_ptr(), embeds.data_ptr(),
+                                             scores.data_ptr(), labels.data_ptr(), n, logits.shape[1], int(frame_id),
+                                             ids.data_ptr(), ws.data_ptr(), ws.numel(), _lib.current_stream(ids)))
+        return ids
+
+    def match(self, bboxes, labels, masks, track_feats, frame_id, indices):
+        n = bboxes.shape[0]
+        if n == 0:
+            return bboxes, labels, torch.zeros(0, dtype=torch.long), []
+        ids = self.match_device(bboxes, labels, masks, track_feats, frame_id).cpu()
+        kept = torch.nonzero(ids > -3).squeeze(1)
+        kept_dev = kept.to(bboxes.device)
+        return bboxes[kept_dev], labels[kept_dev], ids[kept], [indices[i] for i in kept.tolist()]
