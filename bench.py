@@ -144,7 +144,20 @@ def event_time_us(graph, launches, reps=15):
     return ts[len(ts) // 2]
 
 
-def model_step_leg(rank, local_rank, world, device, steps, warmup=3, clips_per_rank=2, bf16=False):
+def count_launches(step):
+    """Device-side events (kernels, memsets, copies) of ONE more step, outside the timed region (torch.profiler;
+    round 1: 5 696 by rocprofv3, profiles/r01_model_step_by_category.csv)."""
+    try:
+        from torch.profiler import ProfilerActivity, profile
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            step()
+            torch.cuda.synchronize()
+        return sum(1 for ev in prof.events() if ev.device_type == torch.autograd.DeviceType.CUDA)
+    except Exception as e:      # a profiler problem must not cost the bench line
+        return f"unavailable: {type(e).__name__}"
+
+
+def model_step_leg(rank, local_rank, world, device, steps, warmup=3, clips_per_rank=2, bf16=False, count=False):
     """clips/s of the SeqFormer-R50 training step (BASELINE config: T=5 synthetic 360p clip, 300
     queries): forward + backward + RCCL gradient all-reduce + clipped AdamW step, two clips per
     rank -- the reference's per-GPU batch (IMS_PER_BATCH 16 on 8 GPUs, configs/base_ytvis.yaml:18) --
@@ -185,9 +198,19 @@ def model_step_leg(rank, local_rank, world, device, steps, warmup=3, clips_per_r
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     n_params = sum(p.numel() for p in model.parameters() if p.requires_grad)
+    launches = None
+    if count:       # one more step on every rank (the gradient all-reduce needs them all); rank 0 counts its launches
+        if rank == 0:
+            launches = count_launches(step)
+        else:
+            step()
+            torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
     del ddp, opt, model
     torch.cuda.empty_cache()
     return {"clips_per_s": world * clips_per_rank * steps / dt, "ms_per_step": dt * 1e3 / steps, "steps": steps,
+            "launches_per_step": launches,
             "clips_per_rank": clips_per_rank, "n_gpus": world, "trainable_params": n_params,
             "grad_allreduce_MB_per_step": round(n_params * 4 / 1e6, 1),
             "config": "SeqFormer R50 (random init), T=5, 360x640 -> 384x640, 300 queries, 6+6 layers, fp32; "
@@ -736,7 +759,7 @@ def main():
     # ---- model-level leg: SeqFormer-R50 T=5 360p training step under DDP (all ranks) ----------
     model_leg = None
     if not a.no_model:
-        model_leg = model_step_leg(rank, local_rank, world, device, a.model_steps)
+        model_leg = model_step_leg(rank, local_rank, world, device, a.model_steps, count=True)
         if model_leg is not None and world == 1:
             one = model_step_leg(rank, local_rank, world, device, a.model_steps, clips_per_rank=1)
             model_leg["one_clip_per_rank"] = {k: one[k] for k in ("clips_per_s", "ms_per_step")}

@@ -284,3 +284,41 @@ def test_ddp_wrapper_over_rccl_on_one_gpu(arch):
         assert all(np.isfinite(losses))
     finally:
         dist.destroy_process_group()
+
+
+def test_folding_all_backbone_scales_at_once_changes_nothing():
+    """`fold_all` (one multi-tensor multiply for all filters, one in the backward) against the per-convolution
+    expression `conv.weight * scale` it replaces: same features, same filter gradients, frozen stages untouched."""
+    from vnext_amd.models import seqformer as SF
+    torch.manual_seed(0)
+    net = SF.ResNet50Trunk().freeze(2)
+    for m in net.modules():
+        if isinstance(m, SF.FrozenBatchNorm2d):
+            m.weight.copy_(torch.rand_like(m.weight) + 0.5)
+            m.bias.copy_(torch.randn_like(m.bias) * 0.1)
+            m.running_mean.copy_(torch.randn_like(m.running_mean) * 0.1)
+            m.running_var.copy_(torch.rand_like(m.running_var) + 0.5)
+    x = torch.randn(1, 3, 64, 96)
+    outs = net(x)
+    sum((o * o).sum() for o in outs).backward()
+    got = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+    assert not any(n.startswith(("stem", "res2")) for n in got) and len(got) == 42
+    for p in net.parameters():
+        p.grad = None
+
+    def plain(x):
+        y = F.max_pool2d(F.relu(SF.conv_bn(x, net.stem[0], net.stem[1])), 3, 2, 1)
+        feats = []
+        for stage in (net.res2, net.res3, net.res4, net.res5):
+            for b in stage:
+                y = b(y)
+            feats.append(y)
+        return feats[1:]
+    import torch.nn.functional as F
+    want = plain(x)
+    sum((o * o).sum() for o in want).backward()
+    for a, b in zip(outs, want):
+        assert torch.equal(a, b)
+    for n, p in net.named_parameters():
+        if p.grad is not None:
+            assert torch.equal(got[n], p.grad), n
