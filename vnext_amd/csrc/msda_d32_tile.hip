@@ -469,7 +469,7 @@ msda_fwd_tile_kernel(const float* __restrict__ value, const int64_t* __restrict_
           const int i = (g * kWaves + wave) * 4 + pair;
           if (side == 0 && i < nqp) {
             const int q = qtab[i];
-            *reinterpret_cast<float4_t*>(out_head + (uint32_t(q) * uint32_t(d.M)) * 32u + ch * 4) = o;
+            __builtin_nontemporal_store(o, reinterpret_cast<float4_t*>(out_head + (uint32_t(q) * uint32_t(d.M)) * 32u + ch * 4));
           }
         }
       }
