@@ -1,6 +1,7 @@
 cd $GRAFT_REPO_ROOT
 K=$GRAFT_REPO_ROOT/tools/kbench.bin
-$K --shape dec360 --dist U --op both --variants 0 --inner 24 --reps 9 --check
-$K --shape dec360 --dist M --op both --variants 0 --inner 24 --reps 9 --check
-$K --shape dec360 --dist U --B 10 --op both --variants 0 --inner 12 --reps 9
-$K --shape dec720 --dist U --op both --variants 0 --inner 8 --reps 7 --check
+for lib in lib lib/exa4; do
+echo "== $lib"
+LD_LIBRARY_PATH=$GRAFT_REPO_ROOT/vnext_amd/$lib $K --shape dec360 --dist U --op bwd --variants 0 --inner 24 --reps 9 --check
+LD_LIBRARY_PATH=$GRAFT_REPO_ROOT/vnext_amd/$lib $K --shape enc360 --dist M --op bwd --variants 0 --inner 8 --reps 7 --check
+done
