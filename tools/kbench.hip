@@ -199,7 +199,7 @@ struct Set {
 int main(int argc, char** argv) {
   std::string shape = "dec360", dist = "U", op = "fwd", variants = "0";
   int B = 5, lq = 0, inner = 24, reps = 15, voff = 0;   // voff: floats added to every `value` base (alignment experiments)
-  bool check = false, dma = false, stamps = false, timeline = false, hbm = false;
+  bool check = false, cold_only = false, dma = false, stamps = false, timeline = false, hbm = false;
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
     auto next = [&]() { return std::string(i + 1 < argc ? argv[++i] : ""); };
@@ -213,6 +213,7 @@ int main(int argc, char** argv) {
     else if (a == "--reps") reps = atoi(next().c_str());
     else if (a == "--voff") voff = atoi(next().c_str());
     else if (a == "--check") check = true;
+    else if (a == "--cold-only") cold_only = true;      // for rocprofv3 runs: every traced launch reads cold inputs
     else if (a == "--dma-test") dma = true;
     else if (a == "--stamps") stamps = true;
     else if (a == "--timeline") timeline = true;
@@ -337,7 +338,7 @@ int main(int argc, char** argv) {
                    diff(sets[0].ga, r_ga, n_s));
         }
       }
-      const float cold = time_graph(is_bwd, true), warm = time_graph(is_bwd, false);
+      const float cold = time_graph(is_bwd, true), warm = cold_only ? cold : time_graph(is_bwd, false);
       const double by = is_bwd ? bytes_bwd : bytes_fwd;
       printf("  variant %4d %s: cold %8.2f us %6.2f TB/s %7.2f Gpt/s | warm %8.2f us %6.2f TB/s%s\n", v, is_bwd ? "bwd" : "fwd", cold,
              by / cold / 1e6, n_s / cold / 1e3, warm, by / warm / 1e6, chk);
