@@ -9,7 +9,7 @@ cd $GRAFT_REPO_ROOT
 python bench.py > $OUT/bench_line.json 2> $OUT/bench.err
 tail -c 400 $OUT/bench_line.json
 cd /tmp && export TMPDIR=/tmp
-B="python $GRAFT_REPO_ROOT/bench.py --no-cpu --no-model --no-warm --no-cases --steps 50 --warmup 5"
+B="python $GRAFT_REPO_ROOT/bench.py --no-cpu --no-model --no-warm --no-cases --no-spans --steps 50 --warmup 5"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o trace -- $B > $OUT/bench_under_trace.json 2> $OUT/trace.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT -o pmc_fetch -- $B > /dev/null 2> $OUT/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT -o pmc_write -- $B > /dev/null 2> $OUT/pmc_write.err
