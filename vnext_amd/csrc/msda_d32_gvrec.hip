@@ -69,6 +69,12 @@ template <> __device__ __forceinline__ void store4<f16_t>(f16_t* p, float4_t v) 
   *reinterpret_cast<uint2_t*>(p) = r;
 }
 
+// The value again, but opaque to the optimiser: what is derived from the result is recomputed where it is used instead of
+// being hoisted out of the loops and then SPILLED (the selection kernel kept `tid | 0x200`, `tid >> 2`, `tid * 4`, ... live
+// across its loops and spilled ten of them: 10 dwords x 64 lanes x 6 080 waves = 15.5 MB of scratch written back to
+// memory per launch -- the whole excess of WRITE_SIZE over the 26.1 MB of grad_value rows, profiles/r02).
+__device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
   int x = int(v);
   x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);  // row_shr:1
@@ -466,6 +472,11 @@ msda_bwd_gv_sel_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
     packed = packed && (running == d.S);
     if (!packed || lvl < 0) return;  // uniform over the workgroup
   }
+  // the unit's geometry is uniform over the workgroup but came through LDS: say so, and it lives in SGPRs
+  lvl = __builtin_amdgcn_readfirstlane(lvl); r0 = __builtin_amdgcn_readfirstlane(r0); r1 = __builtin_amdgcn_readfirstlane(r1);
+  Hl = __builtin_amdgcn_readfirstlane(Hl); Wl = __builtin_amdgcn_readfirstlane(Wl); start = __builtin_amdgcn_readfirstlane(start);
+  u_lvl = __builtin_amdgcn_readfirstlane(u_lvl); qsplit = __builtin_amdgcn_readfirstlane(qsplit);
+  qpiece = __builtin_amdgcn_readfirstlane(qpiece);
   const int rows = r1 - r0;
   constexpr int kRpg = (kRowsMax + kGroups - 1) / kGroups;
   float4_t racc[kRpg];
@@ -490,12 +501,13 @@ msda_bwd_gv_sel_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
   const int s_lo = qpiece * q_per * P, s_hi = (qpiece + 1) * q_per * P < n_samples ? (qpiece + 1) * q_per * P : n_samples;
   for (int win0 = s_lo; win0 < s_hi; win0 += kWin) {
     const int n_w = s_hi - win0 < kWin ? s_hi - win0 : kWin;
+    const int tw = opaque(tid);
     // ---- selection: which samples of this window touch my rows -----------------------------
     unsigned long long bal[kSelRounds], balf[kSelRounds];
     uint32_t hitbits = 0;
 #pragma unroll
     for (int r = 0; r < kSelRounds; ++r) {
-      const int sidx = r * kThreads + tid;
+      const int sidx = r * kThreads + tw;
       const uint32_t v = sidx < n_w ? my_uids[win0 + sidx] : 0xffffffffu;
       const bool hit = int(v & 0xffffu) <= u_lvl && u_lvl <= int(v >> 16) && v != 0xffffffffu;
       const unsigned long long bh = __ballot(hit);
@@ -528,10 +540,10 @@ msda_bwd_gv_sel_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
         // firsts at lanes <= mine: those strictly below, plus my own flag
         const uint32_t qr = pre_q[r * kWaves + wave] + __builtin_amdgcn_mbcnt_hi(uint32_t(balf[r] >> 32), qlo) +
                             (first ? 1u : 0u) - 1u;
-        sel_id[pos] = uint16_t(r * kThreads + tid);
+        sel_id[pos] = uint16_t(r * kThreads + tw);
         sel_qr[pos] = uint16_t(qr);
         if (first) {
-          selq[qr] = uint16_t((r * kThreads + tid) >> 2);
+          selq[qr] = uint16_t((r * kThreads + tw) >> 2);
           if ((qr & uint32_t(kQcMax - 1)) == 0u) cs[qr / kQcMax] = pos;
         }
       }
