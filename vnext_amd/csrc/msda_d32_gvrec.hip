@@ -392,7 +392,10 @@ constexpr size_t kSelLdsBytes = size_t(kQcMax) * 128 + size_t(kThreads) * 32 + s
                                 size_t(kSelParts) * 16 + 64;
 
 template <typename TV>
-__global__ void __launch_bounds__(kThreads, 3 * kWaves / 4)
+#ifndef VNX_SEL_UNITS_PER_CU
+#define VNX_SEL_UNITS_PER_CU 3
+#endif
+__global__ void __launch_bounds__(kThreads, VNX_SEL_UNITS_PER_CU * kWaves / 4)
 msda_bwd_gv_sel_kernel(const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
                        const uint4_t* __restrict__ records, const uint32_t* __restrict__ unit_ids,
                        const TV* __restrict__ grad_out, TV* __restrict__ grad_value, MsdaDims d, int units_min,
@@ -490,10 +493,11 @@ msda_bwd_gv_sel_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
   const TV* go_head = grad_out + (int64_t(b) * d.Lq * d.M + m) * D;
   const int64_t q_stride = int64_t(d.M) * D;
   const uint4_t none = {0xffffffffu, 0u, 0u, 0u};
-  const int g0 = tid, g1 = tid + kThreads;          // the two 16-B pieces of staged rows this thread moves
-  const int grp = tid >> 3, ch4 = tid & 7;
+  // (g0 = tid, g1 = tid + kThreads: the two 16-B pieces of staged rows a thread moves; grp = tid >> 3, ch4 = tid & 7: the
+  //  8-lane group and its 16-B channel piece -- all derived where used from an opaque copy of tid, see opaque())
+
   const int dr[4] = {0, 1, Wl, Wl + 1};
-  const uint32_t below = uint32_t(lane & 3);
+
   int gchunk = 0;                                    // parity of the double-buffered row counters
 
   // the queries this workgroup takes: all of them, or one piece of a query-split level
@@ -511,8 +515,8 @@ msda_bwd_gv_sel_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
       const uint32_t v = sidx < n_w ? my_uids[win0 + sidx] : 0xffffffffu;
       const bool hit = int(v & 0xffffu) <= u_lvl && u_lvl <= int(v >> 16) && v != 0xffffffffu;
       const unsigned long long bh = __ballot(hit);
-      const uint32_t quad = uint32_t(bh >> (lane & ~3)) & 0xfu;       // my query's four samples
-      const bool first = hit && (quad & ((1u << below) - 1u)) == 0u;
+      const uint32_t quad = uint32_t(bh >> (tw & 60)) & 0xfu;          // my query's four samples
+      const bool first = hit && (quad & ((1u << (tw & 3)) - 1u)) == 0u;
       const unsigned long long bf = __ballot(first);
       bal[r] = bh; balf[r] = bf;
       hitbits |= uint32_t(hit) << r | uint32_t(first) << (8 + r);
@@ -566,6 +570,7 @@ msda_bwd_gv_sel_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
       } else {
         next = none;
       }
+      const int g0 = opaque(tid), g1 = g0 + kThreads;
       const int qa = c * kQcMax + (g0 >> 3), qb = c * kQcMax + (g1 >> 3);
       if (qa < n_q) pg0 = load4<TV>(go_head + int64_t(q_win + int(selq[qa])) * q_stride + (g0 & 7) * 4);
       if (qb < n_q) pg1 = load4<TV>(go_head + int64_t(q_win + int(selq[qb])) * q_stride + (g1 & 7) * 4);
@@ -576,8 +581,10 @@ msda_bwd_gv_sel_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
       uint32_t* cnt_next = cnt2 + ((gchunk + 1) & 1) * kRowsMax;
       const uint4_t r = next;
       const uint32_t slot = uint32_t(next_slot);
-      grows[g0] = pg0;
-      grows[g1] = pg1;
+      const int tc = opaque(tid);
+      const int grp = tc >> 3, ch4 = tc & 7;
+      grows[tc] = pg0;
+      grows[tc + kThreads] = pg1;
       if (win0 == 0 && c == 0) VNX_SEL_STAMP(5);
       if (c + 1 < n_chunks) prefetch(c + 1);
       uint32_t mask = 0;
@@ -635,9 +642,9 @@ msda_bwd_gv_sel_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
         const uint2_t* seg = list + ro[k];
         float4_t a1 = {0.f, 0.f, 0.f, 0.f};
         uint32_t i = 0;
-        // (Round 2: four entries per step instead of two -- half the dependent LDS round trips of a dense row --
-        // needs 8 more live registers than the 80 this kernel has at 3 units per CU: 39 spilled instead of 10,
-        // decoder backward 31.3 -> 38.7 us, encoder 240 -> 278 us.  Two it stays.)
+        // (Four entries per step instead of two -- half the dependent LDS round trips of a dense row: measured twice in
+        // round 2, first with the 39 spills it caused (38.7 vs 31.3 us), then spill-free after the kernel had been
+        // slimmed to 72 VGPRs: 30.0 vs 29.5 us at the decoder shape, 230 vs 229 at the encoder -- no gain either way.)
         for (; i + 2 <= n; i += 2) {
           const uint2_t e0 = seg[i], e1 = seg[i + 1];
           const float4_t x0 = g4[e0.x * 8], x1 = g4[e1.x * 8];
@@ -658,6 +665,8 @@ msda_bwd_gv_sel_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
   VNX_SEL_STAMP(11);
 
   TV* out = grad_value + ((int64_t(b) * d.S + start + r0) * d.M + m) * D;
+  const int te = opaque(tid);
+  const int grp = te >> 3, ch4 = te & 7;
   if constexpr (sizeof(TV) == 4) {
     if (qsplit > 1) {   // pieces of a query-split level meet through fp32 atomics (rows zeroed by the grad_loc kernel);
                         // a group's 8 lanes x 4 dwords = one row's 32 consecutive dwords per instruction group
