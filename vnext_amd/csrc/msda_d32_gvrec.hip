@@ -200,6 +200,9 @@ msda_bwd_gv_rec_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
     packed = packed && (running == d.S);
     if (!packed || lvl < 0) return;  // uniform over the workgroup
   }
+  // uniform over the workgroup, but it came through LDS: scalarise (SGPRs instead of VGPRs, see opaque())
+  lvl = __builtin_amdgcn_readfirstlane(lvl); r0 = __builtin_amdgcn_readfirstlane(r0); r1 = __builtin_amdgcn_readfirstlane(r1);
+  Hl = __builtin_amdgcn_readfirstlane(Hl); Wl = __builtin_amdgcn_readfirstlane(Wl); start = __builtin_amdgcn_readfirstlane(start);
   const int rows = r1 - r0;
   if (!RS)
     for (int i = tid; i < rows * 8; i += kThreads) slab[i] = float4_t{0.f, 0.f, 0.f, 0.f};
