@@ -128,13 +128,24 @@ def capture(fns):
     return graph
 
 
+def prewarm(graph, seconds=0.06):
+    """Replay until `seconds` of wall time have passed: the first tens of milliseconds of GPU work after an idle
+    period run up to 10 % slow on this part (clock ramp; measured with tools/kbench.hip: 66.8 -> 59.9 us for the same
+    encoder-shape launch over the first five measurements).  Untimed, outside every timed region."""
+    t0 = time.perf_counter()
+    while True:
+        graph.replay()
+        torch.cuda.synchronize()
+        if time.perf_counter() - t0 >= seconds:
+            return
+
+
 def event_time_us(graph, launches, reps=15):
     """Median microseconds per launch, HIP events on the launch stream: (time of three back-to-back replays -
     time of one) / (2 x launches), i.e. the steady-state duration of a launch incl. the gap to the next one,
     without the one-off latency of starting a graph on an idle GPU (~10 us, which one replay of 24 launches
     would spread over them as +0.4 us each)."""
-    graph.replay()
-    torch.cuda.synchronize()
+    prewarm(graph)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
     def timed(k):
@@ -763,6 +774,7 @@ def main():
     chunk = largest_divisor_leq(a.steps, 100)
     fns = [f for i in range(chunk) for f in step_fns(i)]
     graph = capture(fns)
+    prewarm(graph, 0.15)     # clocks up before the W warm-up steps (untimed either way)
     for _ in range(math.ceil(a.warmup / chunk)):
         graph.replay()
     elapsed = timed_region(graph.replay, a.steps // chunk, world, device)

@@ -1,8 +1,7 @@
 cd $GRAFT_REPO_ROOT
 K=$GRAFT_REPO_ROOT/tools/kbench.bin
-for lib in lib lib/exa4 lib lib/exa4; do
+for lib in lib lib/exk1; do
 echo "== $lib"
-LD_LIBRARY_PATH=$GRAFT_REPO_ROOT/vnext_amd/$lib $K --shape dec360 --dist U --op bwd --variants 0 --inner 24 --reps 9 --check
-LD_LIBRARY_PATH=$GRAFT_REPO_ROOT/vnext_amd/$lib $K --shape enc360 --dist M --op bwd --variants 0 --inner 8 --reps 7 --check
-LD_LIBRARY_PATH=$GRAFT_REPO_ROOT/vnext_amd/$lib $K --shape dec720 --dist U --op bwd --variants 0 --inner 8 --reps 7
+LD_LIBRARY_PATH=$GRAFT_REPO_ROOT/vnext_amd/$lib $K --shape enc360 --dist M --op bwd --variants 0,100 --inner 8 --reps 7
+LD_LIBRARY_PATH=$GRAFT_REPO_ROOT/vnext_amd/$lib $K --shape enc720 --dist M --B 2 --op bwd --variants 0,100 --inner 4 --reps 5
 done

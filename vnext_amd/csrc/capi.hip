@@ -208,11 +208,14 @@ int vnx_get_kernel_variant(void) { return g_kernel_variant; }
 // 257-274 vs 266-289 us (it wins, 3-5 %), 360p 70 vs 62 us (it loses: it is bound by VALU issue -- 7 vector
 // instructions per FMA pair once decode, records, staging and bounding boxes are counted -- where the
 // gather kernel is bound by the L1/TA rate), uniform random locations 95 vs 77 us.  So automatic selection
-// takes it from 12 288 pixels up only.  Variants 700..702 force it (701 / 702: phase stamps), 710 keeps it off.
+// took it from 12 288 pixels up (until the change recorded in use_tile_forward).  Variants 700..702 force it (701 / 702:
+// phase stamps), 710 keeps it off.
 static bool use_tile_forward(int vdt, int ldt, const MsdaDims& d, int variant) {
   if (!msda_tile_fwd_supported(vdt, ldt, d)) return false;
-  if (variant >= 700 && variant <= 702) return true;
-  return variant == 0 && d.Lq == d.S && d.S >= 12288;
+  // Round 2, late: with two samples in flight instead of four on large calls the gather kernel runs at 8 instead of 5
+  // waves per SIMD and takes 54.9 us at 360p (tiled: 65.5), 88 vs 103 us at 720p B = 2, 252 vs 249 us at 720p B = 5 --
+  // the tiled kernel no longer wins anywhere, so it is never selected automatically.
+  return variant >= 700 && variant <= 702;
 }
 
 int vnx_msda_forward(int value_dtype, int loc_dtype, const void* value,

@@ -187,6 +187,9 @@ __device__ __forceinline__ void fused_decode(const TL* __restrict__ raw_off, con
 #ifndef VNX_K1_BATCH
 #define VNX_K1_BATCH 4
 #endif
+#ifndef VNX_K1_BATCH_LARGE
+#define VNX_K1_BATCH_LARGE 2
+#endif
 #ifndef VNX_FWD_WPE
 #define VNX_FWD_WPE 0
 #endif
@@ -375,7 +378,10 @@ msda_fwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
     // The gathers are latency-bound (two dependent HBM round trips per wave: locations, then
     // taps), so put a whole batch of 4 samples = 16 row loads in flight before the first use.
     constexpr int kPer = LP_T / PG;
-    constexpr int kBatch = kPer < VNX_FWD_BATCH ? kPer : VNX_FWD_BATCH;
+    // 4 samples on the small calls (one wave per workgroup, 3 waves per SIMD: latency is everything); 2 on the large
+    // ones, where 55 instead of 95 VGPRs = 8 instead of 5 waves per SIMD matter more (encoder 360p: 59.9 -> 54.8 us)
+    constexpr int kWant = WPB == 1 ? VNX_FWD_BATCH : 2;
+    constexpr int kBatch = kPer < kWant ? kPer : kWant;
 #pragma unroll
     for (int i0 = 0; i0 < kPer; i0 += kBatch) {
       uint4_t o[kBatch];
@@ -776,7 +782,7 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
     // 2 for the large ones (4 waves per workgroup, rows > 4096), which are bound by how many waves fit:
     // encoder shape 106 vs 112 us.
     constexpr int kPer = LP_T / PG;
-    constexpr int kWant = WPB == 1 ? VNX_K1_BATCH : 2;
+    constexpr int kWant = WPB == 1 ? VNX_K1_BATCH : VNX_K1_BATCH_LARGE;
     constexpr int kBatch = kPer < kWant ? kPer : kWant;
 #pragma unroll
     for (int i0 = 0; i0 < kPer; i0 += kBatch) {
