@@ -386,6 +386,13 @@ msda_bwd_gv_rec_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
 // ascending order is kept, so every sum stays deterministic), numbers the distinct queries among
 // them, and only then runs the sort / apply chunks -- over the kept samples, 128 distinct queries
 // (<= 512 samples) per chunk, staging only those queries' grad_out rows.
+// Tried (round 2, late): 176 instead of 128 distinct queries per chunk (22 KiB of staged rows: what three units per CU
+// leave of the LDS; 184 no longer fits: 33.6 us), a chunk whose queries keep more than 512 samples being sorted and
+// applied in several rounds over the same staged rows -- the coarse half-level units of the decoder shape keep ~280
+// distinct queries, i.e. two chunks instead of three on what the phase stamps call the critical path.  Same box, A/B:
+// decoder backward 27.6 vs 27.9-28.2 us, but the encoder shape LOSES even with the kernel templated back to 128 for
+// large calls (225.5 vs 217.9 us at 360p, 492 vs 452 us at 720p B = 2: the step loop no longer unrolls into the old
+// schedule).  Not kept.
 constexpr int kWin = 2048;                        // samples per selection window
 constexpr int kWinQueries = kWin / 4;
 constexpr int kSelRounds = kWin / kThreads;       // 4
