@@ -1,8 +1,4 @@
 cd $GRAFT_REPO_ROOT
 K=$GRAFT_REPO_ROOT/tools/kbench.bin
-for lib in lib lib/exold lib lib/exold; do
-echo "== $lib"
-LD_LIBRARY_PATH=$GRAFT_REPO_ROOT/vnext_amd/$lib $K --shape dec360 --dist U --op bwd --variants 0 --inner 24 --reps 9
-LD_LIBRARY_PATH=$GRAFT_REPO_ROOT/vnext_amd/$lib $K --shape enc360 --dist M --op bwd --variants 0 --inner 8 --reps 7
-LD_LIBRARY_PATH=$GRAFT_REPO_ROOT/vnext_amd/$lib $K --shape enc720 --dist M --B 2 --op bwd --variants 0 --inner 4 --reps 5
-done
+$K --shape dec360 --dist U --op bwd --variants 0 --inner 24 --reps 3 --timeline
+$K --shape dec360 --dist U --op fwd --variants 0 --inner 24 --reps 3 --timeline
