@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define VNX_ABI_VERSION 7
+#define VNX_ABI_VERSION 8
 
 /* element types */
 enum {
@@ -286,6 +286,27 @@ int vnx_tracker_frame(const vnx_tracker_config* cfg, void* state, const float* m
                       const float* embeds, const float* det_scores, const int64_t* labels,
                       int num_dets, int mask_pixels, int frame_id, int64_t* ids_out,
                       void* workspace, size_t workspace_bytes, void* hip_stream);
+
+/*
+ * y = LayerNorm(x + dropout(r)) over rows of 256 channels, in one pass: the chain that closes every sub-layer of the
+ * deformable transformer (projects/SeqFormer/seqformer/models/deformable_transformer.py:201-236,286-385:
+ * `src = src + self.dropout1(src2); src = self.norm1(src)`), three ATen launches forward and four backward per site.
+ *   x, r, y, z [rows, 256] fp32 contiguous; gamma, beta [256]; stats [rows, 2] = {mean, rstd} per row.
+ *   z = x + dropout(r) is an OUTPUT the backward needs (r is dead afterwards).  p = drop probability (0 in eval mode),
+ *   kept elements are scaled by 1 / (1 - p).  The mask is not stored: element e is kept iff hash(seed, e) >= p * 2^32,
+ *   and the backward recomputes it from the same `seed` -- pass the same value to both calls, a fresh one per
+ *   forward call.
+ * Backward: grad_x = d loss / d x, grad_r = d loss / d r (both [rows, 256]), grad_gamma, grad_beta [256] (overwritten, not
+ * accumulated; summed in a fixed order).  partial: scratch of vnx_add_dropout_layernorm_partial_bytes() bytes.
+ */
+size_t vnx_add_dropout_layernorm_partial_bytes(void);
+int vnx_add_dropout_layernorm_forward(int dtype, const void* x, const void* r, const void* gamma, const void* beta,
+                                      void* y, void* z, void* stats, long long rows, int channels, float p, float eps,
+                                      unsigned long long seed, void* hip_stream);
+int vnx_add_dropout_layernorm_backward(int dtype, const void* grad_y, const void* z, const void* stats,
+                                       const void* gamma, void* grad_x, void* grad_r, void* grad_gamma, void* grad_beta,
+                                       void* partial, long long rows, int channels, float p, unsigned long long seed,
+                                       void* hip_stream);
 
 /*
  * Kernel selection override for A/B measurements and tests (process-wide):

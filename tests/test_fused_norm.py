@@ -1,0 +1,93 @@
+"""add_dropout_norm (vnext_amd/ops/fused_norm.py, vnext_amd/csrc/add_norm.hip) against the expression it replaces,
+`norm(x + dropout(x2))` of the reference's transformer layers (deformable_transformer.py:201-236,286-385)."""
+import pytest
+import torch
+
+from vnext_amd.ops.fused_norm import add_dropout_norm, fused_applies
+
+DEV = "cuda:0"
+
+
+def _modules(p, seed=0, train=True):
+    torch.manual_seed(seed)
+    norm = torch.nn.LayerNorm(256)
+    with torch.no_grad():
+        norm.weight.copy_(1 + 0.3 * torch.randn(256))
+        norm.bias.copy_(0.2 * torch.randn(256))
+    drop = torch.nn.Dropout(p)
+    drop.train(train)
+    return drop, norm
+
+
+def test_cpu_and_other_widths_take_the_reference_expression():
+    drop, norm = _modules(0.0)
+    x, r = torch.randn(3, 7, 256), torch.randn(3, 7, 256)
+    assert not fused_applies(x, r, norm)
+    assert torch.equal(add_dropout_norm(x, r, drop, norm), norm(x + drop(r)))
+    n2 = torch.nn.LayerNorm(64)
+    assert not fused_applies(torch.randn(2, 64), torch.randn(2, 64), n2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1, 256), (5, 300, 256), (2, 5, 5100, 256), (4097, 256)])
+def test_without_dropout_it_is_the_layer_norm_of_the_sum(shape):
+    drop, norm = _modules(0.1, train=False)            # eval mode: p = 0
+    norm = norm.to(DEV)
+    g = torch.Generator().manual_seed(1)
+    x = (3 * torch.randn(shape, generator=g) + 1).to(DEV).requires_grad_(True)
+    r = torch.randn(shape, generator=g).to(DEV).requires_grad_(True)
+    assert fused_applies(x, r, norm)
+    y = add_dropout_norm(x, r, drop, norm)
+    xd, rd = x.detach().double().requires_grad_(True), r.detach().double().requires_grad_(True)
+    nd = torch.nn.LayerNorm(256).to(DEV).double()
+    nd.load_state_dict({k: v.double() for k, v in norm.state_dict().items()})
+    want = nd(xd + rd)
+    torch.testing.assert_close(y.double(), want, rtol=0, atol=2e-6 * float(want.detach().abs().max()))
+    go = torch.randn(shape, generator=g).to(DEV)
+    y.backward(go)
+    want.backward(go.double())
+    for got, ref in ((x.grad, xd.grad), (r.grad, rd.grad), (norm.weight.grad, nd.weight.grad), (norm.bias.grad, nd.bias.grad)):
+        torch.testing.assert_close(got.double(), ref, rtol=0, atol=3e-6 * float(ref.abs().max()))
+    norm.weight.grad = norm.bias.grad = None
+
+
+@pytest.mark.gpu
+def test_dropout_mask_statistics_scaling_and_backward_consistency():
+    """With x = 0, gamma = 1, beta = 0 nothing but the mask decides where z = dropout(r) is zero: read the mask off z (the
+    tensor saved for the backward), check its rate and the 1/(1-p) scaling, then hold forward AND backward to torch's
+    expression evaluated with exactly that mask."""
+    p = 0.1
+    drop, norm = _modules(p)
+    norm = norm.to(DEV)
+    g = torch.Generator().manual_seed(3)
+    rows = 20000
+    x = torch.randn(rows, 256, generator=g).to(DEV).requires_grad_(True)
+    r = (torch.rand(rows, 256, generator=g) + 0.5).to(DEV).requires_grad_(True)       # never zero: zeros are drops
+    seed = 0x1234567890ABCDEF
+    y = add_dropout_norm(x, r, drop, norm, seed=seed)
+    z = y.grad_fn.saved_tensors[0].clone()
+    kept = (z - x.detach()) != 0
+    assert abs(float((~kept).float().mean()) - p) < 2e-3                              # 5 M samples: sigma = 1.3e-4
+    assert abs(float((~kept).float().mean(0).max()) - p) < 0.02                       # no column is special
+    torch.testing.assert_close((z - x.detach())[kept], (r.detach() / (1 - p))[kept], rtol=1e-6, atol=1e-6)
+    xd, rd = x.detach().double().requires_grad_(True), r.detach().double().requires_grad_(True)
+    nd = torch.nn.LayerNorm(256).to(DEV).double()
+    nd.load_state_dict({k: v.double() for k, v in norm.state_dict().items()})
+    want = nd(xd + rd * kept.double() / (1 - p))
+    torch.testing.assert_close(y.double(), want, rtol=0, atol=2e-6 * float(want.detach().abs().max()))
+    go = torch.randn(rows, 256, generator=g).to(DEV)
+    y.backward(go)
+    want.backward(go.double())
+    for got, ref in ((x.grad, xd.grad), (r.grad, rd.grad), (norm.weight.grad, nd.weight.grad), (norm.bias.grad, nd.bias.grad)):
+        torch.testing.assert_close(got.double(), ref, rtol=0, atol=3e-6 * float(ref.abs().max()))
+    # a different seed gives a different mask, the same seed the same one
+    z = z.clone()
+    y2 = add_dropout_norm(x, r, drop, norm, seed=seed + 1)
+    y3 = add_dropout_norm(x, r, drop, norm, seed=seed)
+    assert torch.equal(y3.grad_fn.saved_tensors[0], z) and not torch.equal(y2.grad_fn.saved_tensors[0], z)
+    # the parameter gradients are summed in a fixed order: bit-identical on a second run
+    gw = norm.weight.grad.clone()
+    norm.weight.grad = None
+    x.grad = r.grad = None
+    add_dropout_norm(x, r, drop, norm, seed=seed).backward(go)
+    assert torch.equal(norm.weight.grad, gw)

@@ -200,3 +200,47 @@ def test_mask_intersections_are_exact(n, pixels):
     b = (logits > 0).double()
     got = trk.mask_intersections(logits.cuda()).cpu().double()
     assert torch.equal(got, b @ b.t())
+
+
+def test_tracker_config_is_validated_on_the_host(hip_lib):
+    """vnx_tracker_state_bytes / _frame_workspace_bytes are pure host functions: sizes for a valid config, 0 and a
+    message for an invalid one (no GPU needed, nothing is launched)."""
+    import ctypes
+    from vnext_amd import _lib
+    good = dict(capacity=64, channels=256, memory_len=3, memo_tracklet_frames=10, match_metric=0, long_match=1,
+                frame_weight=1, temporal_weight=1, nms_thr_pre=0.5, nms_thr_post=0.05, init_score_thr=0.2,
+                addnew_score_thr=0.2, match_score_thr=0.5, memo_momentum=0.8)
+    cfg = _lib.TrackerConfig(**good)
+    size = hip_lib.vnx_tracker_state_bytes(ctypes.addressof(cfg))
+    # ids / last_frame / exist / label / long_len + embed + memo + long_embed + long_score, each 16-byte aligned
+    assert size == 64 + 5 * 64 * 4 + 2 * 64 * 256 * 4 + 64 * 3 * 256 * 4 + 64 * 3 * 4
+    assert hip_lib.vnx_tracker_frame_workspace_bytes(ctypes.addressof(cfg), 20, 14400) > 20 * 14400 // 8
+    assert hip_lib.vnx_mask_intersections_workspace_bytes(300, 14400) >= 300 * 225 * 8
+    for bad in (dict(capacity=0), dict(capacity=4096), dict(channels=30), dict(memory_len=0), dict(memory_len=64),
+                dict(match_metric=3), dict(memo_momentum=1.5), dict(memo_tracklet_frames=-1)):
+        cfg = _lib.TrackerConfig(**{**good, **bad})
+        assert hip_lib.vnx_tracker_state_bytes(ctypes.addressof(cfg)) == 0, bad
+        assert b"config out of range" in hip_lib.vnx_last_error()
+
+
+@pytest.mark.gpu
+def test_tracker_frame_argument_checks():
+    import ctypes
+    from vnext_amd import _lib
+    lib = _lib.lib()
+    dev = trk.DeviceTracker(**ARGS)
+    g = torch.Generator().manual_seed(0)
+    n = 3
+    frame = (torch.rand(n, 5, generator=g).cuda(), torch.zeros(n, dtype=torch.long).cuda(),
+             torch.randn(n, 1, 8, 8, generator=g).cuda(), torch.randn(n, 16, generator=g).cuda())
+    dev.match_device(*frame, 0)
+    cfgp, st = dev._cfg_ptr, dev.state.data_ptr()
+    ws = torch.empty(lib.vnx_tracker_frame_workspace_bytes(cfgp, 600, 64), dtype=torch.uint8, device="cuda")
+    ids = torch.empty(600, dtype=torch.int64, device="cuda")
+    args = lambda num, wsb: (cfgp, st, frame[2].data_ptr(), frame[3].data_ptr(), frame[0].data_ptr(),     # noqa: E731
+                             frame[1].data_ptr(), num, 64, 1, ids.data_ptr(), ws.data_ptr(), wsb, 0)
+    assert lib.vnx_tracker_frame(*args(513, ws.numel())) != 0 and b"up to 512 detections" in lib.vnx_last_error()
+    assert lib.vnx_tracker_frame(*args(3, 16)) != 0 and b"workspace smaller" in lib.vnx_last_error()
+    assert lib.vnx_tracker_frame(*args(0, 0)) == 0                                    # an empty frame is a no-op
+    with pytest.raises(RuntimeError, match="no CPU implementation"):
+        trk.DeviceTracker(**ARGS).match_device(*(t.cpu() for t in frame), 0)

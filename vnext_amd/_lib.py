@@ -14,10 +14,10 @@ LIB_PATH = os.path.join(_HERE, "lib", "libvnext_hip.so")
 
 VNX_F32, VNX_F64, VNX_BF16, VNX_F16 = 0, 1, 2, 3
 VNX_OK = 0
-ABI_VERSION = 7
+ABI_VERSION = 8
 MSDA_LEVELS_PACKED = 1
 
-_vp, _i, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+_vp, _i, _sz, _ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_longlong
 
 # name -> (restype, argtypes); mirrors include/vnext_hip.h declaration by declaration
 SIGNATURES = {
@@ -40,11 +40,13 @@ SIGNATURES = {
     "vnx_tracker_reset": (_i, [_vp, _vp, _vp]),
     "vnx_tracker_frame_workspace_bytes": (_sz, [_vp, _i, _i]),
     "vnx_tracker_frame": (_i, [_vp] * 6 + [_i] * 3 + [_vp, _vp, _sz, _vp]),
+    "vnx_add_dropout_layernorm_partial_bytes": (_sz, []),
+    "vnx_add_dropout_layernorm_forward": (_i, [_i] + [_vp] * 7 + [_ll, _i, ctypes.c_float, ctypes.c_float, ctypes.c_ulonglong, _vp]),
+    "vnx_add_dropout_layernorm_backward": (_i, [_i] + [_vp] * 9 + [_ll, _i, ctypes.c_float, ctypes.c_ulonglong, _vp]),
     "vnx_set_kernel_variant": (None, [_i]),
     "vnx_get_kernel_variant": (_i, []),
 }
 # measurement aids of include/vnext_hip_debug.h (bench.py, tools/): not part of the drop-in boundary
-_ll = ctypes.c_longlong
 DEBUG_SIGNATURES = {
     "vnx_debug_arm_stamps": (None, [_vp, _ll]),
     "vnx_debug_stamp_regions": (_i, [ctypes.POINTER(_i), ctypes.POINTER(_ll), ctypes.POINTER(_ll), _i]),

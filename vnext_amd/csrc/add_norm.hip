@@ -1,0 +1,212 @@
+// add_norm.hip -- y = LayerNorm(x + dropout(r)): the residual / dropout / normalisation chain that closes every
+// sub-layer of the deformable transformer, in ONE pass (the training step; round-1 review
+// item "fuse residual + dropout + LayerNorm chains").
+//
+// Reference (three ATen launches forward, four backward, per site; 30 sites per step):
+//   projects/SeqFormer/seqformer/models/deformable_transformer.py:201-236  `src = src + self.dropout1(src2);
+//   src = self.norm1(src)` ... (encoder layer), :286-385 (decoder layer: norm1 / norm2 / norm3 and the *_box copies);
+//   projects/IDOL/idol/models/deformable_transformer.py: the same layers.
+// Here: one wave per row of 256 channels (the models' hidden size; 64 lanes x float4), mean and variance by two wave
+// reductions over registers (two-pass, as accurate as ATen's Welford), no LDS, no barrier.  The dropout mask is not
+// stored: keep(element) = hash(seed, element index) >= p * 2^32, recomputed by the backward from the same seed.
+// Forward traffic: x, r read, y and z = x + dropout(r) written (z is what the backward needs; r is then dead);
+// backward: grad_y, z read, grad_x, grad_r written; the gamma / beta gradients leave as per-workgroup partial rows
+// that a second, tiny kernel adds in a fixed order (deterministic, no atomics).
+#include "vnx_common.h"
+
+#include <algorithm>
+
+namespace vnx {
+
+typedef float float4_t __attribute__((ext_vector_type(4)));
+
+constexpr int kAnC = 256;            // channels per row: one float4 per lane
+constexpr int kAnWaves = 4;          // rows per workgroup pass
+constexpr int kAnMaxBlocks = 1024;   // workgroups of the backward = rows of the partial-gradient buffer
+
+// murmur3-style mix of (element index, 64-bit seed) -> 32 uniform bits
+__device__ __forceinline__ uint32_t an_hash(uint32_t idx, uint32_t seed_lo, uint32_t seed_hi) {
+  uint32_t h = idx ^ seed_lo;
+  h *= 0xcc9e2d51u; h = (h << 15) | (h >> 17); h *= 0x1b873593u;
+  h ^= seed_hi;
+  h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+  return h;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// z = x + keep * r * scale for this lane's four channels of `row`
+__device__ __forceinline__ float4_t an_residual(float4_t x, float4_t r, int64_t row, int lane, uint32_t threshold,
+                                                float scale, uint32_t seed_lo, uint32_t seed_hi) {
+  if (threshold == 0u) return x + r;
+  const uint32_t base = uint32_t(row) * uint32_t(kAnC) + uint32_t(lane) * 4u;
+  const uint32_t hi = seed_hi ^ uint32_t(uint64_t(row) >> 24);     // rows beyond 2^24 (4 G elements) still differ
+  float4_t z = x;
+  if (an_hash(base + 0u, seed_lo, hi) >= threshold) z.x += r.x * scale;
+  if (an_hash(base + 1u, seed_lo, hi) >= threshold) z.y += r.y * scale;
+  if (an_hash(base + 2u, seed_lo, hi) >= threshold) z.z += r.z * scale;
+  if (an_hash(base + 3u, seed_lo, hi) >= threshold) z.w += r.w * scale;
+  return z;
+}
+
+__global__ void __launch_bounds__(64 * kAnWaves)
+add_dropout_layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ r,
+                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                 float* __restrict__ y, float* __restrict__ z_out, float* __restrict__ stats,
+                                 int64_t rows, uint32_t threshold, float scale, float eps, uint32_t seed_lo,
+                                 uint32_t seed_hi) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = int64_t(blockIdx.x) * kAnWaves + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int64_t at = row * kAnC + lane * 4;
+  const float4_t xv = *reinterpret_cast<const float4_t*>(x + at);
+  const float4_t rv = *reinterpret_cast<const float4_t*>(r + at);
+  const float4_t g = *reinterpret_cast<const float4_t*>(gamma + lane * 4);
+  const float4_t b = *reinterpret_cast<const float4_t*>(beta + lane * 4);
+  const float4_t z = an_residual(xv, rv, row, lane, threshold, scale, seed_lo, seed_hi);
+  const float mean = wave_sum((z.x + z.y) + (z.z + z.w)) * (1.f / kAnC);
+  const float4_t c = z - mean;
+  const float var = wave_sum((c.x * c.x + c.y * c.y) + (c.z * c.z + c.w * c.w)) * (1.f / kAnC);
+  const float rstd = rsqrtf(var + eps);
+  __builtin_nontemporal_store(c * rstd * g + b, reinterpret_cast<float4_t*>(y + at));
+  *reinterpret_cast<float4_t*>(z_out + at) = z;
+  if (lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+}
+
+// grad_x = dz, grad_r = keep * scale * dz, partial[block] = {sum_rows g * xhat, sum_rows g} over this workgroup's rows
+__global__ void __launch_bounds__(64 * kAnWaves)
+add_dropout_layernorm_bwd_kernel(const float* __restrict__ grad_y, const float* __restrict__ z,
+                                 const float* __restrict__ stats, const float* __restrict__ gamma,
+                                 float* __restrict__ grad_x, float* __restrict__ grad_r, float* __restrict__ partial,
+                                 int64_t rows, uint32_t threshold, float scale, uint32_t seed_lo, uint32_t seed_hi) {
+  __shared__ float4_t red[2][kAnWaves][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float4_t g = *reinterpret_cast<const float4_t*>(gamma + lane * 4);
+  float4_t dg = {0.f, 0.f, 0.f, 0.f}, db = dg;
+  for (int64_t row = int64_t(blockIdx.x) * kAnWaves + wave; row < rows; row += int64_t(gridDim.x) * kAnWaves) {
+    const int64_t at = row * kAnC + lane * 4;
+    const float4_t gy = *reinterpret_cast<const float4_t*>(grad_y + at);
+    const float4_t zv = *reinterpret_cast<const float4_t*>(z + at);
+    const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+    const float4_t xh = (zv - mean) * rstd;
+    const float4_t gg = gy * g;
+    const float m1 = wave_sum((gg.x + gg.y) + (gg.z + gg.w)) * (1.f / kAnC);
+    const float m2 = wave_sum((gg.x * xh.x + gg.y * xh.y) + (gg.z * xh.z + gg.w * xh.w)) * (1.f / kAnC);
+    const float4_t dz = (gg - m1 - xh * m2) * rstd;
+    dg += gy * xh;
+    db += gy;
+    __builtin_nontemporal_store(dz, reinterpret_cast<float4_t*>(grad_x + at));
+    float4_t dr = dz;
+    if (threshold != 0u) {
+      const uint32_t base = uint32_t(row) * uint32_t(kAnC) + uint32_t(lane) * 4u;
+      const uint32_t hi = seed_hi ^ uint32_t(uint64_t(row) >> 24);
+      dr.x = an_hash(base + 0u, seed_lo, hi) >= threshold ? dz.x * scale : 0.f;
+      dr.y = an_hash(base + 1u, seed_lo, hi) >= threshold ? dz.y * scale : 0.f;
+      dr.z = an_hash(base + 2u, seed_lo, hi) >= threshold ? dz.z * scale : 0.f;
+      dr.w = an_hash(base + 3u, seed_lo, hi) >= threshold ? dz.w * scale : 0.f;
+    }
+    __builtin_nontemporal_store(dr, reinterpret_cast<float4_t*>(grad_r + at));
+  }
+  red[0][wave][lane] = dg;
+  red[1][wave][lane] = db;
+  __syncthreads();
+  if (wave < 2) {      // wave 0 adds the gamma partials of the four waves, wave 1 the beta partials: fixed order
+    float4_t s = red[wave][0][lane];
+#pragma unroll
+    for (int w = 1; w < kAnWaves; ++w) s += red[wave][w][lane];
+    *reinterpret_cast<float4_t*>(partial + (int64_t(blockIdx.x) * 2 + wave) * kAnC + lane * 4) = s;
+  }
+}
+
+// grad_gamma[c] = sum_b partial[b][0][c], grad_beta[c] = sum_b partial[b][1][c], b ascending (deterministic)
+__global__ void __launch_bounds__(256)
+layernorm_param_grad_kernel(const float* __restrict__ partial, float* __restrict__ grad_gamma,
+                            float* __restrict__ grad_beta, int blocks) {
+  __shared__ float red[4][128];
+  // 512 columns (gamma | beta) x 4 interleaved block-subsets: thread t owns column t & 127 of quarter blockIdx.x,
+  // subset t >> 7
+  const int col = int(blockIdx.x) * 128 + (threadIdx.x & 127);     // 0..511
+  const int sub = threadIdx.x >> 7;                                // 0..1
+  float s0 = 0.f, s1 = 0.f;
+  for (int b = sub; b < blocks; b += 4) s0 += partial[int64_t(b) * 2 * kAnC + col];
+  for (int b = sub + 2; b < blocks; b += 4) s1 += partial[int64_t(b) * 2 * kAnC + col];
+  red[sub][threadIdx.x & 127] = s0;
+  red[sub + 2][threadIdx.x & 127] = s1;
+  __syncthreads();
+  if (sub == 0) {
+    const int c = threadIdx.x & 127;
+    const float s = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    if (col < kAnC) grad_gamma[col] = s; else grad_beta[col - kAnC] = s;
+  }
+}
+
+static int an_check(const char* who, int dtype, int64_t rows, int channels, float p) {
+  if (dtype != VNX_F32) { set_error("%s: only f32 is built (got dtype %d)", who, dtype); return VNX_ERR_UNSUPPORTED; }
+  if (channels != kAnC) { set_error("%s: built for %d channels per row (got %d)", who, kAnC, channels); return VNX_ERR_UNSUPPORTED; }
+  if (rows < 0 || rows >= (int64_t(1) << 40) || !(p >= 0.f && p < 1.f)) {
+    set_error("%s: bad sizes rows=%lld p=%g", who, (long long)rows, double(p));
+    return VNX_ERR_INVALID_ARGUMENT;
+  }
+  return VNX_OK;
+}
+
+static uint32_t an_threshold(float p) {      // keep iff hash >= threshold:  P(drop) = threshold / 2^32
+  const double t = double(p) * 4294967296.0;
+  return t <= 0.0 ? 0u : (t >= 4294967295.0 ? 0xffffffffu : uint32_t(t + 0.5));
+}
+
+}  // namespace vnx
+
+using namespace vnx;
+
+extern "C" size_t vnx_add_dropout_layernorm_partial_bytes(void) { return size_t(kAnMaxBlocks) * 2 * kAnC * 4; }
+
+extern "C" int vnx_add_dropout_layernorm_forward(int dtype, const void* x, const void* r, const void* gamma,
+                                                 const void* beta, void* y, void* z, void* stats, long long rows,
+                                                 int channels, float p, float eps, unsigned long long seed,
+                                                 void* hip_stream) {
+  if (int st = an_check("vnx_add_dropout_layernorm_forward", dtype, rows, channels, p)) return st;
+  if (rows == 0) return VNX_OK;
+  if (!x || !r || !gamma || !beta || !y || !z || !stats) {
+    set_error("vnx_add_dropout_layernorm_forward: null pointer argument");
+    return VNX_ERR_INVALID_ARGUMENT;
+  }
+  const int64_t blocks = (rows + kAnWaves - 1) / kAnWaves;
+  hipLaunchKernelGGL(add_dropout_layernorm_fwd_kernel, dim3(uint32_t(blocks)), dim3(64 * kAnWaves), 0,
+                     (hipStream_t)hip_stream, (const float*)x, (const float*)r, (const float*)gamma, (const float*)beta,
+                     (float*)y, (float*)z, (float*)stats, int64_t(rows), an_threshold(p), 1.f / (1.f - p), eps,
+                     uint32_t(seed), uint32_t(seed >> 32));
+  return check_launch("add_dropout_layernorm_fwd");
+}
+
+extern "C" int vnx_add_dropout_layernorm_backward(int dtype, const void* grad_y, const void* z, const void* stats,
+                                                  const void* gamma, void* grad_x, void* grad_r, void* grad_gamma,
+                                                  void* grad_beta, void* partial, long long rows, int channels, float p,
+                                                  unsigned long long seed, void* hip_stream) {
+  if (int st = an_check("vnx_add_dropout_layernorm_backward", dtype, rows, channels, p)) return st;
+  if (!grad_gamma || !grad_beta || !partial) {
+    set_error("vnx_add_dropout_layernorm_backward: null pointer argument");
+    return VNX_ERR_INVALID_ARGUMENT;
+  }
+  hipStream_t stream = (hipStream_t)hip_stream;
+  int blocks = int(std::min<int64_t>(kAnMaxBlocks, (rows + kAnWaves - 1) / kAnWaves));
+  if (rows > 0) {
+    if (!grad_y || !z || !stats || !gamma || !grad_x || !grad_r) {
+      set_error("vnx_add_dropout_layernorm_backward: null pointer argument");
+      return VNX_ERR_INVALID_ARGUMENT;
+    }
+    hipLaunchKernelGGL(add_dropout_layernorm_bwd_kernel, dim3(uint32_t(blocks)), dim3(64 * kAnWaves), 0, stream,
+                       (const float*)grad_y, (const float*)z, (const float*)stats, (const float*)gamma, (float*)grad_x,
+                       (float*)grad_r, (float*)partial, int64_t(rows), an_threshold(p), 1.f / (1.f - p), uint32_t(seed),
+                       uint32_t(seed >> 32));
+  } else {
+    blocks = 0;
+  }
+  hipLaunchKernelGGL(layernorm_param_grad_kernel, dim3(4), dim3(256), 0, stream, (const float*)partial,
+                     (float*)grad_gamma, (float*)grad_beta, blocks);
+  return check_launch("add_dropout_layernorm_bwd");
+}

@@ -19,6 +19,7 @@ from torch import nn
 from torch.nn.init import constant_, normal_, xavier_uniform_
 
 from ..ops.functions import level_tensors
+from ..ops.fused_norm import add_dropout_norm
 from ..ops.modules import MSDeformAttnIDOL
 from .seqformer_transformer import DeformableTransformerEncoder as _ClipEncoder
 from .seqformer_transformer import _get_activation_fn, _get_clones, inverse_sigmoid
@@ -40,9 +41,9 @@ class DeformableTransformerEncoderLayer(nn.Module):
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None):
         q = src if pos is None else src + pos
         src2 = self.self_attn(q, reference_points, src, spatial_shapes, level_start_index, padding_mask)[0]
-        src = self.norm1(src + self.dropout1(src2))
+        src = add_dropout_norm(src, src2, self.dropout1, self.norm1)
         src2 = self.linear2(self.dropout2(self.activation(self.linear1(src))))
-        return self.norm2(src + self.dropout3(src2))
+        return add_dropout_norm(src, src2, self.dropout3, self.norm2)
 
 
 class DeformableTransformerEncoder(nn.Module):
@@ -82,12 +83,12 @@ class DeformableTransformerDecoderLayer(nn.Module):
                 src_padding_mask=None):
         q = k = tgt if query_pos is None else tgt + query_pos
         tgt2 = self.self_attn(q.transpose(0, 1), k.transpose(0, 1), tgt.transpose(0, 1))[0].transpose(0, 1)
-        tgt = self.norm2(tgt + self.dropout2(tgt2))
+        tgt = add_dropout_norm(tgt, tgt2, self.dropout2, self.norm2)
         tgt2, loc, w = self.cross_attn(tgt if query_pos is None else tgt + query_pos, reference_points, src,
                                        src_spatial_shapes, level_start_index, src_padding_mask)
-        tgt = self.norm1(tgt + self.dropout1(tgt2))
+        tgt = add_dropout_norm(tgt, tgt2, self.dropout1, self.norm1)
         tgt2 = self.linear2(self.dropout3(self.activation(self.linear1(tgt))))
-        return self.norm3(tgt + self.dropout4(tgt2)), loc, w
+        return add_dropout_norm(tgt, tgt2, self.dropout4, self.norm3), loc, w
 
 
 class DeformableTransformerDecoder(nn.Module):

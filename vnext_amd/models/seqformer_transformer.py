@@ -20,6 +20,7 @@ from torch import nn
 from torch.nn.init import constant_, normal_, xavier_uniform_
 
 from ..ops.functions import level_tensors
+from ..ops.fused_norm import add_dropout_norm
 from ..ops.modules import MSDeformAttnSeqFormer
 
 
@@ -65,12 +66,12 @@ class DeformableTransformerEncoderLayer(nn.Module):
 
     def forward_ffn(self, src):
         src2 = self.linear2(self.dropout2(self.activation(self.linear1(src))))
-        return self.norm2(src + self.dropout3(src2))
+        return add_dropout_norm(src, src2, self.dropout3, self.norm2)
 
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None):
         src2 = self.self_attn(self.with_pos_embed(src, pos), None, reference_points, src, spatial_shapes,
                               level_start_index, padding_mask)
-        src = self.norm1(src + self.dropout1(src2))
+        src = add_dropout_norm(src, src2, self.dropout1, self.norm1)
         return self.forward_ffn(src)
 
 
@@ -140,24 +141,24 @@ class DeformableTransformerDecoderLayer(nn.Module):
 
     def forward_ffn(self, tgt):
         tgt2 = self.linear2(self.dropout3(self.activation(self.linear1(tgt))))
-        return self.norm3(tgt + self.dropout4(tgt2))
+        return add_dropout_norm(tgt, tgt2, self.dropout4, self.norm3)
 
     def forward_ffn_box(self, tgt):
         tgt2 = self.linear2_box(self.dropout3_box(self.activation_box(self.linear1_box(tgt))))
-        return self.norm3_box(tgt + self.dropout4_box(tgt2))
+        return add_dropout_norm(tgt, tgt2, self.dropout4_box, self.norm3_box)
 
     def forward(self, tgt, tgt_box, query_pos, reference_points, src, src_spatial_shapes, level_start_index,
                 src_padding_mask=None):
         # self attention of the mask & class queries
         q1 = k1 = self.with_pos_embed(tgt, query_pos)
         tgt2 = self.self_attn(q1.transpose(0, 1), k1.transpose(0, 1), tgt.transpose(0, 1))[0].transpose(0, 1)
-        tgt = self.norm2(tgt + self.dropout2(tgt2))
+        tgt = add_dropout_norm(tgt, tgt2, self.dropout2, self.norm2)
 
         if tgt_box.dim() == 3:  # first layer: box queries still shared by the frames [N, Q, C]
             q_box = k_box = self.with_pos_embed(tgt_box, query_pos)
             tgt2_box = self.self_attn_box(q_box.transpose(0, 1), k_box.transpose(0, 1),
                                           tgt_box.transpose(0, 1))[0].transpose(0, 1)
-            tgt_box = self.norm2_box(tgt_box + self.dropout2_box(tgt2_box))
+            tgt_box = add_dropout_norm(tgt_box, tgt2_box, self.dropout2_box, self.norm2_box)
             box_query = self.with_pos_embed(tgt_box, query_pos)
         else:  # [N, T, Q, C]: every frame attends over its own box queries -- one batched call
             N, nf, num_q, C = tgt_box.shape
@@ -165,22 +166,22 @@ class DeformableTransformerDecoderLayer(nn.Module):
             pos = None if query_pos is None else query_pos.unsqueeze(1).expand(N, nf, num_q, C).reshape(N * nf, num_q, C)
             q_box = k_box = self.with_pos_embed(flat, pos)
             t2 = self.self_attn_box(q_box.transpose(0, 1), k_box.transpose(0, 1), flat.transpose(0, 1))[0].transpose(0, 1)
-            tgt_box = self.norm2_box(flat + self.dropout2_box(t2)).view(N, nf, num_q, C)
+            tgt_box = add_dropout_norm(flat, t2, self.dropout2_box, self.norm2_box).view(N, nf, num_q, C)
             box_query = tgt_box if query_pos is None else tgt_box + query_pos.unsqueeze(1)
 
         tgt2, tgt2_box, sampling_locations, attention_weights = self.cross_attn(
             self.with_pos_embed(tgt, query_pos), box_query, reference_points, src, src_spatial_shapes,
             level_start_index, src_padding_mask)
 
-        if tgt_box.dim() == 3:
-            tgt_box = tgt_box.unsqueeze(1) + self.dropout1_box(tgt2_box)
+        if tgt_box.dim() == 3:      # first layer: the shared box queries broadcast over the frames
+            tgt_box = self.norm1_box(tgt_box.unsqueeze(1) + self.dropout1_box(tgt2_box))
         else:
-            tgt_box = tgt_box + self.dropout1_box(tgt2_box)
-        tgt_box = self.forward_ffn_box(self.norm1_box(tgt_box))
+            tgt_box = add_dropout_norm(tgt_box, tgt2_box, self.dropout1_box, self.norm1_box)
+        tgt_box = self.forward_ffn_box(tgt_box)
 
         time_weight = F.softmax(self.time_attention_weights(tgt_box), 1)   # softmax over the frames
         tgt2 = (tgt2 * time_weight).sum(1)
-        tgt = self.norm1(tgt + self.dropout1(tgt2))
+        tgt = add_dropout_norm(tgt, tgt2, self.dropout1, self.norm1)
         return self.forward_ffn(tgt), tgt_box, sampling_locations, attention_weights
 
 

@@ -1,0 +1,80 @@
+"""y = LayerNorm(x + dropout(r)) in one HIP pass (vnext_amd/csrc/add_norm.hip).
+
+The reference closes every sub-layer of its deformable transformer with
+`x = x + self.dropoutN(x2); x = self.normN(x)` (projects/SeqFormer/seqformer/models/deformable_transformer.py:201-236,
+286-385; IDOL's copy is identical): dropout, add and layer_norm are three launches forward and four backward, 30 times
+per training step.  `add_dropout_norm(x, r, dropout_module, norm_module)` is that expression; on the GPU, for fp32 rows
+of 256 channels (both models' hidden size), it is one launch forward and two backward.  Everywhere else (CPU, autocast,
+other widths) it IS the reference expression, evaluated by torch.
+
+Dropout: the kernel keeps element e iff hash(seed, e) >= p * 2^32 and the backward recomputes the mask from the same
+seed, so no mask is stored.  The seed of a call is `torch.initial_seed()` mixed with a per-process call counter: runs
+are repeatable after `torch.manual_seed`, masks differ from call to call, but they are not torch's Philox stream (a
+dropout mask has no reference value to be equal to).  A seed is a host integer: under hipGraph capture it is baked
+into the graph, so captured TRAINING replays repeat their masks (inference, p = 0, is unaffected).
+"""
+from __future__ import annotations
+
+import torch
+
+from .. import _lib
+
+CHANNELS = 256
+_calls = 0
+
+
+def _next_seed() -> int:
+    global _calls
+    _calls += 1
+    return (torch.initial_seed() * 0x9E3779B97F4A7C15 + _calls * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+
+
+class _AddDropoutLayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, r, gamma, beta, p, eps, seed):
+        lib = _lib.lib()
+        x, r = x.contiguous(), r.contiguous()
+        rows = x.numel() // CHANNELS
+        y, z = torch.empty_like(x), torch.empty_like(x)
+        stats = torch.empty(rows, 2, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.vnx_add_dropout_layernorm_forward(
+                _lib.VNX_F32, x.data_ptr(), r.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), z.data_ptr(),
+                stats.data_ptr(), rows, CHANNELS, float(p), float(eps), int(seed), _lib.current_stream(x)))
+        ctx.save_for_backward(z, stats, gamma)
+        ctx.p, ctx.seed = float(p), int(seed)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_y):
+        lib = _lib.lib()
+        z, stats, gamma = ctx.saved_tensors
+        grad_y = grad_y.contiguous()
+        rows = z.numel() // CHANNELS
+        grad_x, grad_r = torch.empty_like(z), torch.empty_like(z)
+        grad_gamma, grad_beta = torch.empty_like(gamma), torch.empty_like(gamma)
+        partial = torch.empty(lib.vnx_add_dropout_layernorm_partial_bytes(), dtype=torch.uint8, device=z.device)
+        with torch.cuda.device(z.device):
+            _lib.check(lib.vnx_add_dropout_layernorm_backward(
+                _lib.VNX_F32, grad_y.data_ptr(), z.data_ptr(), stats.data_ptr(), gamma.data_ptr(), grad_x.data_ptr(),
+                grad_r.data_ptr(), grad_gamma.data_ptr(), grad_beta.data_ptr(), partial.data_ptr(), rows, CHANNELS,
+                ctx.p, ctx.seed, _lib.current_stream(z)))
+        return grad_x, grad_r, grad_gamma, grad_beta, None, None, None
+
+
+def fused_applies(x, r, norm) -> bool:
+    return (x.is_cuda and x.dtype == torch.float32 and r.dtype == torch.float32 and x.shape == r.shape
+            and x.shape[-1] == CHANNELS and tuple(norm.normalized_shape) == (CHANNELS,)
+            and norm.weight is not None and norm.bias is not None and norm.weight.dtype == torch.float32
+            and not torch.is_autocast_enabled())
+
+
+def add_dropout_norm(x, r, dropout, norm, seed=None):
+    """`norm(x + dropout(r))` for an nn.Dropout and an nn.LayerNorm (see the module docstring)."""
+    if not fused_applies(x, r, norm):
+        return norm(x + dropout(r))
+    p = dropout.p if dropout.training else 0.0
+    if p >= 1.0:
+        return norm(x + dropout(r))
+    return _AddDropoutLayerNorm.apply(x, r, norm.weight, norm.bias, p, norm.eps, _next_seed() if seed is None else seed)
