@@ -560,6 +560,30 @@ __device__ __forceinline__ float group8_sum(float v) {
   return v;
 }
 
+// The same for four values at once, as v_add_f32_dpp (one instruction per step): left to the compiler the four chains are
+// vectorised into v_pk_add_f32, which has no DPP form, so every step becomes v_mov_b32_dpp + half a packed add.  The four
+// chains are interleaved, so a DPP read follows the write of its register by three instructions (>= the 2 wait states the
+// hardware wants between a VALU write and a DPP read); the leading s_nop covers the first step.
+__device__ __forceinline__ void group8_sum4(float4_t& v) {
+  float a = v.x, b = v.y, c = v.z, d = v.w;
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %3, %3, %3 row_half_mirror row_mask:0xf bank_mask:0xf"
+      : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+  v = float4_t{a, b, c, d};
+}
+
 template <typename TV>
 __device__ __forceinline__ float4_t load_row4(const TV* p);
 template <>
@@ -696,6 +720,8 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
       // kernel's units (pixel ranges of `rows per unit` rows) the sample's corners fall into
       if (sample_records != nullptr) {
         const int64_t ri = ((int64_t(b) * d.M + m) * d.L + l) * (int64_t(d.Lq) * d.P) + int64_t(q) * d.P + (p - l * d.P);
+        // (nt stores of the records / unit tags / gradients: this kernel 93.6 -> 73 us at the encoder shape, the
+        //  grad_value kernel that reads them correspondingly slower -- 211.7 vs 213-215 us per backward; not kept)
         sample_records[ri] = record;
         if (sample_units != nullptr) {
           uint32_t uu = 0xffffffffu;
@@ -784,20 +810,38 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
     constexpr int kPer = LP_T / PG;
     constexpr int kWant = WPB == 1 ? VNX_K1_BATCH : VNX_K1_BATCH_LARGE;
     constexpr int kBatch = kPer < kWant ? kPer : kWant;
+    // Round 2, late: this kernel is bound by vector-instruction issue on large calls (PMC, encoder 360p: 46.6 M wave
+    // instructions x 4 clk / 1 024 SIMDs = 96 us = its duration), and most of them were the per-channel bilinear
+    // algebra of every sample (val, d val / dh, d val / dw: 56 operations, then three dots and three 8-lane
+    // reductions).  By linearity all three gradients are combinations of FOUR dots d_k = <grad_out row, tap row k>:
+    //   grad_attn = hh (hw d1 + lw d2) + lh (hw d3 + lw d4),  grad_w = a (hh (d2 - d1) + lh (d4 - d3)),
+    //   grad_h = a (hw (d3 - d1) + lw (d4 - d2))
+    // so phase 2 only takes the dots (3 packed instructions per tap) and reduces them; the combinations are left to
+    // phase 3, where ONE lane per sample does them for 64 samples at once instead of every lane for its group's sample.
+    typedef float float2_t __attribute__((ext_vector_type(2)));
+    const float2_t t_lo = {top.x, top.y}, t_hi = {top.z, top.w};
+    auto dot = [&](const float4_t v) {
+      float2_t acc = t_lo * float2_t{v.x, v.y};
+      acc = t_hi * float2_t{v.z, v.w} + acc;
+      return acc.x + acc.y;
+    };
 #pragma unroll
     for (int i0 = 0; i0 < kPer; i0 += kBatch) {
       uint4_t o[kBatch];
-      float4_t geo[kBatch];
       float4_t v[kBatch][4];
 #pragma unroll
-      for (int j = 0; j < kBatch; ++j) { o[j] = g_off[i0 + j]; geo[j] = g_geo[i0 + j]; }
+      for (int j = 0; j < kBatch; ++j) o[j] = g_off[i0 + j];
 #pragma unroll
       for (int j = 0; j < kBatch; ++j) {
         v[j][0] = tap(o[j].x); v[j][1] = tap(o[j].y); v[j][2] = tap(o[j].z); v[j][3] = tap(o[j].w);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int j = 0; j < kBatch; ++j) one_sample(i0 + j, o[j], geo[j], v[j][0], v[j][1], v[j][2], v[j][3]);
+      for (int j = 0; j < kBatch; ++j) {
+        float4_t dd = {dot(v[j][0]), dot(v[j][1]), dot(v[j][2]), dot(v[j][3])};
+        group8_sum4(dd);
+        if (ch == 0) g_res[i0 + j] = dd;
+      }
     }
   } else {
     for (int i = 0; i < per_group; ++i) {
@@ -815,7 +859,15 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
     if (q3 < d.Lq) {
       const int l = p / d.P;
       const int64_t wi = ((int64_t(b) * d.Lq + q3) * d.M + m) * LP + p;
-      const float4_t r = s_res[qi3 * (LP + 1) + p];
+      float4_t r = s_res[qi3 * (LP + 1) + p];
+      if constexpr (LP_T > 0 && !ATOMICS) {   // the four dots of phase 2 -> (grad_w, grad_h, grad_attn), see there
+        const float4_t gq = s_geo[qi3 * (LP + 1) + p];
+        const float lh = gq.x, lw = gq.y, a = gq.z, hh = 1.f - lh, hw = 1.f - lw;
+        const float d1 = r.x, d2 = r.y, d3 = r.z, d4 = r.w;
+        r.x = a * (hh * (d2 - d1) + lh * (d4 - d3));
+        r.y = a * (hw * (d3 - d1) + lw * (d4 - d2));
+        r.z = hh * (hw * d1 + lw * d2) + lh * (hw * d3 + lw * d4);
+      }
       // (a vector load of the level size here is one more dependent memory round trip at the end of the wave)
       const float Hf = pairs <= 64 ? float(keep_H) : float(int(shapes[2 * l]));
       const float Wf = pairs <= 64 ? float(keep_W) : float(int(shapes[2 * l + 1]));
