@@ -501,7 +501,10 @@ msda_bwd_gv_sel_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
   const uint4_t* my_recs = records + level_base;
   const uint32_t* my_uids = unit_ids + level_base;
   const TV* go_head = grad_out + (int64_t(b) * d.Lq * d.M + m) * D;
-  const int64_t q_stride = int64_t(d.M) * D;
+  // element strides as 24-bit multiplies (v_mul_u32_u24, full rate; the 64-bit products the compiler made of them were
+  // three quarter-rate v_mul_lo / v_mul_hi each): queries and rows < 2^24, heads x 32 channels < 2^24, products < 2^32
+  // (the launcher refuses larger calls)
+  const uint32_t q_stride = uint32_t(d.M) * uint32_t(D);
   const uint4_t none = {0xffffffffu, 0u, 0u, 0u};
   // (g0 = tid, g1 = tid + kThreads: the two 16-B pieces of staged rows a thread moves; grp = tid >> 3, ch4 = tid & 7: the
   //  8-lane group and its 16-B channel piece -- all derived where used from an opaque copy of tid, see opaque())
@@ -582,8 +585,8 @@ msda_bwd_gv_sel_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
       }
       const int g0 = opaque(tid), g1 = g0 + kThreads;
       const int qa = c * kQcMax + (g0 >> 3), qb = c * kQcMax + (g1 >> 3);
-      if (qa < n_q) pg0 = load4<TV>(go_head + int64_t(q_win + int(selq[qa])) * q_stride + (g0 & 7) * 4);
-      if (qb < n_q) pg1 = load4<TV>(go_head + int64_t(q_win + int(selq[qb])) * q_stride + (g1 & 7) * 4);
+      if (qa < n_q) pg0 = load4<TV>(go_head + __umul24(uint32_t(q_win) + selq[qa], q_stride) + (g0 & 7) * 4);
+      if (qb < n_q) pg1 = load4<TV>(go_head + __umul24(uint32_t(q_win) + selq[qb], q_stride) + (g1 & 7) * 4);
     };
     prefetch(0);
     for (int c = 0; c < n_chunks; ++c, ++gchunk) {
@@ -684,7 +687,7 @@ msda_bwd_gv_sel_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
       for (int k = 0; k < kRpg; ++k) {
         const int row = grp + k * kGroups;
         if (row < rows) {
-          float* p = reinterpret_cast<float*>(out) + int64_t(row) * d.M * D + ch4 * 4;
+          float* p = reinterpret_cast<float*>(out) + __umul24(uint32_t(row), q_stride) + ch4 * 4;
           atomic_add(p, racc[k].x); atomic_add(p + 1, racc[k].y); atomic_add(p + 2, racc[k].z); atomic_add(p + 3, racc[k].w);
         }
       }
@@ -695,7 +698,7 @@ msda_bwd_gv_sel_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
 #pragma unroll
   for (int k = 0; k < kRpg; ++k) {
     const int row = grp + k * kGroups;
-    if (row < rows) store4<TV>(out + int64_t(row) * d.M * D + ch4 * 4, racc[k]);
+    if (row < rows) store4<TV>(out + __umul24(uint32_t(row), q_stride) + ch4 * 4, racc[k]);
   }
   VNX_STAMP(12);
 }
@@ -718,6 +721,8 @@ bool msda_d32_gvrec_supported(int vdt, int ldt, const MsdaDims& d) {
   if (d.L > rec::kLevelsMax) return false;
   if (d.S > rec::kRowsMax * 4000) return false;     // units and rows/unit share one word
   if (int64_t(d.Lq) * d.P >= (int64_t(1) << 31)) return false;
+  // 24-bit stride multiplies in the selection kernel: query index and heads x channels below 2^24, offsets below 2^32
+  if (d.Lq >= (1 << 24) || d.M * 32 >= (1 << 24) || int64_t(d.Lq) * d.M * 32 >= (int64_t(1) << 32)) return false;
   const int64_t blocks = int64_t(d.B) * d.M * msda_gvrec_units_bound(d, 16);
   return blocks < (int64_t(1) << 31);
 }
