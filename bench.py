@@ -73,9 +73,23 @@ def make_set(res, B, Lq, seed, device, dist="U"):
     if dist == "U":
         loc = torch.rand(B, Lq, 8, 4, 4, 2, device=device, generator=g)
     else:
-        ref = torch.rand(B, Lq, 1, 1, 1, 2, device=device, generator=g)
+        # SURVEY.md section 8d, "M": a reference point per query (decoder: random box centres; encoder, Lq == S: the
+        # pixel-centre grid of deformable_transformer.py:183-190) + (dir_m (k + 1) + N(0, 1)) / (W_l, H_l), the
+        # initialisation bias of ops/modules/ms_deform_attn.py:65-73
+        if Lq == S:
+            cells = []
+            for h, w in SHAPES[res]:
+                ys, xs = torch.meshgrid(torch.arange(h, device=device) + 0.5, torch.arange(w, device=device) + 0.5, indexing="ij")
+                cells.append(torch.stack([xs.reshape(-1) / w, ys.reshape(-1) / h], -1))
+            ref = torch.cat(cells, 0).view(1, S, 1, 1, 1, 2).expand(B, S, 1, 1, 1, 2)
+        else:
+            ref = torch.rand(B, Lq, 1, 1, 1, 2, device=device, generator=g)
+        th = torch.arange(8, device=device) * (2 * math.pi / 8)
+        dirs = torch.stack([th.cos(), th.sin()], -1)
+        dirs = (dirs / dirs.abs().max(-1, keepdim=True)[0]).view(1, 1, 8, 1, 1, 2)
+        steps = torch.arange(1, 5, device=device, dtype=torch.float32).view(1, 1, 1, 1, 4, 1)
         wh = torch.stack([shapes[:, 1], shapes[:, 0]], -1).float().view(1, 1, 1, 4, 1, 2)
-        loc = (ref + 2.0 * torch.randn(B, Lq, 8, 4, 4, 2, device=device, generator=g) / wh).contiguous()
+        loc = (ref + (dirs * steps + torch.randn(B, Lq, 8, 4, 4, 2, device=device, generator=g)) / wh).contiguous()
     attn = torch.softmax(torch.randn(B, Lq, 8, 16, device=device, generator=g), -1).view(B, Lq, 8, 4, 4)
     grad_out = torch.randn(B, Lq, 256, device=device, generator=g)
     out = torch.empty(B, Lq, 256, device=device)
