@@ -663,7 +663,7 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
         const int n = int(shapes[2 * l]) * int(shapes[2 * l + 1]);
         int units = (n + kGvRowsMax - 1) / kGvRowsMax;
         if (units < units_min) units = units_min;
-        if (gv_query_splits(units, d.Lq, d.P, true) > 1) {
+        if (gv_query_splits(units, d.Lq, d.P, true, d.B * d.M) > 1) {
           float* rows = fa.qsplit_zero + ((int64_t(b) * d.S + int(lsi[l])) * d.M + m) * D;
           for (int r = (t_in_b * WPB + wave) * 8 + (lane >> 3); r < n; r += tiles_per_batch * WPB * 8)
             *reinterpret_cast<float4_t*>(rows + int64_t(r) * d.M * D + (lane & 7) * 4) = float4_t{0.f, 0.f, 0.f, 0.f};

@@ -450,7 +450,7 @@ msda_bwd_gv_sel_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
       rpu = (n + units - 1) / units;
       units = (n + rpu - 1) / rpu;
     }
-    const int qs = gv_query_splits(units, d.Lq, P, sizeof(TV) == 4);
+    const int qs = gv_query_splits(units, d.Lq, P, sizeof(TV) == 4, d.B * d.M);
     meta[4 * tid] = H; meta[4 * tid + 1] = W; meta[4 * tid + 2] = int(lsi[tid]);
     meta[4 * tid + 3] = units | (rpu << 12) | (qs << 24);     // units <= 4000, rpu <= 320, qs <= 8
   }
@@ -707,7 +707,7 @@ msda_bwd_gv_sel_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
 
 int msda_gvrec_units_bound(const MsdaDims& d, int units_min) {
   // row-units of all levels, plus the extra pieces of the query-split levels (at most two row-units each)
-  const int qs = gv_query_splits(1, d.Lq, d.P, true);
+  const int qs = gv_query_splits(1, d.Lq, d.P, true, d.B * d.M);
   return d.L * (units_min + 1) + (d.S + rec::kRowsMax - 1) / rec::kRowsMax + d.L * 4 * (qs - 1);
 }
 
