@@ -79,7 +79,7 @@ __device__ __forceinline__ void store_row4<bf16_t>(bf16_t* p, float4_t v) {
   uint2_t r;
   r.x = uint32_t(f32_to_bf16_bits(v.x)) | (uint32_t(f32_to_bf16_bits(v.y)) << 16);
   r.y = uint32_t(f32_to_bf16_bits(v.z)) | (uint32_t(f32_to_bf16_bits(v.w)) << 16);
-  *reinterpret_cast<uint2_t*>(p) = r;
+  __builtin_nontemporal_store(r, reinterpret_cast<uint2_t*>(p));
 }
 __device__ __forceinline__ uint32_t float_to_half_bits(float f) {
   return uint32_t(__builtin_bit_cast(uint16_t, _Float16(f)));
@@ -89,7 +89,7 @@ __device__ __forceinline__ void store_row4<f16_t>(f16_t* p, float4_t v) {
   uint2_t r;
   r.x = float_to_half_bits(v.x) | (float_to_half_bits(v.y) << 16);
   r.y = float_to_half_bits(v.z) | (float_to_half_bits(v.w) << 16);
-  *reinterpret_cast<uint2_t*>(p) = r;
+  __builtin_nontemporal_store(r, reinterpret_cast<uint2_t*>(p));
 }
 
 // -----------------------------------------------------------------------------

@@ -60,13 +60,13 @@ template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, float4_t v
   uint2_t r;
   r.x = uint32_t(f32_to_bf16_bits(v.x)) | (uint32_t(f32_to_bf16_bits(v.y)) << 16);
   r.y = uint32_t(f32_to_bf16_bits(v.z)) | (uint32_t(f32_to_bf16_bits(v.w)) << 16);
-  *reinterpret_cast<uint2_t*>(p) = r;
+  __builtin_nontemporal_store(r, reinterpret_cast<uint2_t*>(p));
 }
 template <> __device__ __forceinline__ void store4<f16_t>(f16_t* p, float4_t v) {
   uint2_t r;
   r.x = uint32_t(__builtin_bit_cast(uint16_t, _Float16(v.x))) | (uint32_t(__builtin_bit_cast(uint16_t, _Float16(v.y))) << 16);
   r.y = uint32_t(__builtin_bit_cast(uint16_t, _Float16(v.z))) | (uint32_t(__builtin_bit_cast(uint16_t, _Float16(v.w))) << 16);
-  *reinterpret_cast<uint2_t*>(p) = r;
+  __builtin_nontemporal_store(r, reinterpret_cast<uint2_t*>(p));
 }
 
 // The value again, but opaque to the optimiser: what is derived from the result is recomputed where it is used instead of
