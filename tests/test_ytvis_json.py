@@ -38,3 +38,24 @@ def test_masks_round_trip_and_video_record():
     assert rec[0]["video_id"] == 7 and rec[0]["category_id"] == 4 and len(rec[0]["segmentations"]) == 4
     assert not rle_decode(rec[0]["segmentations"][3]).any()              # an absent frame is an empty mask
     json.dumps(rec)                                                        # serialisable as the evaluator writes it
+
+
+def test_rle_writer_reproduces_the_pycocotools_strings_held_by_the_reference_tests():
+    """tests/golden/rle_coco.json (oracle/make_golden_rle.py): the four RLE strings under /root/reference/tests
+    (tests/data/test_coco_evaluation.py:24, tests/test_visualizer.py:54) are pycocotools outputs.  Decoding one and
+    encoding the mask again must give the identical string -- that pins string_to_counts, rle_decode, rle_counts and
+    counts_to_string (negative differences, multi-character counts, the column-major order) to the library."""
+    import os
+    from conftest import ROOT
+    cases = json.load(open(os.path.join(ROOT, "tests", "golden", "rle_coco.json")))
+    assert len(cases) == 4
+    for c in cases:
+        h, w = c["size"]
+        counts = string_to_counts(c["counts"])
+        assert sum(counts) == h * w and all(n >= 0 for n in counts)
+        assert counts_to_string(counts) == c["counts"]
+        mask = rle_decode({"size": c["size"], "counts": c["counts"]})
+        assert mask.shape == (h, w) and mask.any() and not mask.all()
+        assert rle_encode(mask) == {"size": [h, w], "counts": c["counts"]}
+        # runs alternate 0 / 1 starting with 0: the set pixels are the odd runs
+        assert int(mask.sum()) == sum(counts[1::2])
