@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define VNX_ABI_VERSION 8
+#define VNX_ABI_VERSION 9
 
 /* element types */
 enum {
@@ -295,18 +295,22 @@ int vnx_tracker_frame(const vnx_tracker_config* cfg, void* state, const float* m
  *   z = x + dropout(r) is an OUTPUT the backward needs (r is dead afterwards).  p = drop probability (0 in eval mode),
  *   kept elements are scaled by 1 / (1 - p).  The mask is not stored: element e is kept iff hash(seed, e) >= p * 2^32,
  *   and the backward recomputes it from the same `seed` -- pass the same value to both calls, a fresh one per
- *   forward call.
+ *   forward call.  seed_device (may be null): a 64-bit word in DEVICE memory that the kernels read and mix into
+ *   `seed`.  A host integer is baked into a captured hipGraph, so every replay of a captured training step would
+ *   drop the same elements; a device word the caller bumps once per step (inside the graph) gives each replay fresh
+ *   masks.  It must hold the same value when the matching backward runs.
  * Backward: grad_x = d loss / d x, grad_r = d loss / d r (both [rows, 256]), grad_gamma, grad_beta [256] (overwritten, not
  * accumulated; summed in a fixed order).  partial: scratch of vnx_add_dropout_layernorm_partial_bytes() bytes.
  */
 size_t vnx_add_dropout_layernorm_partial_bytes(void);
 int vnx_add_dropout_layernorm_forward(int dtype, const void* x, const void* r, const void* gamma, const void* beta,
                                       void* y, void* z, void* stats, long long rows, int channels, float p, float eps,
-                                      unsigned long long seed, void* hip_stream);
+                                      unsigned long long seed, const unsigned long long* seed_device,
+                                      void* hip_stream);
 int vnx_add_dropout_layernorm_backward(int dtype, const void* grad_y, const void* z, const void* stats,
                                        const void* gamma, void* grad_x, void* grad_r, void* grad_gamma, void* grad_beta,
                                        void* partial, long long rows, int channels, float p, unsigned long long seed,
-                                       void* hip_stream);
+                                       const unsigned long long* seed_device, void* hip_stream);
 
 /*
  * Kernel selection override for A/B measurements and tests (process-wide):

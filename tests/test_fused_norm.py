@@ -91,3 +91,82 @@ def test_dropout_mask_statistics_scaling_and_backward_consistency():
     x.grad = r.grad = None
     add_dropout_norm(x, r, drop, norm, seed=seed).backward(go)
     assert torch.equal(norm.weight.grad, gw)
+
+
+@pytest.mark.gpu
+def test_captured_training_replays_draw_fresh_masks_and_backward_follows():
+    """a host seed is baked into a captured hipGraph.  Inside `step_scope` the kernels mix in a device-side
+    step seed that a captured `add_` bumps on every replay: masks differ from replay to replay, and the backward of a
+    replay (captured too, as make_graphed_callables does) recomputes the mask of ITS forward."""
+    from vnext_amd.ops.fused_norm import step_scope
+    p = 0.25
+    drop, norm = _modules(p)
+    norm = norm.to(DEV)
+    with torch.no_grad():
+        norm.weight.fill_(1.0); norm.bias.zero_()
+    rows = 512
+    g = torch.Generator().manual_seed(5)
+    x = torch.zeros(rows, 256, device=DEV)
+    r = (torch.rand(rows, 256, generator=g) + 0.5).to(DEV)
+    go = torch.randn(rows, 256, generator=g).to(DEV)
+
+    class Site(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.drop, self.norm = drop, norm
+
+        def forward(self, xx, rr):
+            with step_scope(xx.device):
+                y = add_dropout_norm(xx, rr, self.drop, self.norm)
+            return y
+
+    site = Site().train()
+    xs, rs = x.clone().requires_grad_(True), r.clone().requires_grad_(True)
+    graphed = torch.cuda.make_graphed_callables(site, (xs, rs))
+    masks, gmasks = [], []
+    for _ in range(3):
+        xi, ri = x.clone().requires_grad_(True), r.clone().requires_grad_(True)
+        y = graphed(xi, ri)
+        y.backward(go)
+        torch.cuda.synchronize()
+        # x = 0: z = dropout(r), so y's row statistics depend on the mask; read the mask off grad_r instead:
+        # grad_r = keep * scale * dz with dz != 0 almost surely
+        gmasks.append((ri.grad != 0).clone())
+        # and off the forward: dropped elements have z = 0 -> y = (0 - mean) * rstd, identical within a row
+        masks.append(y.detach().clone())
+    for i in range(3):
+        rate = 1.0 - float(gmasks[i].float().mean())
+        assert abs(rate - p) < 0.02
+    assert not torch.equal(gmasks[0], gmasks[1]) and not torch.equal(gmasks[1], gmasks[2])
+    assert not torch.equal(masks[0], masks[1])
+    # forward and backward of one replay agree on the mask: a dropped element of row i has y == min-like constant
+    # c_i = -mean_i * rstd_i; recompute z's zero pattern from y and compare with the backward's pattern
+    for y, gm in zip(masks, gmasks):
+        kept = gm
+        z = torch.where(kept, r / (1 - p), torch.zeros_like(r))
+        want = torch.nn.functional.layer_norm(z, (256,))
+        torch.testing.assert_close(y, want, rtol=0, atol=3e-5)
+
+
+@pytest.mark.gpu
+def test_capture_without_a_step_scope_falls_back_to_the_graph_safe_expression():
+    p = 0.25
+    drop, norm = _modules(p)
+    norm = norm.to(DEV)
+    x = torch.zeros(256, 256, device=DEV)
+    r = torch.ones(256, 256, device=DEV)
+    out = torch.empty_like(x)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(2):
+            out.copy_(add_dropout_norm(x, r, drop, norm))
+    torch.cuda.current_stream().wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        y = add_dropout_norm(x, r, drop, norm)       # no step_scope: nn.Dropout's Philox offset advances per replay
+        assert y.grad_fn is None or "AddDropoutLayerNorm" not in type(y.grad_fn).__name__
+        out.copy_(y)
+    graph.replay(); torch.cuda.synchronize(); a = out.clone()
+    graph.replay(); torch.cuda.synchronize(); b = out.clone()
+    assert not torch.equal(a, b)

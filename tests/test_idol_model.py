@@ -90,7 +90,7 @@ def test_inference_output_format(cpu_stand_ins):
         assert len(track) == 3 and all(m is None or (tuple(m.shape) == (70, 100) and m.dtype == torch.bool) for m in track)
 
 
-def _associate_from_golden(g, v, device, tracker_cls=None):
+def _associate_from_golden(g, v, device, tracker_cls=None, capacity=None):
     model = build_model(get_idol_cfg(**{"MODEL.DEVICE": device, **TINY})).eval()
     logits = torch.from_numpy(g[f"v{v}.pred_logits"]).to(device)
     boxes = torch.from_numpy(g[f"v{v}.pred_boxes"]).to(device)
@@ -103,11 +103,18 @@ def _associate_from_golden(g, v, device, tracker_cls=None):
         per_frame.append({"indices": c.tolist(), "logits": logits[f, q], "boxes": boxes[f, q], "embeds": embeds[f, q],
                           "masks": masks[f, q]})
     oh, ow, ih, iw = (int(x) for x in g[f"v{v}.sizes"])
-    tracker = (tracker_cls or trk.IDOL_Tracker)(
-        init_score_thr=0.2, obj_score_thr=0.1, nms_thr_pre=0.5, nms_thr_post=0.05, addnew_score_thr=0.2,
-        memo_tracklet_frames=10, memo_momentum=0.8, long_match=True, frame_weight=True, temporal_weight=True,
-        memory_len=3)
-    res = model.associate(per_frame, tracker, (oh, ow), (ih, iw))
+    args = dict(init_score_thr=0.2, obj_score_thr=0.1, nms_thr_pre=0.5, nms_thr_post=0.05, addnew_score_thr=0.2,
+                memo_tracklet_frames=10, memo_momentum=0.8, long_match=True, frame_weight=True, temporal_weight=True,
+                memory_len=3)
+    if capacity is None:
+        tracker = (tracker_cls or trk.IDOL_Tracker)(**args)
+        res = model.associate(per_frame, tracker, (oh, ow), (ih, iw))
+    else:       # a device tracker with too few slots: the video is associated again by the host tracker
+        tracker = tracker_cls(capacity=capacity, **args)
+        with pytest.raises(RuntimeError, match="more simultaneous tracklets"):
+            model.associate(per_frame, tracker_cls(capacity=capacity, **args), (oh, ow), (ih, iw))
+        res = model.associate(per_frame, tracker, (oh, ow), (ih, iw), host_factory=lambda: trk.IDOL_Tracker(**args))
+        assert tracker.counters()[1] > 0
     np.testing.assert_array_equal(np.array(res["pred_labels"]), g[f"v{v}.labels"])
     np.testing.assert_allclose(np.array(res["pred_scores"]), g[f"v{v}.scores"], rtol=1e-5)
     present = g[f"v{v}.present"]
@@ -136,6 +143,15 @@ def test_video_postprocessing_equals_reference_on_gpu(v):
 def test_video_postprocessing_with_the_tracker_on_the_device(v):
     """The same fixtures through DeviceTracker: ids stay on the device, one copy per video (models/idol.py:associate)."""
     _associate_from_golden(dict(np.load(os.path.join(GOLDEN_DIR, "inference_idol.npz"))), v, "cuda:0", trk.DeviceTracker)
+
+
+@pytest.mark.gpu
+def test_a_video_that_outgrows_the_device_tracker_is_associated_again_on_the_host():
+    """slot overflow used to raise after the whole video and lose it."""
+    assert trk.DeviceTracker.supports(memory_len=3, max_dets=300) and not trk.DeviceTracker.supports(memory_len=17)
+    assert not trk.DeviceTracker.supports(memory_len=3, max_dets=513)
+    _associate_from_golden(dict(np.load(os.path.join(GOLDEN_DIR, "inference_idol.npz"))), 0, "cuda:0", trk.DeviceTracker,
+                           capacity=1)
 
 
 @pytest.mark.gpu

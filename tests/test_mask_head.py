@@ -78,7 +78,7 @@ def test_kernel_matches_reference_outputs(name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("H_,W_,n", [(48, 80, 300), (92, 160, 37), (1, 130, 3), (17, 1, 2)])
+@pytest.mark.parametrize("H_,W_,n", [(48, 80, 300), (92, 160, 37), (1, 130, 3), (17, 1, 2), (33, 47, 5), (7, 95, 4), (5, 31, 3), (6, 64, 3)])
 def test_kernel_at_frame_sizes(H_, W_, n):
     """360p / 720p frame sizes (BASELINE configs): a sample of instances against the oracle,
     and linearity in the last layer's bias (adds a constant to every logit)."""

@@ -33,6 +33,19 @@ __device__ __forceinline__ uint32_t an_hash(uint32_t idx, uint32_t seed_lo, uint
   return h;
 }
 
+// Effective seed of a launch: the host's 64 bits, mixed with a 64-bit word read from DEVICE memory when the caller
+// passes one.  A host integer is baked into a captured hipGraph -- every replay of a captured training step would drop
+// the same elements -- whereas a device word bumped once per step (by a captured `add_`) gives every replay
+// fresh masks; forward and backward of one step read the same word, so the backward still recomputes the mask.
+__device__ __forceinline__ void an_effective_seed(uint32_t& lo, uint32_t& hi, const unsigned long long* seed_device) {
+  if (seed_device == nullptr) return;
+  const unsigned long long s = *seed_device;                       // wave-uniform (scalar load)
+  uint32_t a = uint32_t(s) * 0x9E3779B1u, b = (uint32_t(s >> 32) + 0x7F4A7C15u) * 0x85EBCA77u;
+  a ^= a >> 15; b ^= b >> 13;
+  lo ^= a * 0xC2B2AE3Du;
+  hi ^= b * 0x27D4EB2Fu + a;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -58,10 +71,11 @@ add_dropout_layernorm_fwd_kernel(const float* __restrict__ x, const float* __res
                                  const float* __restrict__ gamma, const float* __restrict__ beta,
                                  float* __restrict__ y, float* __restrict__ z_out, float* __restrict__ stats,
                                  int64_t rows, uint32_t threshold, float scale, float eps, uint32_t seed_lo,
-                                 uint32_t seed_hi) {
+                                 uint32_t seed_hi, const unsigned long long* __restrict__ seed_device) {
   const int lane = threadIdx.x & 63;
   const int64_t row = int64_t(blockIdx.x) * kAnWaves + (threadIdx.x >> 6);
   if (row >= rows) return;
+  if (threshold != 0u) an_effective_seed(seed_lo, seed_hi, seed_device);
   const int64_t at = row * kAnC + lane * 4;
   const float4_t xv = *reinterpret_cast<const float4_t*>(x + at);
   const float4_t rv = *reinterpret_cast<const float4_t*>(r + at);
@@ -82,8 +96,10 @@ __global__ void __launch_bounds__(64 * kAnWaves)
 add_dropout_layernorm_bwd_kernel(const float* __restrict__ grad_y, const float* __restrict__ z,
                                  const float* __restrict__ stats, const float* __restrict__ gamma,
                                  float* __restrict__ grad_x, float* __restrict__ grad_r, float* __restrict__ partial,
-                                 int64_t rows, uint32_t threshold, float scale, uint32_t seed_lo, uint32_t seed_hi) {
+                                 int64_t rows, uint32_t threshold, float scale, uint32_t seed_lo, uint32_t seed_hi,
+                                 const unsigned long long* __restrict__ seed_device) {
   __shared__ float4_t red[2][kAnWaves][64];
+  if (threshold != 0u) an_effective_seed(seed_lo, seed_hi, seed_device);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float4_t g = *reinterpret_cast<const float4_t*>(gamma + lane * 4);
   float4_t dg = {0.f, 0.f, 0.f, 0.f}, db = dg;
@@ -168,7 +184,7 @@ extern "C" size_t vnx_add_dropout_layernorm_partial_bytes(void) { return size_t(
 extern "C" int vnx_add_dropout_layernorm_forward(int dtype, const void* x, const void* r, const void* gamma,
                                                  const void* beta, void* y, void* z, void* stats, long long rows,
                                                  int channels, float p, float eps, unsigned long long seed,
-                                                 void* hip_stream) {
+                                                 const unsigned long long* seed_device, void* hip_stream) {
   if (int st = an_check("vnx_add_dropout_layernorm_forward", dtype, rows, channels, p)) return st;
   if (rows == 0) return VNX_OK;
   if (!x || !r || !gamma || !beta || !y || !z || !stats) {
@@ -179,14 +195,15 @@ extern "C" int vnx_add_dropout_layernorm_forward(int dtype, const void* x, const
   hipLaunchKernelGGL(add_dropout_layernorm_fwd_kernel, dim3(uint32_t(blocks)), dim3(64 * kAnWaves), 0,
                      (hipStream_t)hip_stream, (const float*)x, (const float*)r, (const float*)gamma, (const float*)beta,
                      (float*)y, (float*)z, (float*)stats, int64_t(rows), an_threshold(p), 1.f / (1.f - p), eps,
-                     uint32_t(seed), uint32_t(seed >> 32));
+                     uint32_t(seed), uint32_t(seed >> 32), seed_device);
   return check_launch("add_dropout_layernorm_fwd");
 }
 
 extern "C" int vnx_add_dropout_layernorm_backward(int dtype, const void* grad_y, const void* z, const void* stats,
                                                   const void* gamma, void* grad_x, void* grad_r, void* grad_gamma,
                                                   void* grad_beta, void* partial, long long rows, int channels, float p,
-                                                  unsigned long long seed, void* hip_stream) {
+                                                  unsigned long long seed, const unsigned long long* seed_device,
+                                                  void* hip_stream) {
   if (int st = an_check("vnx_add_dropout_layernorm_backward", dtype, rows, channels, p)) return st;
   if (!grad_gamma || !grad_beta || !partial) {
     set_error("vnx_add_dropout_layernorm_backward: null pointer argument");
@@ -202,7 +219,7 @@ extern "C" int vnx_add_dropout_layernorm_backward(int dtype, const void* grad_y,
     hipLaunchKernelGGL(add_dropout_layernorm_bwd_kernel, dim3(uint32_t(blocks)), dim3(64 * kAnWaves), 0, stream,
                        (const float*)grad_y, (const float*)z, (const float*)stats, (const float*)gamma, (float*)grad_x,
                        (float*)grad_r, (float*)partial, int64_t(rows), an_threshold(p), 1.f / (1.f - p), uint32_t(seed),
-                       uint32_t(seed >> 32));
+                       uint32_t(seed >> 32), seed_device);
   } else {
     blocks = 0;
   }

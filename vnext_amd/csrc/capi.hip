@@ -4,8 +4,6 @@
 #include <stdarg.h>
 #include <stdio.h>
 
-#include <mutex>
-
 #include "vnx_common.h"
 #include "../../include/vnext_hip_debug.h"
 
@@ -39,9 +37,6 @@ int msda_backward_generic(int, int, const void*, const int64_t*, const int64_t*,
                           int only_if_not_packed, hipStream_t);
 int convert_f32_to(int, const void*, void*, int64_t, const int64_t*, const int64_t*, int, int,
                    hipStream_t);
-bool msda_d32_gv_supported(int vdt, int ldt, const MsdaDims& d);
-int msda_backward_gv_d32(int, int, const int64_t*, const int64_t*, const void*, const void*,
-                         const void*, void*, MsdaDims, int variant, hipStream_t);
 int zero_if_not_packed(const int64_t*, const int64_t*, int, int, void*, size_t, hipStream_t);
 bool msda_d32_fwd_supported(int vdt, int ldt, const MsdaDims& d);
 bool msda_tile_fwd_supported(int vdt, int ldt, const MsdaDims& d);
@@ -62,31 +57,6 @@ bool msda_d32_gvrec_supported(int vdt, int ldt, const MsdaDims& d);
 size_t msda_gvrec_record_bytes(const MsdaDims& d);
 int msda_backward_gvrec_d32(int vdt, const int64_t*, const int64_t*, const void* records, const void*,
                             void*, MsdaDims, int variant, hipStream_t);
-
-// One non-blocking side stream + fork/join events per device, created on first use and kept
-// for the life of the process (the backward forks its two independent kernels onto it).
-struct SideStream {
-  hipStream_t stream = nullptr;
-  hipEvent_t fork = nullptr, join = nullptr;
-  bool ok = false, tried = false;
-};
-
-static SideStream* side_stream_for_current_device() {
-  static SideStream table[64];
-  static std::mutex mu;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-  std::lock_guard<std::mutex> lock(mu);
-  SideStream& s = table[dev];
-  if (!s.tried) {
-    s.tried = true;
-    s.ok = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) == hipSuccess &&
-           hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) == hipSuccess &&
-           hipEventCreateWithFlags(&s.join, hipEventDisableTiming) == hipSuccess;
-    if (!s.ok) (void)hipGetLastError();
-  }
-  return s.ok ? &s : nullptr;
-}
 
 static int check_common(const char* fn, int vdt, int ldt, const void* value,
                         const int64_t* shapes, const int64_t* lsi, const void* loc,
@@ -246,16 +216,12 @@ int vnx_msda_forward(int value_dtype, int loc_dtype, const void* value,
 
 static bool bwd_fast_path(int vdt, int ldt, const MsdaDims& d, int variant) {
   return variant != 1 && !(variant >= 300 && variant < 400) &&
-         msda_d32_bwd_supported(vdt, ldt, d) && msda_d32_gv_supported(vdt, ldt, d);
+         msda_d32_bwd_supported(vdt, ldt, d) && msda_d32_gvrec_supported(vdt, ldt, d);
 }
 
 // Workspace layout of the backward: [sample records (fast path, 256-B aligned size) | fp32
 // grad_value image (16-bit values whenever the general path may run)].
 static size_t align256(size_t n) { return (n + 255) & ~size_t(255); }
-
-static bool use_records(int vdt, int ldt, const MsdaDims& d, int variant) {
-  return variant != 600 && msda_d32_gvrec_supported(vdt, ldt, d);
-}
 
 size_t vnx_msda_backward_workspace_bytes(int value_dtype, int loc_dtype, int batch,
                                          int spatial_size, int num_heads, int channels,
@@ -265,7 +231,7 @@ size_t vnx_msda_backward_workspace_bytes(int value_dtype, int loc_dtype, int bat
   const bool sixteen = (value_dtype == VNX_BF16 || value_dtype == VNX_F16);
   const size_t image = sixteen ? sizeof(float) * size_t(batch) * size_t(spatial_size) * size_t(num_heads) * size_t(channels) : 0;
   if (!bwd_fast_path(value_dtype, loc_dtype, d, variant)) return image;
-  const size_t records = use_records(value_dtype, loc_dtype, d, variant) ? align256(msda_gvrec_record_bytes(d)) : 0;
+  const size_t records = align256(msda_gvrec_record_bytes(d));
   // packed levels promised: the general path never runs, no fp32 image
   return records + ((flags & VNX_MSDA_LEVELS_PACKED) ? 0 : image);
 }
@@ -315,54 +281,29 @@ int vnx_msda_backward(int value_dtype, int loc_dtype, const void* value,
   if (bwd_fast_path(value_dtype, loc_dtype, d, variant)) {
     // (1) grad_loc / grad_attn: per-query gather kernel, no atomics; it also leaves one 16-B
     //     geometry record per sample in the workspace.
-    // (2) grad_value: owner-computes slabs fed by those records; does nothing on the device
+    // (2) grad_value: owner-computes units fed by those records; does nothing on the device
     //     unless the levels are packed.
     // (3) unless the caller promised packed levels: the general path, each kernel of which
     //     does nothing on the device when the levels ARE packed.  No host sync either way.
-    const bool with_rec = use_records(value_dtype, loc_dtype, d, variant);
-    const size_t rec_bytes = with_rec ? align256(msda_gvrec_record_bytes(d)) : 0;
-    void* records = with_rec ? workspace : nullptr;
+    // (The record-less predecessor of (2) -- every unit re-deriving its level's geometry -- and the side
+    //  stream that overlapped it with (1) are archived under tools/experiments/msda_d32_gv.hip.)
+    const size_t rec_bytes = align256(msda_gvrec_record_bytes(d));
+    void* records = workspace;
     void* image = (sixteen && !(flags & VNX_MSDA_LEVELS_PACKED)) ? (void*)((char*)workspace + rec_bytes) : nullptr;
     const bool only_gl = variant >= 100 && variant < 200;  // timing ablations
     const bool only_gv = variant >= 400 && variant < 500;
-    // The two kernels of the no-record form share inputs only and CAN be forked onto a side
-    // stream (variant 501).  Measured on MI355X the fork/join costs more than the overlap
-    // returns (52 vs 48 us per backward at the T=5 decoder shape), so it is off.
-    SideStream* side = (variant == 501 && !with_rec) ? side_stream_for_current_device() : nullptr;
-    hipStream_t gv_stream = stream;
-    if (side) {
-      if (hipEventRecord(side->fork, stream) == hipSuccess &&
-          hipStreamWaitEvent(side->stream, side->fork, 0) == hipSuccess)
-        gv_stream = side->stream;
-      else
-        (void)hipGetLastError();  // fall back to one stream
-    }
-    if (!only_gv || with_rec) {
-      // records mode: the accumulation-image argument carries fp32 grad_value itself, whose rows of the
-      // query-split levels the kernel zeroes (gv_query_splits)
-      st = msda_backward_d32(value_dtype, loc_dtype, value, spatial_shapes, level_start_index,
-                             sampling_loc, attn_weight, grad_output,
-                             (with_rec && value_dtype == VNX_F32) ? grad_value : nullptr, grad_sampling_loc,
-                             grad_attn_weight, d, only_gl ? variant : 100 + (variant < 100 ? variant : 0),
-                             records, stream);
-      if (st != VNX_OK) return st;
-    }
+    // records mode: the accumulation-image argument carries fp32 grad_value itself, whose rows of the
+    // query-split levels the kernel zeroes (gv_query_splits)
+    st = msda_backward_d32(value_dtype, loc_dtype, value, spatial_shapes, level_start_index,
+                           sampling_loc, attn_weight, grad_output,
+                           value_dtype == VNX_F32 ? grad_value : nullptr, grad_sampling_loc,
+                           grad_attn_weight, d, only_gl ? variant : 100 + (variant < 100 ? variant : 0),
+                           records, stream);
+    if (st != VNX_OK) return st;
     if (!only_gl) {
-      if (with_rec)
-        st = msda_backward_gvrec_d32(value_dtype, spatial_shapes, level_start_index, records, grad_output,
-                                     grad_value, d, variant, stream);
-      else
-        st = msda_backward_gv_d32(value_dtype, loc_dtype, spatial_shapes, level_start_index,
-                                  sampling_loc, attn_weight, grad_output, grad_value, d, variant, gv_stream);
+      st = msda_backward_gvrec_d32(value_dtype, spatial_shapes, level_start_index, records, grad_output,
+                                   grad_value, d, variant, stream);
       if (st != VNX_OK) return st;
-    }
-    if (gv_stream != stream) {
-      if (hipEventRecord(side->join, gv_stream) != hipSuccess ||
-          hipStreamWaitEvent(stream, side->join, 0) != hipSuccess) {
-        set_error("vnx_msda_backward: joining the side stream failed: %s",
-                  hipGetErrorString(hipGetLastError()));
-        return VNX_ERR_LAUNCH;
-      }
     }
     if (!(flags & VNX_MSDA_LEVELS_PACKED) && !only_gl && !only_gv) {
       void* gv_acc = sixteen ? image : grad_value;

@@ -105,9 +105,8 @@ __device__ __forceinline__ int small_div(int a, int b) {
   if (r >= b) ++q;
   return q;
 }
-// rows per unit of the grad_value kernels for a level of n pixels: the split of
-// msda_d32_gvrec.hip's level table (kGvRowsMax rows per unit at most, units_min units at least)
-constexpr int kGvRowsMax = 320;
+// rows per unit of the grad_value kernels for a level of n pixels = gv_level_split(n, units_min).rpu
+// (vnx_common.h), here without the integer-division sequence (one lane per sample evaluates it)
 __device__ __forceinline__ int gv_rows_per_unit(int n, int units_min) {
   int units = (n + kGvRowsMax - 1) / kGvRowsMax;
   if (units < units_min) units = units_min;
@@ -661,9 +660,7 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
       const int t_in_b = tile - b * tiles_per_batch;
       for (int l = 0; l < d.L; ++l) {
         const int n = int(shapes[2 * l]) * int(shapes[2 * l + 1]);
-        int units = (n + kGvRowsMax - 1) / kGvRowsMax;
-        if (units < units_min) units = units_min;
-        if (gv_query_splits(units, d.Lq, d.P, true, d.B * d.M) > 1) {
+        if (gv_query_splits(gv_level_split(n, units_min).units, d.Lq, d.P, true, d.B * d.M) > 1) {
           float* rows = fa.qsplit_zero + ((int64_t(b) * d.S + int(lsi[l])) * d.M + m) * D;
           for (int r = (t_in_b * WPB + wave) * 8 + (lane >> 3); r < n; r += tiles_per_batch * WPB * 8)
             *reinterpret_cast<float4_t*>(rows + int64_t(r) * d.M * D + (lane & 7) * 4) = float4_t{0.f, 0.f, 0.f, 0.f};

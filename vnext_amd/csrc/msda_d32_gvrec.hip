@@ -89,7 +89,7 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
 constexpr int kWaves = 8;                   // 512 threads, one sample per thread per chunk
 constexpr int kThreads = 64 * kWaves;
 constexpr int kGroups = kThreads / 8;       // 8-lane groups
-constexpr int kRowsMax = 320;               // 40 KiB slab
+constexpr int kRowsMax = kGvRowsMax;        // 320 rows: 40 KiB as an LDS slab
 constexpr int kQcMax = 128;                 // queries per chunk (16 KiB of grad_out rows in LDS)
 constexpr int kLevelsMax = 64;
 // slab 40 K + grad_out rows 16 K + tap list 16 K + 3 x 320 counters/offsets + allocator + level
@@ -159,14 +159,8 @@ msda_bwd_gv_rec_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
   if (tid < d.L) {
     const int H = int(shapes[2 * tid]), W = int(shapes[2 * tid + 1]);
     const int n = H * W;
-    int units = 0, rpu = 1;
-    if (n > 0) {
-      units = (n + kRowsMax - 1) / kRowsMax;
-      if (units < units_min) units = units_min;
-      if (units > n) units = n;
-      rpu = (n + units - 1) / units;
-      units = (n + rpu - 1) / rpu;
-    }
+    const GvSplit sp = gv_level_split(n, units_min);
+    const int units = sp.units, rpu = sp.rpu;
     meta[4 * tid] = H; meta[4 * tid + 1] = W; meta[4 * tid + 2] = int(lsi[tid]);
     meta[4 * tid + 3] = units | (rpu << 12);
   }
@@ -442,14 +436,8 @@ msda_bwd_gv_sel_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
   if (tid < d.L) {
     const int H = int(shapes[2 * tid]), W = int(shapes[2 * tid + 1]);
     const int n = H * W;
-    int units = 0, rpu = 1;
-    if (n > 0) {
-      units = (n + kRowsMax - 1) / kRowsMax;
-      if (units < units_min) units = units_min;
-      if (units > n) units = n;
-      rpu = (n + units - 1) / units;
-      units = (n + rpu - 1) / rpu;
-    }
+    const GvSplit sp = gv_level_split(n, units_min);
+    const int units = sp.units, rpu = sp.rpu;
     const int qs = gv_query_splits(units, d.Lq, P, sizeof(TV) == 4, d.B * d.M);
     meta[4 * tid] = H; meta[4 * tid + 1] = W; meta[4 * tid + 2] = int(lsi[tid]);
     meta[4 * tid + 3] = units | (rpu << 12) | (qs << 24);     // units <= 4000, rpu <= 320, qs <= 8

@@ -254,4 +254,28 @@ int convert_f32_to(int vdt, const void* src, void* dst, int64_t n, const int64_t
   return VNX_ERR_INVALID_ARGUMENT;
 }
 
+// ---- helper of the general (not packed) path: zero-fill that runs only when the levels are NOT packed ----
+typedef float zero_f4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256)
+zero_if_not_packed_kernel(const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi, int L,
+                          int S, zero_f4* __restrict__ dst, int64_t n16, unsigned char* tail,
+                          int tail_bytes) {
+  if (levels_packed(shapes, lsi, L, S)) return;
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n16;
+       i += int64_t(gridDim.x) * blockDim.x)
+    dst[i] = zero_f4{0.f, 0.f, 0.f, 0.f};
+  if (blockIdx.x == 0 && int(threadIdx.x) < tail_bytes) tail[threadIdx.x] = 0;
+}
+
+int zero_if_not_packed(const int64_t* shapes, const int64_t* lsi, int L, int S, void* dst,
+                       size_t bytes, hipStream_t stream) {
+  const int64_t n16 = int64_t(bytes / 16);
+  int64_t blocks = (n16 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(zero_if_not_packed_kernel, dim3(uint32_t(blocks)), dim3(256), 0, stream, shapes,
+                     lsi, L, S, (zero_f4*)dst, n16, (unsigned char*)dst + n16 * 16, int(bytes % 16));
+  return check_launch("zero_if_not_packed");
+}
+
 }  // namespace vnx

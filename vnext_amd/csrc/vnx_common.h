@@ -136,6 +136,26 @@ struct FusedArgs {
 // batch_heads = B x M: with fewer than 32 (batch, head) pairs the grid leaves workgroup slots empty (25 units each
 // against 768 slots), and the middle levels are split further: 4 instead of 2 pieces -- encoder backward at B = 2:
 // 123 -> 109 us at 360p, 450 -> 412 us at 720p; at B = 5 (a full grid) 4 pieces measured 1-2 % slower than 2.
+// The unit split of a level of n pixels, the ONE definition shared by the grad_loc kernel (which zeroes the rows of
+// query-split levels and tags every sample with the units it touches), the grad_value kernels' level tables and the
+// launcher's grid bound: at most kGvRowsMax rows per unit, at least units_min units, then normalised so that no unit is
+// empty (units = ceil(n / rows_per_unit)).  (Round 2 had the zeroing phase use the count BEFORE normalisation: with
+// units_min = 5 a 16-pixel level gave 5 there and 4 in the grad_value kernel -- different sides of the query-split
+// threshold, atomics onto rows nobody had zeroed.  Latent at the default units_min = 2)
+constexpr int kGvRowsMax = 320;
+struct GvSplit { int units, rpu; };
+__host__ __device__ inline GvSplit gv_level_split(int n, int units_min) {
+  GvSplit s{0, 1};
+  if (n > 0) {
+    int units = (n + kGvRowsMax - 1) / kGvRowsMax;
+    if (units < units_min) units = units_min;
+    if (units > n) units = n;
+    s.rpu = (n + units - 1) / units;
+    s.units = (n + s.rpu - 1) / s.rpu;
+  }
+  return s;
+}
+
 __host__ __device__ inline int gv_query_splits(int row_units, int Lq, int P, bool f32, int batch_heads) {
   if (!f32 || P != 4 || row_units > 4 || Lq < 1024) return 1;
   const int chunks = (Lq + 127) / 128;

@@ -326,23 +326,30 @@ class IDOL(nn.Module):
         per_frame = []
         for s in range(0, len(video), self.batch_infer_len):
             per_frame.extend(self.inference_forward(video[s:s + self.batch_infer_len]))
-        make = DeviceTracker if self.device.type == "cuda" else IDOL_Tracker
-        tracker = make(init_score_thr=0.2, obj_score_thr=0.1, nms_thr_pre=self.nms_pre, nms_thr_post=0.05,
-                       addnew_score_thr=self.add_new_score, memo_tracklet_frames=10, memo_momentum=0.8,
-                       long_match=self.inference_tw, frame_weight=(self.inference_tw | self.inference_fw),
-                       temporal_weight=self.inference_tw, memory_len=self.memory_len)
+        args = dict(init_score_thr=0.2, obj_score_thr=0.1, nms_thr_pre=self.nms_pre, nms_thr_post=0.05,
+                    addnew_score_thr=self.add_new_score, memo_tracklet_frames=10, memo_momentum=0.8,
+                    long_match=self.inference_tw, frame_weight=(self.inference_tw | self.inference_fw),
+                    temporal_weight=self.inference_tw, memory_len=self.memory_len)
+        most = max((len(fr["indices"]) for fr in per_frame), default=0)
+        on_device = self.device.type == "cuda" and DeviceTracker.supports(memory_len=self.memory_len, max_dets=most)
+        tracker = (DeviceTracker if on_device else IDOL_Tracker)(**args)
         ih, iw = video[0].shape[-2:]
         oh, ow = batched_inputs[0].get("height", ih), batched_inputs[0].get("width", iw)
-        return self.associate(per_frame, tracker, (oh, ow), (ih, iw))
+        return self.associate(per_frame, tracker, (oh, ow), (ih, iw), host_factory=lambda: IDOL_Tracker(**args))
 
     @torch.no_grad()
-    def associate(self, per_frame, tracker, ori_size, image_size):
+    def associate(self, per_frame, tracker, ori_size, image_size, host_factory=None):
         """IDOL.inference (idol.py:313-471) on the pre-selected candidates of every frame.
 
         With a `DeviceTracker` the association of the whole video is enqueued without a host round trip:
         every frame leaves its ids in device memory, they are read ONCE after the last frame, and the
         per-track bookkeeping (which only needs the ids) runs on that copy.  With the host-side
-        `IDOL_Tracker` (CPU, differential tests) the ids arrive frame by frame, as in the reference."""
+        `IDOL_Tracker` (CPU, differential tests) the ids arrive frame by frame, as in the reference.
+
+        The device tracker has fixed limits (slots alive at a time, detections per frame, memory_len): a video that
+        outgrows its slots is associated AGAIN by `host_factory()` (the host-side tracker, no limits) instead of
+        being lost -- a tracklet that found no slot is never remembered, so the device ids up to that point may
+        already differ from the reference's and are discarded as a whole."""
         n_frames = len(per_frame)
         on_device = isinstance(tracker, DeviceTracker)
         probs, frame_ids = [], []
@@ -363,7 +370,9 @@ class IDOL(nn.Module):
             sizes = [len(x) for x in frame_ids]
             frame_ids = list(torch.cat(frame_ids).cpu().split(sizes))      # the one copy of the video
             if tracker.counters()[1]:
-                raise RuntimeError("DeviceTracker: more simultaneous tracklets than slots; raise `capacity`")
+                if host_factory is None:
+                    raise RuntimeError("DeviceTracker: more simultaneous tracklets than slots; raise `capacity`")
+                return self.associate(per_frame, host_factory(), ori_size, image_size)
         video = {}
         for t, (fr, ids) in enumerate(zip(per_frame, frame_ids)):
             for row, k in enumerate(ids.tolist()):

@@ -288,6 +288,11 @@ class _TrainTrunk(nn.Module):
         object.__setattr__(self, "_owner", owner)
 
     def forward(self, stack):
+        from ..ops.fused_norm import step_scope
+        with step_scope(stack.device):     # the fused dropout sites read a device-side step seed bumped HERE per replay
+            return self._forward(stack)
+
+    def _forward(self, stack):
         o = self._owner
         h, w = stack.shape[-2:]
         H, W = (h + 31) // 32 * 32, (w + 31) // 32 * 32

@@ -257,6 +257,15 @@ class DeviceTracker(object):
         self.cfg = None
         self.state = None
 
+    # limits of vnext_amd/csrc/tracker.hip (kTrkMaxDet, kTrkMaxMem, kTrkMaxCap)
+    MAX_DETS, MAX_MEMORY_LEN, MAX_CAPACITY = 512, 16, 2048
+
+    @classmethod
+    def supports(cls, memory_len=10, max_dets=0, capacity=1024):
+        """whether the device kernels take this configuration; callers fall back to `IDOL_Tracker` otherwise"""
+        return 1 <= int(memory_len) <= cls.MAX_MEMORY_LEN and int(max_dets) <= cls.MAX_DETS and \
+            1 <= int(capacity) <= cls.MAX_CAPACITY
+
     def _start(self, device, channels):
         import ctypes
         from .. import _lib

@@ -10,8 +10,15 @@ other widths) it IS the reference expression, evaluated by torch.
 Dropout: the kernel keeps element e iff hash(seed, e) >= p * 2^32 and the backward recomputes the mask from the same
 seed, so no mask is stored.  The seed of a call is `torch.initial_seed()` mixed with a per-process call counter: runs
 are repeatable after `torch.manual_seed`, masks differ from call to call, but they are not torch's Philox stream (a
-dropout mask has no reference value to be equal to).  A seed is a host integer: under hipGraph capture it is baked
-into the graph, so captured TRAINING replays repeat their masks (inference, p = 0, is unaffected).
+dropout mask has no reference value to be equal to).
+
+hipGraph capture: a host integer is baked into a captured graph, so replays of a captured TRAINING step
+would drop the same elements every step, where the `nn.Dropout` this replaces is graph-safe (its Philox offset advances
+per replay).  Under capture with p > 0 the kernels therefore also read a per-device STEP SEED from device memory
+(`seed_device` of the C ABI): `step_scope(device)` -- entered by the owner of the captured callable at the top of its
+forward, `_TrainTrunk.forward` here -- bumps that word with a captured `add_`, once per replay; the baked host seeds
+only tell the call sites apart.  The backward of the step reads the same word.  A capture that never entered a
+`step_scope` falls back to the reference expression `norm(x + dropout(r))` (three graph-safe ATen launches).
 """
 from __future__ import annotations
 
@@ -21,6 +28,38 @@ from .. import _lib
 
 CHANNELS = 256
 _calls = 0
+_step_seed = {}          # device -> int64[1] tensor, bumped once per training step inside step_scope()
+_scope_depth = 0
+
+
+def step_seed_tensor(device) -> torch.Tensor:
+    device = torch.device(device)
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    t = _step_seed.get(key)
+    if t is None:
+        t = _step_seed[key] = torch.full((1,), torch.initial_seed() & 0x7FFFFFFFFFFF, dtype=torch.int64, device=device)
+    return t
+
+
+class step_scope:
+    """`with step_scope(device): ...` around the part of a training step that may be captured into a hipGraph: bumps
+    the device's step seed (a captured op when capturing, so every replay bumps it again) and marks the fused
+    dropout sites inside as safe to fuse under capture."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+
+    def __enter__(self):
+        global _scope_depth
+        if self.device.type == "cuda":
+            step_seed_tensor(self.device).add_(0x9E3779B97F4A7C15 & 0x7FFFFFFFFFFF)
+        _scope_depth += 1
+        return self
+
+    def __exit__(self, *exc):
+        global _scope_depth
+        _scope_depth -= 1
+        return False
 
 
 def _next_seed() -> int:
@@ -31,7 +70,7 @@ def _next_seed() -> int:
 
 class _AddDropoutLayerNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, r, gamma, beta, p, eps, seed):
+    def forward(ctx, x, r, gamma, beta, p, eps, seed, seed_tensor):
         lib = _lib.lib()
         x, r = x.contiguous(), r.contiguous()
         rows = x.numel() // CHANNELS
@@ -40,9 +79,10 @@ class _AddDropoutLayerNorm(torch.autograd.Function):
         with torch.cuda.device(x.device):
             _lib.check(lib.vnx_add_dropout_layernorm_forward(
                 _lib.VNX_F32, x.data_ptr(), r.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), z.data_ptr(),
-                stats.data_ptr(), rows, CHANNELS, float(p), float(eps), int(seed), _lib.current_stream(x)))
+                stats.data_ptr(), rows, CHANNELS, float(p), float(eps), int(seed),
+                seed_tensor.data_ptr() if seed_tensor is not None else None, _lib.current_stream(x)))
         ctx.save_for_backward(z, stats, gamma)
-        ctx.p, ctx.seed = float(p), int(seed)
+        ctx.p, ctx.seed, ctx.seed_tensor = float(p), int(seed), seed_tensor
         return y
 
     @staticmethod
@@ -59,8 +99,9 @@ class _AddDropoutLayerNorm(torch.autograd.Function):
             _lib.check(lib.vnx_add_dropout_layernorm_backward(
                 _lib.VNX_F32, grad_y.data_ptr(), z.data_ptr(), stats.data_ptr(), gamma.data_ptr(), grad_x.data_ptr(),
                 grad_r.data_ptr(), grad_gamma.data_ptr(), grad_beta.data_ptr(), partial.data_ptr(), rows, CHANNELS,
-                ctx.p, ctx.seed, _lib.current_stream(z)))
-        return grad_x, grad_r, grad_gamma, grad_beta, None, None, None
+                ctx.p, ctx.seed, ctx.seed_tensor.data_ptr() if ctx.seed_tensor is not None else None,
+                _lib.current_stream(z)))
+        return grad_x, grad_r, grad_gamma, grad_beta, None, None, None, None
 
 
 def fused_applies(x, r, norm) -> bool:
@@ -77,4 +118,10 @@ def add_dropout_norm(x, r, dropout, norm, seed=None):
     p = dropout.p if dropout.training else 0.0
     if p >= 1.0:
         return norm(x + dropout(r))
-    return _AddDropoutLayerNorm.apply(x, r, norm.weight, norm.bias, p, norm.eps, _next_seed() if seed is None else seed)
+    seed_tensor = None
+    if p > 0.0 and torch.cuda.is_current_stream_capturing():
+        if _scope_depth == 0:                    # nobody bumps a step seed in this capture: stay graph-safe
+            return norm(x + dropout(r))
+        seed_tensor = step_seed_tensor(x.device)
+    return _AddDropoutLayerNorm.apply(x, r, norm.weight, norm.bias, p, norm.eps, _next_seed() if seed is None else seed,
+                                      seed_tensor)
