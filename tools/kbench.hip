@@ -249,7 +249,22 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&dshapes, sizeof hshapes)); CK(hipMalloc(&dlsi, sizeof hlsi));
   CK(hipMemcpy(dshapes, hshapes, sizeof hshapes, hipMemcpyHostToDevice));
   CK(hipMemcpy(dlsi, hlsi, sizeof hlsi, hipMemcpyHostToDevice));
-  const size_t ws_bytes = vnx_msda_backward_workspace_bytes(VNX_F32, VNX_F32, B, S, M, D, L, Lq, P, VNX_MSDA_LEVELS_PACKED);
+  size_t ws_bytes = 0;     // the largest workspace any of the variants asks for (records vs tile words)
+  {
+    size_t pos0 = 0;
+    while (pos0 < variants.size()) {
+      size_t c = variants.find(',', pos0);
+      if (c == std::string::npos) c = variants.size();
+      vnx_set_kernel_variant(atoi(variants.substr(pos0, c - pos0).c_str()));
+      ws_bytes = std::max(ws_bytes, vnx_msda_backward_workspace_bytes(VNX_F32, VNX_F32, B, S, M, D, L, Lq, P, VNX_MSDA_LEVELS_PACKED));
+      pos0 = c + 1;
+    }
+    for (int v : {0, 1, 412}) {
+      vnx_set_kernel_variant(v);
+      ws_bytes = std::max(ws_bytes, vnx_msda_backward_workspace_bytes(VNX_F32, VNX_F32, B, S, M, D, L, Lq, P, VNX_MSDA_LEVELS_PACKED));
+    }
+    vnx_set_kernel_variant(0);
+  }
   std::vector<Set> sets(nsets);
   for (int i = 0; i < nsets; ++i) {
     Set& s = sets[i];

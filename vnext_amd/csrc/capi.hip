@@ -47,7 +47,13 @@ int msda_forward_d32(int, int, const void*, const int64_t*, const int64_t*, cons
                      const void*, void*, MsdaDims, int variant, hipStream_t);
 int msda_backward_d32(int, int, const void*, const int64_t*, const int64_t*, const void*,
                       const void*, const void*, void*, void*, void*, MsdaDims, int variant,
-                      void* records, hipStream_t);
+                      void* records, void* tile_summary, hipStream_t);
+int msda_bwd_tile_queries(const MsdaDims& d, int variant);
+bool msda_d32_gvtiles_supported(int vdt, int ldt, const MsdaDims& d);
+size_t msda_gvtiles_summary_bytes(const MsdaDims& d, int tile_queries);
+int msda_backward_gvtiles_d32(int vdt, int ldt, const int64_t*, const int64_t*, const void* loc, const void* attn,
+                              const void* summaries, const void* grad_out, void* grad_value, MsdaDims,
+                              int tile_queries, hipStream_t);
 bool msda_d32_fused_supported(int vdt, int ldt, const MsdaDims& d);
 int msda_fused_d32(bool backward, int vdt, int ldt, const void* value, const int64_t* shapes, const int64_t* lsi,
                    const void* raw_off, const void* raw_logit, const void* grad_out, void* out_or_grad_off,
@@ -219,9 +225,23 @@ static bool bwd_fast_path(int vdt, int ldt, const MsdaDims& d, int variant) {
          msda_d32_bwd_supported(vdt, ldt, d) && msda_d32_gvrec_supported(vdt, ldt, d);
 }
 
-// Workspace layout of the backward: [sample records (fast path, 256-B aligned size) | fp32
+// Workspace layout of the backward: [sample records or tile words (fast path, 256-B aligned size) | fp32
 // grad_value image (16-bit values whenever the general path may run)].
 static size_t align256(size_t n) { return (n + 255) & ~size_t(255); }
+
+// Which grad_value path a fast-path call takes: per-sample records + per-unit selection (msda_d32_gvrec.hip: calls
+// with few, scattered queries -- the decoders') or per-tile words (msda_d32_gvtiles.hip: from 1 024 queries up -- the
+// encoders').  Measured on MI355X, T = 5 encoder calls, model-like locations, cold: see DESIGN.md section 3.3b.
+// Variants 430 / 431 force records / tiles for A/B runs; the variants that name a record-fed kernel keep it.
+static bool use_tiles(int vdt, int ldt, const MsdaDims& d, int variant) {
+  if (variant == 430 || variant == 408 || variant == 412 || variant == 420 || variant == 425) return false;
+  if (d.P != 4 || d.L * d.P != 16 || !msda_d32_gvtiles_supported(vdt, ldt, d)) return false;
+  return variant == 431 || d.Lq >= 1024;
+}
+static size_t fast_path_scratch_bytes(int vdt, int ldt, const MsdaDims& d, int variant) {
+  if (use_tiles(vdt, ldt, d, variant)) return align256(msda_gvtiles_summary_bytes(d, msda_bwd_tile_queries(d, variant)));
+  return align256(msda_gvrec_record_bytes(d));
+}
 
 size_t vnx_msda_backward_workspace_bytes(int value_dtype, int loc_dtype, int batch,
                                          int spatial_size, int num_heads, int channels,
@@ -231,7 +251,7 @@ size_t vnx_msda_backward_workspace_bytes(int value_dtype, int loc_dtype, int bat
   const bool sixteen = (value_dtype == VNX_BF16 || value_dtype == VNX_F16);
   const size_t image = sixteen ? sizeof(float) * size_t(batch) * size_t(spatial_size) * size_t(num_heads) * size_t(channels) : 0;
   if (!bwd_fast_path(value_dtype, loc_dtype, d, variant)) return image;
-  const size_t records = align256(msda_gvrec_record_bytes(d));
+  const size_t records = fast_path_scratch_bytes(value_dtype, loc_dtype, d, variant);
   // packed levels promised: the general path never runs, no fp32 image
   return records + ((flags & VNX_MSDA_LEVELS_PACKED) ? 0 : image);
 }
@@ -287,22 +307,29 @@ int vnx_msda_backward(int value_dtype, int loc_dtype, const void* value,
     //     does nothing on the device when the levels ARE packed.  No host sync either way.
     // (The record-less predecessor of (2) -- every unit re-deriving its level's geometry -- and the side
     //  stream that overlapped it with (1) are archived under tools/experiments/msda_d32_gv.hip.)
-    const size_t rec_bytes = align256(msda_gvrec_record_bytes(d));
-    void* records = workspace;
+    const bool tiles = use_tiles(value_dtype, loc_dtype, d, variant);
+    const size_t rec_bytes = fast_path_scratch_bytes(value_dtype, loc_dtype, d, variant);
+    void* records = tiles ? nullptr : workspace;
+    void* tile_words = tiles ? workspace : nullptr;
     void* image = (sixteen && !(flags & VNX_MSDA_LEVELS_PACKED)) ? (void*)((char*)workspace + rec_bytes) : nullptr;
     const bool only_gl = variant >= 100 && variant < 200;  // timing ablations
-    const bool only_gv = variant >= 400 && variant < 500;
-    // records mode: the accumulation-image argument carries fp32 grad_value itself, whose rows of the
+    const bool only_gv = (variant >= 400 && variant < 430) || (variant > 431 && variant < 500);
+    // records / tile mode: the accumulation-image argument carries fp32 grad_value itself, whose rows of the
     // query-split levels the kernel zeroes (gv_query_splits)
     st = msda_backward_d32(value_dtype, loc_dtype, value, spatial_shapes, level_start_index,
                            sampling_loc, attn_weight, grad_output,
                            value_dtype == VNX_F32 ? grad_value : nullptr, grad_sampling_loc,
                            grad_attn_weight, d, only_gl ? variant : 100 + (variant < 100 ? variant : 0),
-                           records, stream);
+                           records, tile_words, stream);
     if (st != VNX_OK) return st;
     if (!only_gl) {
-      st = msda_backward_gvrec_d32(value_dtype, spatial_shapes, level_start_index, records, grad_output,
-                                   grad_value, d, variant, stream);
+      if (tiles)
+        st = msda_backward_gvtiles_d32(value_dtype, loc_dtype, spatial_shapes, level_start_index, sampling_loc,
+                                       attn_weight, tile_words, grad_output, grad_value, d,
+                                       msda_bwd_tile_queries(d, variant), stream);
+      else
+        st = msda_backward_gvrec_d32(value_dtype, spatial_shapes, level_start_index, records, grad_output,
+                                     grad_value, d, variant, stream);
       if (st != VNX_OK) return st;
     }
     if (!(flags & VNX_MSDA_LEVELS_PACKED) && !only_gl && !only_gv) {
@@ -335,7 +362,7 @@ int vnx_msda_backward(int value_dtype, int loc_dtype, const void* value,
   if (variant >= 300 && variant < 400 && msda_d32_bwd_supported(value_dtype, loc_dtype, d))
     st = msda_backward_d32(value_dtype, loc_dtype, value, spatial_shapes, level_start_index,
                            sampling_loc, attn_weight, grad_output, gv_acc, grad_sampling_loc,
-                           grad_attn_weight, d, variant - 300, nullptr, stream);
+                           grad_attn_weight, d, variant - 300, nullptr, nullptr, stream);
   else
     st = msda_backward_generic(value_dtype, loc_dtype, value, spatial_shapes, level_start_index,
                                sampling_loc, attn_weight, grad_output, gv_acc, grad_sampling_loc,

@@ -105,6 +105,10 @@ __device__ __forceinline__ int small_div(int a, int b) {
   if (r >= b) ++q;
   return q;
 }
+typedef unsigned short ushort2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {     // v_pk_min_u16
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(ushort2_t, a), __builtin_bit_cast(ushort2_t, b)));
+}
 // rows per unit of the grad_value kernels for a level of n pixels = gv_level_split(n, units_min).rpu
 // (vnx_common.h), here without the integer-division sequence (one lane per sample evaluates it)
 __device__ __forceinline__ int gv_rows_per_unit(int n, int units_min) {
@@ -628,7 +632,8 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
                     const TL* __restrict__ attn, const TV* __restrict__ grad_out,
                     float* __restrict__ gv, TL* __restrict__ grad_loc, TL* __restrict__ grad_attn,
                     MsdaDims d, int tiles_per_batch, uint4_t* __restrict__ sample_records,
-                    uint32_t* __restrict__ sample_units, int units_min, unsigned long long* stamps, FusedArgs fa) {
+                    uint32_t* __restrict__ sample_units, uint32_t* __restrict__ tile_summary, int units_min,
+                    unsigned long long* stamps, FusedArgs fa) {
   static_assert(!FUSED || (LP_T == 16 && !ATOMICS), "the fused prologue is built for L*P == 16, record-fed grad_value");
   stamp_begin(stamps);
   constexpr int D = 32;
@@ -656,7 +661,8 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
   // ---- phase 0: zero the grad_value rows of the query-split levels (gv_query_splits) of this (batch, head):
   //      the tiles of a batch element share the rows, eight rows per wave and step -----------------------
   if constexpr (!ATOMICS && sizeof(TV) == 4) {
-    if (fa.qsplit_zero != nullptr && sample_units != nullptr && d.Lq >= 1024 && levels_packed(shapes, lsi, d.L, d.S)) {
+    if (fa.qsplit_zero != nullptr && (sample_units != nullptr || tile_summary != nullptr) && d.Lq >= 1024 &&
+        levels_packed(shapes, lsi, d.L, d.S)) {
       const int t_in_b = tile - b * tiles_per_batch;
       for (int l = 0; l < d.L; ++l) {
         const int n = int(shapes[2 * l]) * int(shapes[2 * l + 1]);
@@ -672,6 +678,10 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
   // ---- phase 1 ------------------------------------------------------------------
   const int pairs = QPW * LP;
   int keep_H = 1, keep_W = 1;      // level size of this lane's sample: reused by phase 3 when pairs <= 64
+  // tile mode of the grad_value path (msda_d32_gvtiles.hip; L*P == 16, P == 4): instead of a record and a unit range per
+  // SAMPLE, this workgroup leaves per level ONE word: the range of grad_value units the corners of its queries' samples
+  // touch, as  unit_lo | (0xffff - unit_hi) << 16  -- the form a packed 16-bit minimum reduces; 0xffffffff = no taps
+  uint32_t tile_key = 0xffffffffu;
   for (int e = lane; e < pairs; e += 64) {
     const int qi = e / LP, p = e - qi * LP;
     const int q = q0 + qi;
@@ -711,6 +721,16 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
         g4.x = h - hf; g4.y = w - wf; g4.z = a;
         record = uint4_t{(uint32_t(h0 + 1) << 16) | uint32_t(w0 + 1), __float_as_uint(g4.x),
                          __float_as_uint(g4.y), __float_as_uint(a)};
+        if constexpr (LP_T == 16 && !ATOMICS) {
+          if (tile_summary != nullptr) {
+            const int p00 = h0 * W + w0;
+            const int lo = (top && lef) ? p00 : (top && rig) ? p00 + 1 : (bot && lef) ? p00 + W : p00 + W + 1;
+            const int hi = (bot && rig) ? p00 + W + 1 : (bot && lef) ? p00 + W : (top && rig) ? p00 + 1 : p00;
+            const int rpu = gv_rows_per_unit(H * W, units_min);
+            const uint32_t key = uint32_t(small_div(lo, rpu)) | ((0xffffu - uint32_t(small_div(hi, rpu))) << 16);
+            tile_key = pk_min_u16(tile_key, key);
+          }
+        }
       }
       // the geometry, kept for the grad_value kernel (msda_d32_gvrec.hip):
       // [batch][head][level][query*points], 16 B per sample -- plus, in 4 B, the range of that
@@ -738,8 +758,30 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
     s_off[qi * (LP + 1) + p] = o4;
     s_geo[qi * (LP + 1) + p] = g4;
   }
+  uint32_t* s_tile = reinterpret_cast<uint32_t*>(smem + size_t(WPB) * 3 * ent * 16);    // [WPB][4] (tile mode)
+  if constexpr (LP_T == 16 && !ATOMICS) {
+    if (tile_summary != nullptr) {       // uniform.  A lane's samples all have level (lane & 15) >> 2 (P == 4):
+      // minimum over the 4 points (quad) and over the wave's queries (lane bits 4, 5)
+      tile_key = pk_min_u16(tile_key, uint32_t(__builtin_amdgcn_update_dpp(int(tile_key), int(tile_key), 0xB1, 0xF, 0xF, true)));
+      tile_key = pk_min_u16(tile_key, uint32_t(__builtin_amdgcn_update_dpp(int(tile_key), int(tile_key), 0x4E, 0xF, 0xF, true)));
+      tile_key = pk_min_u16(tile_key, uint32_t(__shfl_xor(int(tile_key), 16, 64)));
+      tile_key = pk_min_u16(tile_key, uint32_t(__shfl_xor(int(tile_key), 32, 64)));
+      if ((lane & 3) == 0 && lane < 16) {
+        if (WPB > 1) s_tile[wave * 4 + (lane >> 2)] = tile_key;
+        else tile_summary[((int64_t(b) * d.M + m) * d.L + (lane >> 2)) * tiles_per_batch + (tile - b * tiles_per_batch)] = tile_key;
+      }
+    }
+  }
   if (WPB > 1) __syncthreads(); else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
+  if constexpr (LP_T == 16 && !ATOMICS && WPB > 1) {
+    if (tile_summary != nullptr && threadIdx.x < 4) {
+      uint32_t k = s_tile[threadIdx.x];
+#pragma unroll
+      for (int w2 = 1; w2 < WPB; ++w2) k = pk_min_u16(k, s_tile[w2 * 4 + threadIdx.x]);
+      tile_summary[((int64_t(b) * d.M + m) * d.L + int(threadIdx.x)) * tiles_per_batch + (tile - b * tiles_per_batch)] = k;
+    }
+  }
 
   // ---- phase 2 ------------------------------------------------------------------
   const int ch = lane & 7;
@@ -907,10 +949,14 @@ template <typename TV, typename TL, int QPW, int WPB>
 static int launch_bwd_cfg(const void* value, const int64_t* shapes, const int64_t* lsi,
                           const void* loc, const void* attn, const void* grad_out, void* gv,
                           void* grad_loc, void* grad_attn, const MsdaDims& d, bool atomics,
-                          void* records, hipStream_t stream) {
-  // records mode: `gv` is not an accumulation image but fp32 grad_value itself (or null), whose rows of the
+                          void* records, void* tile_summary, hipStream_t stream) {
+  // records / tile mode: `gv` is not an accumulation image but fp32 grad_value itself (or null), whose rows of the
   // query-split levels this kernel zeroes for the grad_value kernel's atomics
-  void* qsplit_zero = (!atomics && records != nullptr && sizeof(TV) == 4) ? gv : nullptr;
+  void* qsplit_zero = (!atomics && (records != nullptr || tile_summary != nullptr) && sizeof(TV) == 4) ? gv : nullptr;
+  if (tile_summary != nullptr && (d.L * d.P != 16 || d.P != 4 || atomics)) {
+    set_error("msda_backward: tile mode needs 4 levels x 4 points");
+    return VNX_ERR_UNSUPPORTED;
+  }
   const int LP = d.L * d.P;
   const int tiles_per_batch = (d.Lq + QPW * WPB - 1) / (QPW * WPB);
   const int64_t blocks = int64_t(d.B) * tiles_per_batch * d.M;
@@ -918,7 +964,7 @@ static int launch_bwd_cfg(const void* value, const int64_t* shapes, const int64_
     set_error("msda_backward: %lld workgroups exceed the grid limit", (long long)blocks);
     return VNX_ERR_UNSUPPORTED;
   }
-  const size_t lds = size_t(WPB) * 3 * QPW * (LP + 1) * 16;
+  const size_t lds = size_t(WPB) * 3 * QPW * (LP + 1) * 16 + 64;     // + [WPB][4] tile words (tile mode)
   // the unit ranges sit behind the records in the workspace (gv_unit_ids_offset); only the P == 4
   // grad_value kernel reads them
   void* unit_ids = (records != nullptr && d.P == 4) ? (void*)((char*)records + gv_unit_ids_offset(d)) : nullptr;
@@ -927,7 +973,8 @@ static int launch_bwd_cfg(const void* value, const int64_t* shapes, const int64_
   hipLaunchKernelGGL((msda_bwd_d32_kernel<TV, TL, QPW, WPB, LPT, AT>), dim3(uint32_t(blocks)),   \
                      dim3(64 * WPB), lds, stream, (const TV*)value, shapes, lsi, (const TL*)loc, \
                      (const TL*)attn, (const TV*)grad_out, (float*)gv, (TL*)grad_loc,            \
-                     (TL*)grad_attn, d, tiles_per_batch, (uint4_t*)records, (uint32_t*)unit_ids, units_min,       \
+                     (TL*)grad_attn, d, tiles_per_batch, (uint4_t*)records, (uint32_t*)unit_ids,                \
+                     (uint32_t*)tile_summary, units_min,                                                          \
                      take_stamp_region(kStampGradLoc, blocks), FusedArgs{nullptr, nullptr, 0, 0, (float*)qsplit_zero})
   if (!atomics) { if (LP == 16) VNX_LAUNCH(16, false); else VNX_LAUNCH(0, false); }
   else { if (LP == 16) VNX_LAUNCH(16, true); else VNX_LAUNCH(0, true); }
@@ -939,20 +986,27 @@ template <typename TV, typename TL>
 static int launch_bwd(const void* value, const int64_t* shapes, const int64_t* lsi,
                       const void* loc, const void* attn, const void* grad_out, void* gv,
                       void* grad_loc, void* grad_attn, const MsdaDims& d, int variant, void* records,
-                      hipStream_t stream) {
+                      void* tile_summary, hipStream_t stream) {
   // variant 100+v: ablation without the grad_value atomics (timing only, wrong grad_value)
   const bool atomics = variant < 100;
   const FwdCfg c = pick_fwd_cfg(d, atomics ? variant : variant - 100);
 #define VNX_CASE(Q, W)                                                                       \
   if (c.qpw == Q && c.wpb == W)                                                              \
     return launch_bwd_cfg<TV, TL, Q, W>(value, shapes, lsi, loc, attn, grad_out, gv, grad_loc, \
-                                        grad_attn, d, atomics, records, stream);
+                                        grad_attn, d, atomics, records, tile_summary, stream);
   VNX_CASE(8, 4) VNX_CASE(4, 4) VNX_CASE(2, 4) VNX_CASE(1, 4)
   VNX_CASE(8, 1) VNX_CASE(4, 1) VNX_CASE(2, 1) VNX_CASE(1, 1)
   VNX_CASE(4, 2)
 #undef VNX_CASE
   set_error("msda_backward: no kernel for qpw=%d wpb=%d", c.qpw, c.wpb);
   return VNX_ERR_UNSUPPORTED;
+}
+
+// queries per workgroup of the grad_loc kernel = per tile word of the tile mode (the launcher's own choice)
+int msda_bwd_tile_queries(const MsdaDims& d, int variant) {
+  // the grad_loc launcher's variant decoding: < 100 as is, 100..199 (grad_loc only, timing) minus 100, others automatic
+  const FwdCfg c = pick_fwd_cfg(d, variant < 100 ? variant : (variant < 200 ? variant - 100 : 0));
+  return c.qpw * c.wpb;
 }
 
 bool msda_d32_bwd_supported(int vdt, int ldt, const MsdaDims& d) {
@@ -964,9 +1018,9 @@ bool msda_d32_bwd_supported(int vdt, int ldt, const MsdaDims& d) {
 int msda_backward_d32(int vdt, int ldt, const void* value, const int64_t* shapes,
                       const int64_t* lsi, const void* loc, const void* attn,
                       const void* grad_out, void* gv, void* grad_loc, void* grad_attn, MsdaDims d,
-                      int variant, void* records, hipStream_t stream) {
+                      int variant, void* records, void* tile_summary, hipStream_t stream) {
   // the 16-bit row limit of the sample records (h0+1, w0+1 packed into one word)
-#define VNX_ARGS value, shapes, lsi, loc, attn, grad_out, gv, grad_loc, grad_attn, d, variant, records, stream
+#define VNX_ARGS value, shapes, lsi, loc, attn, grad_out, gv, grad_loc, grad_attn, d, variant, records, tile_summary, stream
   if (vdt == VNX_F32) return launch_bwd<float, float>(VNX_ARGS);
   if (vdt == VNX_BF16 && ldt == VNX_F32) return launch_bwd<bf16_t, float>(VNX_ARGS);
   if (vdt == VNX_BF16 && ldt == VNX_BF16) return launch_bwd<bf16_t, bf16_t>(VNX_ARGS);
@@ -1005,13 +1059,14 @@ static int launch_bwd_fused_cfg(const void* value, const int64_t* shapes, const 
     set_error("msda_fused_backward: %lld workgroups exceed the grid limit", (long long)blocks);
     return VNX_ERR_UNSUPPORTED;
   }
-  const size_t lds = size_t(WPB) * 3 * QPW * 17 * 16;
+  const size_t lds = size_t(WPB) * 3 * QPW * 17 * 16 + 64;
   void* unit_ids = (records != nullptr && d.P == 4) ? (void*)((char*)records + gv_unit_ids_offset(d)) : nullptr;
   const int units_min = gv_units_min(d);
   hipLaunchKernelGGL((msda_bwd_d32_kernel<TV, TL, QPW, WPB, 16, false, true>), dim3(uint32_t(blocks)), dim3(64 * WPB),
                      lds, stream, (const TV*)value, shapes, lsi, (const TL*)raw_off, (const TL*)raw_logit,
                      (const TV*)grad_out, (float*)nullptr, (TL*)grad_off, (TL*)grad_logit, d, tiles_per_batch,
-                     (uint4_t*)records, (uint32_t*)unit_ids, units_min, take_stamp_region(kStampGradLoc, blocks), fa);
+                     (uint4_t*)records, (uint32_t*)unit_ids, (uint32_t*)nullptr, units_min,
+                     take_stamp_region(kStampGradLoc, blocks), fa);
   return check_launch("msda_bwd_d32_fused");
 }
 

@@ -21,77 +21,11 @@
 //   * writes the slab with 16-B stores.  No floating-point atomics, no zero-fill pass, no fp32
 //     image for 16-bit tensors; every grad_value row has exactly one owner.
 // Levels must be packed (checked on the device; see msda_d32_gv.hip / capi.hip).
-#include "vnx_common.h"
+#include "msda_gv_common.h"
 
 namespace vnx {
 namespace rec {
 
-typedef float float4_t __attribute__((ext_vector_type(4)));
-typedef uint32_t uint2_t __attribute__((ext_vector_type(2)));
-typedef uint32_t uint4_t __attribute__((ext_vector_type(4)));
-
-template <typename TV> __device__ __forceinline__ float4_t load4(const TV* p);
-template <> __device__ __forceinline__ float4_t load4<float>(const float* p) {
-  return *reinterpret_cast<const float4_t*>(p);
-}
-template <> __device__ __forceinline__ float4_t load4<bf16_t>(const bf16_t* p) {
-  const uint2_t r = *reinterpret_cast<const uint2_t*>(p);
-  float4_t v;
-  v.x = __uint_as_float(r.x << 16); v.y = __uint_as_float(r.x & 0xffff0000u);
-  v.z = __uint_as_float(r.y << 16); v.w = __uint_as_float(r.y & 0xffff0000u);
-  return v;
-}
-template <> __device__ __forceinline__ float4_t load4<f16_t>(const f16_t* p) {
-  const uint2_t r = *reinterpret_cast<const uint2_t*>(p);
-  float4_t v;
-  v.x = float(__builtin_bit_cast(_Float16, uint16_t(r.x & 0xffffu)));
-  v.y = float(__builtin_bit_cast(_Float16, uint16_t(r.x >> 16)));
-  v.z = float(__builtin_bit_cast(_Float16, uint16_t(r.y & 0xffffu)));
-  v.w = float(__builtin_bit_cast(_Float16, uint16_t(r.y >> 16)));
-  return v;
-}
-template <typename TV> __device__ __forceinline__ void store4(TV* p, float4_t v);
-template <> __device__ __forceinline__ void store4<float>(float* p, float4_t v) {
-  // grad_value is written once and read by another kernel much later: `nt` (decoder-360p backward 33.8 -> 31.4 us)
-  // (same WRITE_SIZE / FETCH_SIZE per launch as plain stores; rocprofv3 18.9 vs 20.0 us for this kernel)
-  __builtin_nontemporal_store(v, reinterpret_cast<float4_t*>(p));
-}
-template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, float4_t v) {
-  uint2_t r;
-  r.x = uint32_t(f32_to_bf16_bits(v.x)) | (uint32_t(f32_to_bf16_bits(v.y)) << 16);
-  r.y = uint32_t(f32_to_bf16_bits(v.z)) | (uint32_t(f32_to_bf16_bits(v.w)) << 16);
-  __builtin_nontemporal_store(r, reinterpret_cast<uint2_t*>(p));
-}
-template <> __device__ __forceinline__ void store4<f16_t>(f16_t* p, float4_t v) {
-  uint2_t r;
-  r.x = uint32_t(__builtin_bit_cast(uint16_t, _Float16(v.x))) | (uint32_t(__builtin_bit_cast(uint16_t, _Float16(v.y))) << 16);
-  r.y = uint32_t(__builtin_bit_cast(uint16_t, _Float16(v.z))) | (uint32_t(__builtin_bit_cast(uint16_t, _Float16(v.w))) << 16);
-  __builtin_nontemporal_store(r, reinterpret_cast<uint2_t*>(p));
-}
-
-// The value again, but opaque to the optimiser: what is derived from the result is recomputed where it is used instead of
-// being hoisted out of the loops and then SPILLED (the selection kernel kept `tid | 0x200`, `tid >> 2`, `tid * 4`, ... live
-// across its loops and spilled ten of them: 10 dwords x 64 lanes x 6 080 waves = 15.5 MB of scratch written back to
-// memory per launch -- the whole excess of WRITE_SIZE over the 26.1 MB of grad_value rows, profiles/r02).
-__device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
-
-__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
-  int x = int(v);
-  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);  // row_shr:1
-  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);  // row_shr:2
-  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false);  // row_shr:4
-  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false);  // row_shr:8
-  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1, 3
-  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2, 3
-  return uint32_t(x);
-}
-
-constexpr int kWaves = 8;                   // 512 threads, one sample per thread per chunk
-constexpr int kThreads = 64 * kWaves;
-constexpr int kGroups = kThreads / 8;       // 8-lane groups
-constexpr int kRowsMax = kGvRowsMax;        // 320 rows: 40 KiB as an LDS slab
-constexpr int kQcMax = 128;                 // queries per chunk (16 KiB of grad_out rows in LDS)
-constexpr int kLevelsMax = 64;
 // slab 40 K + grad_out rows 16 K + tap list 16 K + 3 x 320 counters/offsets + allocator + level
 // table = 76.8 KiB -> two units per CU.
 constexpr size_t kLdsBytes = size_t(kRowsMax) * 128 + size_t(kQcMax) * 128 + size_t(kThreads) * 32 +
@@ -396,9 +330,6 @@ constexpr size_t kSelLdsBytes = size_t(kQcMax) * 128 + size_t(kThreads) * 32 + s
                                 size_t(kSelParts) * 16 + 64;
 
 template <typename TV>
-#ifndef VNX_SEL_UNITS_PER_CU
-#define VNX_SEL_UNITS_PER_CU 3
-#endif
 __global__ void __launch_bounds__(kThreads, VNX_SEL_UNITS_PER_CU * kWaves / 4)
 msda_bwd_gv_sel_kernel(const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
                        const uint4_t* __restrict__ records, const uint32_t* __restrict__ unit_ids,

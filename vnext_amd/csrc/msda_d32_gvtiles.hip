@@ -1,0 +1,359 @@
+// msda_d32_gvtiles.hip -- grad_value, owner-computes, for calls with MANY queries (the encoder's: the queries
+// are the pixels of the pyramid, Lq = S), fed by per-tile summaries instead of per-sample records.
+//
+// The record-fed kernel (msda_d32_gvrec.hip) has the grad_loc kernel leave 16 B of geometry + 4 B of unit range for
+// EVERY sample (65 MB written per T=5 360p encoder call, 250 MB at 720p) and every unit scan the 4-B words of ALL of
+// its level's samples in selection windows of 2 048 -- ten windows of three barriers and a dependent load each before
+// the first tap is applied.  At the decoder shape (300 scattered queries) that selection is what makes a unit cheap;
+// at the encoder shape it is a third of the kernel, and the records are 40 % of the backward's memory traffic.
+//
+// Here selection works on TILES of queries: a workgroup of the grad_loc kernel handles T consecutive queries (T = 16
+// on large calls) of one (batch, head), and consecutive queries of an encoder call are neighbouring pixels whose
+// samples land next to each other.  That workgroup reduces, per level, the range of grad_value units its samples'
+// corners touch and leaves ONE 4-byte word per (batch, head, level, tile): 319 words per level at 360p where there
+// were 20 400 tags.  A unit of this kernel
+//   1. reads its level's tile words (one load round per 512 tiles), keeps the tiles whose range contains it
+//      (wave ballots + one 32-entry scan: ascending order, so every sum stays deterministic);
+//   2. walks the kept tiles 128 queries (8 tiles) per chunk: one sample per thread -- its location and weight read
+//      from the op's own inputs, the geometry recomputed (15 VALU instructions; the predecessor of the record kernel
+//      was slow because every unit recomputed ALL samples of its level, not because of these) -- the tiles' grad_out
+//      rows staged in LDS (consecutive queries: the rows of a tile are one strided run), then the same counting sort
+//      by destination row and register accumulation as the record-fed kernel;
+//   3. writes its rows once (or, for the pieces of a query-split level, adds them with fp32 atomics onto rows the
+//      grad_loc kernel zeroed: gv_query_splits, split by tile range here).
+// No records, no tags, no windows.  Levels must be packed (checked on the device).  Reference semantics:
+// ms_deform_im2col_cuda.cuh:87-159 (the scatter this replaces), :253-298 (index decode).
+#include "msda_gv_common.h"
+
+namespace vnx {
+namespace rec {
+
+constexpr int kTileWin = 4 * kThreads;            // tile words examined per selection round: 2 048
+constexpr int kTileParts = 4 * kWaves;            // (round, wave) pieces per selection
+constexpr size_t kTilesLdsBytes = size_t(kQcMax) * 128 + size_t(kThreads) * 32 + size_t(kRowsMax) * 12 + 16 +
+                                  4 * kLevelsMax * 4 + size_t(kTileWin) * 2 + size_t(kTileParts) * 8 + 16;
+
+template <typename TV, typename TL>
+__global__ void __launch_bounds__(kThreads, VNX_SEL_UNITS_PER_CU * kWaves / 4)
+msda_bwd_gv_tiles_kernel(const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
+                         const TL* __restrict__ loc, const TL* __restrict__ attn,
+                         const uint32_t* __restrict__ summaries, const TV* __restrict__ grad_out,
+                         TV* __restrict__ grad_value, MsdaDims d, int units_min, int tile_shift, int n_tiles) {
+  constexpr int D = 32, P = 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float4_t* grows = reinterpret_cast<float4_t*>(smem);                       // [128][8] grad_out rows
+  uint2_t* list = reinterpret_cast<uint2_t*>(grows + kQcMax * 8);            // [4*threads] taps
+  uint32_t* cnt2 = reinterpret_cast<uint32_t*>(list + 4 * kThreads);         // [2][rows]
+  uint32_t* offs = cnt2 + 2 * kRowsMax;                                      // [rows]
+  uint32_t* alloc = offs + kRowsMax;                                         // [4]
+  int* meta = reinterpret_cast<int*>(alloc + 4);                             // [4*L]
+  uint16_t* hit = reinterpret_cast<uint16_t*>(meta + 4 * kLevelsMax);        // [kTileWin] window-relative tile
+  uint32_t* part_s = reinterpret_cast<uint32_t*>(hit + kTileWin);            // [32] kept tiles per piece
+  uint32_t* pre_s = part_s + kTileParts;                                     // [32] exclusive prefixes
+  uint32_t* tot = pre_s + kTileParts;                                        // [1] kept tiles of the round
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // dispatch order = cost order (units numbered from the last level back), head <-> XCD map rotating with the
+  // batch element: as in msda_d32_gvrec.hip
+  const int rest = blockIdx.x / d.M;
+  const int unit = rest / d.B;
+  const int b = rest - unit * d.B;
+  const int m = (blockIdx.x % d.M + b) % d.M;
+
+  if (tid < d.L) {
+    const int H = int(shapes[2 * tid]), W = int(shapes[2 * tid + 1]);
+    const GvSplit sp = gv_level_split(H * W, units_min);
+    const int qs = gv_query_splits(sp.units, d.Lq, P, sizeof(TV) == 4, d.B * d.M);
+    meta[4 * tid] = H; meta[4 * tid + 1] = W; meta[4 * tid + 2] = int(lsi[tid]);
+    meta[4 * tid + 3] = sp.units | (sp.rpu << 12) | (qs << 24);     // units <= 4000, rpu <= 320, qs <= 8
+  }
+  for (int i = tid; i < 2 * kRowsMax; i += kThreads) cnt2[i] = 0;
+  if (tid == 0) alloc[0] = 0;
+  __syncthreads();
+
+  int lvl = -1, r0 = 0, r1 = 0, Hl = 0, Wl = 0, start = 0, u_lvl = 0, qsplit = 1, qpiece = 0;
+  {
+    int running = 0;
+    bool packed = true;
+    int u = unit;
+    for (int l = 0; l < d.L; ++l) {
+      packed = packed && (meta[4 * l + 2] == running);
+      running += meta[4 * l] * meta[4 * l + 1];
+    }
+    for (int l = d.L - 1; l >= 0; --l) {       // units are numbered from the last (coarsest) level back
+      const int H = meta[4 * l], W = meta[4 * l + 1], st = meta[4 * l + 2], ur = meta[4 * l + 3];
+      const int n = H * W, units = ur & 0xfff, rpu = (ur >> 12) & 0xfff, qs = ur >> 24;
+      if (lvl < 0) {
+        if (u < units * qs) {        // a level's workgroups: row-unit major, query piece minor
+          lvl = l; Hl = H; Wl = W; start = st; qsplit = qs;
+          u_lvl = u / qs; qpiece = u - u_lvl * qs;
+          r0 = u_lvl * rpu;
+          r1 = r0 + rpu < n ? r0 + rpu : n;
+        } else {
+          u -= units * qs;
+        }
+      }
+    }
+    packed = packed && (running == d.S);
+    if (!packed || lvl < 0) return;  // uniform over the workgroup
+  }
+  // uniform over the workgroup, but it came through LDS: scalarise (SGPRs, see opaque())
+  lvl = __builtin_amdgcn_readfirstlane(lvl); r0 = __builtin_amdgcn_readfirstlane(r0); r1 = __builtin_amdgcn_readfirstlane(r1);
+  Hl = __builtin_amdgcn_readfirstlane(Hl); Wl = __builtin_amdgcn_readfirstlane(Wl); start = __builtin_amdgcn_readfirstlane(start);
+  u_lvl = __builtin_amdgcn_readfirstlane(u_lvl); qsplit = __builtin_amdgcn_readfirstlane(qsplit);
+  qpiece = __builtin_amdgcn_readfirstlane(qpiece);
+  const int rows = r1 - r0;
+  constexpr int kRpg = (kRowsMax + kGroups - 1) / kGroups;
+  float4_t racc[kRpg];
+#pragma unroll
+  for (int k = 0; k < kRpg; ++k) racc[k] = float4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int LP = d.L * P;
+  const uint32_t* summ = summaries + ((int64_t(b) * d.M + m) * d.L + lvl) * int64_t(n_tiles);
+  // sample (q, head m, level lvl, point k) of this batch element: index  base + q * (M * LP) + k  into attn, twice that
+  // into loc; q * M * LP * 2 < 2^32 (msda_d32_gvtiles_supported)
+  const TL* attn_bm = attn + (int64_t(b) * d.Lq * d.M + m) * LP + lvl * P;
+  const TL* loc_bm = loc + 2 * ((int64_t(b) * d.Lq * d.M + m) * LP + lvl * P);
+  const uint32_t s_stride = uint32_t(d.M) * uint32_t(LP);
+  const TV* go_head = grad_out + (int64_t(b) * d.Lq * d.M + m) * D;
+  const uint32_t q_stride = uint32_t(d.M) * uint32_t(D);
+  const float Hf = float(Hl), Wf = float(Wl);
+  const int tile_mask = (1 << tile_shift) - 1;
+  const int tpc_shift = 7 - tile_shift;              // tiles per chunk = 128 >> tile_shift
+  const int dr[4] = {0, 1, Wl, Wl + 1};
+
+  int gchunk = 0;                                    // parity of the double-buffered row counters
+
+  // the tiles this workgroup takes: all of them, or one piece of a query-split level
+  const int t_per = (n_tiles + qsplit - 1) / qsplit;
+  const int t_lo = qpiece * t_per, t_hi = (qpiece + 1) * t_per < n_tiles ? (qpiece + 1) * t_per : n_tiles;
+  for (int win0 = t_lo; win0 < t_hi; win0 += kTileWin) {
+    const int n_w = t_hi - win0 < kTileWin ? t_hi - win0 : kTileWin;
+    const int tw = opaque(tid);
+    // ---- selection: which tiles of this round touch my rows -----------------------------------
+    unsigned long long bal[4];
+    uint32_t hitbits = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ti = r * kThreads + tw;
+      // word = unit_lo | (0xffff - unit_hi) << 16 (what a packed 16-bit minimum reduces); 0xffffffff = no taps
+      const uint32_t v = ti < n_w ? summ[win0 + ti] : 0xffffffffu;
+      const int lo = int(v & 0xffffu), hi = 0xffff - int(v >> 16);
+      const bool h = lo <= u_lvl && u_lvl <= hi;
+      const unsigned long long bh = __ballot(h);
+      bal[r] = bh;
+      hitbits |= uint32_t(h) << r;
+      if (lane == 0) part_s[r * kWaves + wave] = uint32_t(__popcll(bh));
+    }
+    __syncthreads();
+    if (tid < 64) {                                   // one wave scans the 32 (round, wave) pieces
+      const uint32_t ns = tid < kTileParts ? part_s[tid] : 0u;
+      const uint32_t is = wave_inclusive_scan(ns);
+      if (tid < kTileParts) pre_s[tid] = is - ns;
+      if (tid == kTileParts - 1) tot[0] = is;
+    }
+    __syncthreads();
+    const int n_hit = int(tot[0]);
+    if (n_hit == 0) continue;                         // uniform: no tile of this round lands here
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (hitbits & (1u << r)) {
+        const uint32_t lo32 = __builtin_amdgcn_mbcnt_lo(uint32_t(bal[r]), 0u);
+        const uint32_t pos = pre_s[r * kWaves + wave] + __builtin_amdgcn_mbcnt_hi(uint32_t(bal[r] >> 32), lo32);
+        hit[pos] = uint16_t(r * kThreads + tw);
+      }
+    }
+    __syncthreads();
+
+    // ---- chunks of 128 queries (whole tiles) over the kept tiles ---------------------------------
+    const int n_chunks = ((n_hit << tile_shift) + kQcMax - 1) / kQcMax;
+    float nx = 0.f, ny = 0.f, na = 0.f;
+    bool nvalid = false;
+    float4_t pg0 = {0.f, 0.f, 0.f, 0.f}, pg1 = pg0;
+    // query of slot s (0..127) of chunk c, or -1
+    auto slot_query = [&](int c, int s) {
+      const int ht = (c << tpc_shift) + (s >> tile_shift);
+      if (ht >= n_hit) return -1;
+      const int q = ((win0 + int(hit[ht])) << tile_shift) + (s & tile_mask);
+      return q < d.Lq ? q : -1;
+    };
+    auto prefetch = [&](int c) {
+      const int tq = opaque(tid);
+      const int q = slot_query(c, tq >> 2);
+      nvalid = q >= 0;
+      if (nvalid) {
+        const uint32_t si = __umul24(uint32_t(q), s_stride) + uint32_t(tq & 3);
+        nx = to_acc(loc_bm[2 * si]); ny = to_acc(loc_bm[2 * si + 1]);
+        na = to_acc(attn_bm[si]);
+      }
+      const int g0 = opaque(tid), g1 = g0 + kThreads;
+      const int qa = slot_query(c, g0 >> 3), qb = slot_query(c, g1 >> 3);
+      if (qa >= 0) pg0 = load4<TV>(go_head + __umul24(uint32_t(qa), q_stride) + (g0 & 7) * 4);
+      if (qb >= 0) pg1 = load4<TV>(go_head + __umul24(uint32_t(qb), q_stride) + (g1 & 7) * 4);
+    };
+    prefetch(0);
+    for (int c = 0; c < n_chunks; ++c, ++gchunk) {
+      uint32_t* cnt = cnt2 + (gchunk & 1) * kRowsMax;
+      uint32_t* cnt_next = cnt2 + ((gchunk + 1) & 1) * kRowsMax;
+      const float x = nx, y = ny, a = na;
+      const bool valid = nvalid;
+      const int tc = opaque(tid);
+      const uint32_t slot = uint32_t(tc) >> 2;
+      const int grp = tc >> 3, ch4 = tc & 7;
+      grows[tc] = pg0;
+      grows[tc + kThreads] = pg1;
+      if (c + 1 < n_chunks) prefetch(c + 1);
+      uint32_t mask = 0;
+      int row00 = 0;
+      float wt[4] = {0.f, 0.f, 0.f, 0.f};
+      uint32_t rank[4] = {0u, 0u, 0u, 0u};
+      if (valid) {
+        const float h = y * Hf - 0.5f, w = x * Wf - 0.5f;                     // cuh:285-286
+        if (h > -1.f && w > -1.f && h < Hf && w < Wf) {                        // cuh:288
+          const float hf = floorf(h), wf = floorf(w);
+          const int h0 = int(hf), w0 = int(wf);
+          const float lh = h - hf, lw = w - wf, hh = 1.f - lh, hw = 1.f - lw;
+          const bool top = h0 >= 0, bot = h0 + 1 <= Hl - 1, lef = w0 >= 0, rig = w0 + 1 <= Wl - 1;
+          const int p00 = h0 * Wl + w0;
+          mask = (uint32_t(top && lef && p00 >= r0 && p00 < r1)) |
+                 (uint32_t(top && rig && p00 + 1 >= r0 && p00 + 1 < r1) << 1) |
+                 (uint32_t(bot && lef && p00 + Wl >= r0 && p00 + Wl < r1) << 2) |
+                 (uint32_t(bot && rig && p00 + Wl + 1 >= r0 && p00 + Wl + 1 < r1) << 3);
+          row00 = p00 - r0;
+          wt[0] = a * (hh * hw); wt[1] = a * (hh * lw); wt[2] = a * (lh * hw); wt[3] = a * (lh * lw);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (mask & (1u << t))
+          rank[t] = __hip_atomic_fetch_add(cnt + row00 + dr[t], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __syncthreads();
+      {
+        const uint32_t my_cnt = tid < rows ? cnt[tid] : 0u;
+        const uint32_t incl = wave_inclusive_scan(my_cnt);
+        const uint32_t wave_total = uint32_t(__builtin_amdgcn_readlane(int(incl), 63));
+        uint32_t base = 0;
+        if (lane == 0 && wave_total != 0)
+          base = __hip_atomic_fetch_add(alloc, wave_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        base = uint32_t(__builtin_amdgcn_readfirstlane(int(base)));
+        if (tid < rows) offs[tid] = base + incl - my_cnt;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (mask & (1u << t)) list[offs[row00 + dr[t]] + rank[t]] = uint2_t{slot, __float_as_uint(wt[t])};
+      __syncthreads();
+      if (tid == 0) alloc[0] = 0;
+      uint32_t rn[kRpg], ro[kRpg];
+#pragma unroll
+      for (int k = 0; k < kRpg; ++k) {
+        const int row = grp + k * kGroups;
+        rn[k] = row < rows ? cnt[row] : 0u;
+        ro[k] = row < rows ? offs[row] : 0u;
+        if (row < rows) cnt_next[row] = 0;
+      }
+      const float4_t* g4 = grows + ch4;
+#pragma unroll
+      for (int k = 0; k < kRpg; ++k) {
+        const uint32_t n = rn[k];
+        if (n == 0) continue;
+        const uint2_t* seg = list + ro[k];
+        float4_t a1 = {0.f, 0.f, 0.f, 0.f};
+        uint32_t i = 0;
+        for (; i + 2 <= n; i += 2) {
+          const uint2_t e0 = seg[i], e1 = seg[i + 1];
+          const float4_t x0 = g4[e0.x * 8], x1 = g4[e1.x * 8];
+          racc[k] += __uint_as_float(e0.y) * x0;
+          a1 += __uint_as_float(e1.y) * x1;
+        }
+        if (i < n) {
+          const uint2_t e = seg[i];
+          a1 += __uint_as_float(e.y) * g4[e.x * 8];
+        }
+        racc[k] += a1;
+      }
+      __syncthreads();
+    }
+  }
+
+  TV* out = grad_value + ((int64_t(b) * d.S + start + r0) * d.M + m) * D;
+  const int te = opaque(tid);
+  const int grp = te >> 3, ch4 = te & 7;
+  if constexpr (sizeof(TV) == 4) {
+    if (qsplit > 1) {   // pieces of a query-split level meet through fp32 atomics (rows zeroed by the grad_loc kernel)
+#pragma unroll
+      for (int k = 0; k < kRpg; ++k) {
+        const int row = grp + k * kGroups;
+        if (row < rows) {
+          float* p = reinterpret_cast<float*>(out) + __umul24(uint32_t(row), q_stride) + ch4 * 4;
+          atomic_add(p, racc[k].x); atomic_add(p + 1, racc[k].y); atomic_add(p + 2, racc[k].z); atomic_add(p + 3, racc[k].w);
+        }
+      }
+      return;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < kRpg; ++k) {
+    const int row = grp + k * kGroups;
+    if (row < rows) store4<TV>(out + __umul24(uint32_t(row), q_stride) + ch4 * 4, racc[k]);
+  }
+}
+
+}  // namespace rec
+
+int msda_gvrec_units_bound(const MsdaDims& d, int units_min);
+
+// bytes of the tile words: [batch][head][level][tile]
+size_t msda_gvtiles_summary_bytes(const MsdaDims& d, int tile_queries) {
+  const size_t n_tiles = (size_t(d.Lq) + tile_queries - 1) / tile_queries;
+  return size_t(4) * size_t(d.B) * d.M * d.L * n_tiles;
+}
+
+bool msda_d32_gvtiles_supported(int vdt, int ldt, const MsdaDims& d) {
+  if (d.D != 32 || d.P != 4 || vdt == VNX_F64) return false;
+  if (vdt == VNX_F32 && ldt != VNX_F32) return false;
+  if (d.L > rec::kLevelsMax) return false;
+  if (d.S > rec::kRowsMax * 4000) return false;     // units and rows/unit share one word
+  // 24-bit stride multiplies: query index, heads x channels and heads x samples below 2^24; element offsets below 2^32
+  if (d.Lq >= (1 << 24) || d.M * 32 >= (1 << 24) || d.M * d.L * 4 >= (1 << 24)) return false;
+  if (int64_t(d.Lq) * d.M * 32 >= (int64_t(1) << 32) || int64_t(d.Lq) * d.M * d.L * 8 >= (int64_t(1) << 32)) return false;
+  const int64_t blocks = int64_t(d.B) * d.M * msda_gvrec_units_bound(d, 16);
+  return blocks < (int64_t(1) << 31);
+}
+
+template <typename TV, typename TL>
+static int launch_gvtiles(const int64_t* shapes, const int64_t* lsi, const void* loc, const void* attn,
+                          const void* summaries, const void* grad_out, void* grad_value, const MsdaDims& d,
+                          int units_min, int tile_queries, hipStream_t stream) {
+  int tile_shift = 0;
+  while ((1 << tile_shift) < tile_queries) ++tile_shift;
+  if ((1 << tile_shift) != tile_queries || tile_queries > rec::kQcMax) {
+    set_error("msda_backward_gvtiles: tile of %d queries (a power of two <= %d is required)", tile_queries, rec::kQcMax);
+    return VNX_ERR_UNSUPPORTED;
+  }
+  const int n_tiles = (d.Lq + tile_queries - 1) / tile_queries;
+  const int64_t blocks = int64_t(d.B) * d.M * msda_gvrec_units_bound(d, units_min);
+  hipLaunchKernelGGL((rec::msda_bwd_gv_tiles_kernel<TV, TL>), dim3(uint32_t(blocks)), dim3(rec::kThreads),
+                     rec::kTilesLdsBytes, stream, shapes, lsi, (const TL*)loc, (const TL*)attn,
+                     (const uint32_t*)summaries, (const TV*)grad_out, (TV*)grad_value, d, units_min, tile_shift, n_tiles);
+  return check_launch("msda_bwd_gv_tiles");
+}
+
+// grad_value from the op's inputs and the tile words; a no-op on the device when the levels are not packed.
+int msda_backward_gvtiles_d32(int vdt, int ldt, const int64_t* shapes, const int64_t* lsi, const void* loc,
+                              const void* attn, const void* summaries, const void* grad_out, void* grad_value,
+                              MsdaDims d, int tile_queries, hipStream_t stream) {
+  const int units_min = gv_units_min(d);
+#define VNX_ARGS shapes, lsi, loc, attn, summaries, grad_out, grad_value, d, units_min, tile_queries, stream
+  if (vdt == VNX_F32) return launch_gvtiles<float, float>(VNX_ARGS);
+  if (vdt == VNX_BF16 && ldt == VNX_F32) return launch_gvtiles<bf16_t, float>(VNX_ARGS);
+  if (vdt == VNX_BF16 && ldt == VNX_BF16) return launch_gvtiles<bf16_t, bf16_t>(VNX_ARGS);
+  if (vdt == VNX_F16 && ldt == VNX_F32) return launch_gvtiles<f16_t, float>(VNX_ARGS);
+  if (vdt == VNX_F16 && ldt == VNX_F16) return launch_gvtiles<f16_t, f16_t>(VNX_ARGS);
+#undef VNX_ARGS
+  set_error("msda_backward_gvtiles_d32: unsupported dtype pair (%d, %d)", vdt, ldt);
+  return VNX_ERR_INVALID_ARGUMENT;
+}
+
+}  // namespace vnx
