@@ -3,8 +3,9 @@ CPU oracle over ALL rows of the BASELINE encoder shapes, and on the inputs that 
 paths: non-dyadic pyramids (cells of uneven size), taps outside the window (global fetch), samples
 outside the map (zero padding, ms_deform_im2col_cuda.cuh:55-78,288), unpacked levels and Lq != S
 (linear blocks), non-finite values next to padded taps, the fused prologue (ops/modules/ms_deform_attn.py:
-99-112).  Everything goes through the C ABI; variant 700 = the tiled kernel, 710 = the per-query gather kernel,
-0 = automatic selection (since late round 2 always the gather kernel: it is the faster one at every shape)."""
+99-112).  Everything goes through the C ABI; variant 700 = the first tiled kernel, 720 = the second
+(vnext_amd/csrc/msda_d32_tile2.hip: 16 x 8 cells, one sample per 8-lane set, next item prefetched), 710 = the
+per-query gather kernel, 0 = automatic selection."""
 import numpy as np
 import pytest
 import torch
@@ -18,6 +19,7 @@ from vnext_amd import _lib, msda_ext  # noqa: E402
 from vnext_amd.ops.functions import level_tensors  # noqa: E402
 
 DEV = "cuda:0"
+TILED = [700, 720]
 S360 = [(48, 80), (24, 40), (12, 20), (6, 10)]
 S720 = [(92, 160), (46, 80), (23, 40), (12, 20)]
 
@@ -83,7 +85,7 @@ def test_encoder_shapes_all_rows_against_the_oracle(shapes, B):
     """BASELINE encoder shapes (Lq = S; 360p: B = T = 5), every output row."""
     sh, lsi, value, loc, attn = encoder_case(shapes, B, seed=11)
     want = oracle(value, sh, lsi, loc, attn)
-    for variant in (0, 700, 710):
+    for variant in (0, 700, 710, 720):
         close(fwd(value, sh, lsi, loc, attn, variant), want)
 
 
@@ -95,19 +97,22 @@ def test_encoder_shapes_all_rows_against_the_oracle(shapes, B):
     [(3, 5), (20, 31), (2, 2), (7, 3)],        # the finest level is not level 0
 ])
 @pytest.mark.parametrize("uniform", [False, True])
-def test_uneven_pyramids(shapes, uniform):
+@pytest.mark.parametrize("tiled", TILED)
+def test_uneven_pyramids(shapes, uniform, tiled):
     sh, lsi, value, loc, attn = encoder_case(shapes, 3, seed=5, uniform=uniform)
-    close(fwd(value, sh, lsi, loc, attn, 700), oracle(value, sh, lsi, loc, attn))
+    close(fwd(value, sh, lsi, loc, attn, tiled), oracle(value, sh, lsi, loc, attn))
 
 
 @pytest.mark.parametrize("spread", [4.0, 25.0])
-def test_taps_outside_the_window_come_from_global_memory(spread):
-    """Large offsets: most samples leave the <= 256-pixel window of their cell (and many the map)."""
+@pytest.mark.parametrize("tiled", TILED)
+def test_taps_outside_the_window_come_from_global_memory(spread, tiled):
+    """Large offsets: most samples leave the window of their cell (and many the map)."""
     sh, lsi, value, loc, attn = encoder_case(S360, 2, seed=7, spread=spread)
-    close(fwd(value, sh, lsi, loc, attn, 700), oracle(value, sh, lsi, loc, attn))
+    close(fwd(value, sh, lsi, loc, attn, tiled), oracle(value, sh, lsi, loc, attn))
 
 
-def test_linear_blocks_when_the_queries_are_not_the_pixels():
+@pytest.mark.parametrize("tiled", TILED)
+def test_linear_blocks_when_the_queries_are_not_the_pixels(tiled):
     """Lq != S (a decoder call forced onto the tiled kernel) and unpacked levels (gaps between them):
     the kernel falls back to blocks of 64 consecutive queries; the result must not change."""
     g = torch.Generator().manual_seed(3)
@@ -117,7 +122,7 @@ def test_linear_blocks_when_the_queries_are_not_the_pixels():
     value = torch.randn(2, S, 8, 32, generator=g)
     loc = torch.rand(2, 333, 8, 4, 4, 2, generator=g)
     attn = torch.softmax(torch.randn(2, 333, 8, 16, generator=g), -1).view(2, 333, 8, 4, 4)
-    close(fwd(value, sh, lsi, loc, attn, 700), oracle(value, sh, lsi, loc, attn))
+    close(fwd(value, sh, lsi, loc, attn, tiled), oracle(value, sh, lsi, loc, attn))
     # unpacked: 7 unused rows in front of every level, Lq == S_padded
     gaps = torch.arange(1, 5) * 7
     lsi2 = lsi + gaps
@@ -125,17 +130,18 @@ def test_linear_blocks_when_the_queries_are_not_the_pixels():
     value2 = torch.randn(2, S2, 8, 32, generator=g)
     loc2 = torch.rand(2, S2, 8, 4, 4, 2, generator=g)
     attn2 = torch.softmax(torch.randn(2, S2, 8, 16, generator=g), -1).view(2, S2, 8, 4, 4)
-    close(fwd(value2, sh, lsi2, loc2, attn2, 700), oracle(value2, sh, lsi2, loc2, attn2))
+    close(fwd(value2, sh, lsi2, loc2, attn2, tiled), oracle(value2, sh, lsi2, loc2, attn2))
 
 
-def test_padded_taps_never_touch_the_data():
+@pytest.mark.parametrize("tiled", TILED)
+def test_padded_taps_never_touch_the_data(tiled):
     """Samples outside the map and NaN locations contribute exactly nothing, also when `value` holds
     non-finite numbers elsewhere: only queries whose taps really read those rows may see them."""
     sh, lsi, value, loc, attn = encoder_case(S360, 1, seed=9)
     value[0, 0] = float("inf")                     # pixel (0, 0) of level 0, all heads
     loc[0, 4000:4010] = float("nan")               # ten queries with NaN locations
     loc[0, 4010:4020] = 7.0                        # ten queries far outside the map
-    got = fwd(value, sh, lsi, loc, attn, 700)
+    got = fwd(value, sh, lsi, loc, attn, tiled)
     alt = fwd(value, sh, lsi, loc, attn, 710)
     assert np.all(got[0, 4000:4020] == 0.0) and np.all(alt[0, 4000:4020] == 0.0)
     finite = np.isfinite(alt)
@@ -179,11 +185,12 @@ def test_fused_prologue_on_the_tiled_kernel(ref_dim, ref_div):
     close(outs[710], want, 5e-5)
 
 
-def test_graph_capture_and_repeatability():
+@pytest.mark.parametrize("tiled", TILED)
+def test_graph_capture_and_repeatability(tiled):
     """No allocation, no synchronisation inside the call; same bits on every replay."""
     sh, lsi, value, loc, attn = encoder_case(S360, 2, seed=2)
     dv, ds, di, dl, da = (t.to(DEV) for t in (value, sh, lsi, loc, attn))
-    _lib.set_kernel_variant(700)
+    _lib.set_kernel_variant(tiled)
     first = MSDA.ms_deform_attn_forward(dv, ds, di, dl, da, 64)
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()

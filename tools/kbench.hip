@@ -148,6 +148,43 @@ __global__ void stride_probe(const float4_t* __restrict__ base, size_t n_rec, in
   }
   if (acc.x == 123.456f) sink[0] = acc.y;
 }
+// ---- does `buffer_load ... lds` reach LDS addresses above 64 KiB (M0 wider than 16 bits)? ------------------------
+__global__ void dma_high_probe(const float* __restrict__ src, float* __restrict__ dst, int n_floats, int hi_off) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lo_off = hi_off & 0xffff;
+  for (int i = threadIdx.x; i < 256; i += blockDim.x) {
+    reinterpret_cast<float*>(smem + lo_off)[i] = -7.f;
+    reinterpret_cast<float*>(smem + hi_off)[i] = -9.f;
+  }
+  __syncthreads();
+  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, n_floats * 4, 0x00020000);
+  const int lane = threadIdx.x & 63;
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(smem + hi_off), 16, unsigned(lane * 16), 0, 0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  dst[threadIdx.x * 4 + 0] = reinterpret_cast<float*>(smem + hi_off)[threadIdx.x * 4];
+  dst[threadIdx.x * 4 + 1] = reinterpret_cast<float*>(smem + lo_off)[threadIdx.x * 4];
+}
+static void run_dma_high_probe() {
+  const int n = 64 * 4;
+  std::vector<float> h(n);
+  for (int i = 0; i < n; ++i) h[i] = float(i + 1);
+  float *src, *dst;
+  CK(hipMalloc(&src, n * 4)); CK(hipMalloc(&dst, 256 * 4));
+  CK(hipMemcpy(src, h.data(), n * 4, hipMemcpyHostToDevice));
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dma_high_probe), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+  for (int hi_off : {0x11100, 0x20000}) {
+    hipLaunchKernelGGL(dma_high_probe, dim3(1), dim3(64), 144 * 1024, 0, src, dst, n, hi_off);
+    CK(hipDeviceSynchronize());
+    std::vector<float> o(256);
+    CK(hipMemcpy(o.data(), dst, 256 * 4, hipMemcpyDeviceToHost));
+    int hi_ok = 1, lo_untouched = 1;
+    for (int t = 0; t < 64; ++t) { hi_ok &= (o[t * 4] == h[t * 4]); lo_untouched &= (o[t * 4 + 1] == -7.f); }
+    printf("[dma-high-probe] LDS offset 0x%x: data landed there: %d; the alias 64 KiB below untouched: %d (got %g / %g)\n", hi_off, hi_ok,
+           lo_untouched, o[4], o[5]);
+  }
+  CK(hipFree(src)); CK(hipFree(dst));
+}
 static void run_stride_probe() {
   const size_t n_rec = size_t(384) << 10;       // 384 Ki records x 1 KiB = 384 MiB (> Infinity Cache)
   float4_t* buf; float* sink;
@@ -223,7 +260,7 @@ int main(int argc, char** argv) {
     else if (a == "--hbm-probe") hbm = true;
     else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 1; }
   }
-  if (dma) run_dma_probe();
+  if (dma) { run_dma_probe(); run_dma_high_probe(); }
   if (hbm) { run_stride_probe(); return 0; }
   const bool p720 = shape.size() >= 3 && shape.substr(shape.size() - 3) == "720";
   const int HW360[4][2] = {{48, 80}, {24, 40}, {12, 20}, {6, 10}}, HW720[4][2] = {{92, 160}, {46, 80}, {23, 40}, {12, 20}};

@@ -42,6 +42,8 @@ bool msda_d32_fwd_supported(int vdt, int ldt, const MsdaDims& d);
 bool msda_tile_fwd_supported(int vdt, int ldt, const MsdaDims& d);
 int msda_forward_tile(const void*, const int64_t*, const int64_t*, const void*, const void*, void*, MsdaDims,
                       const FusedArgs*, int debug, hipStream_t);
+bool msda_tile2_fwd_supported(int vdt, int ldt, const MsdaDims& d);
+int msda_forward_tile2(const void*, const int64_t*, const int64_t*, const void*, const void*, void*, MsdaDims, hipStream_t);
 bool msda_d32_bwd_supported(int vdt, int ldt, const MsdaDims& d);
 int msda_forward_d32(int, int, const void*, const int64_t*, const int64_t*, const void*,
                      const void*, void*, MsdaDims, int variant, hipStream_t);
@@ -194,6 +196,12 @@ static bool use_tile_forward(int vdt, int ldt, const MsdaDims& d, int variant) {
   return variant >= 700 && variant <= 702;
 }
 
+// The second LDS-staged form (msda_d32_tile2.hip): variant 720 forces it, 710 / 730 forbid it.
+static bool use_tile2_forward(int vdt, int ldt, const MsdaDims& d, int variant) {
+  if (!msda_tile2_fwd_supported(vdt, ldt, d)) return false;
+  return variant == 720;
+}
+
 int vnx_msda_forward(int value_dtype, int loc_dtype, const void* value,
                      const int64_t* spatial_shapes, const int64_t* level_start_index,
                      const void* sampling_loc, const void* attn_weight, void* output, int batch,
@@ -210,6 +218,8 @@ int vnx_msda_forward(int value_dtype, int loc_dtype, const void* value,
   }
   hipStream_t stream = (hipStream_t)hip_stream;
   const int variant = g_kernel_variant;
+  if (use_tile2_forward(value_dtype, loc_dtype, d, variant))
+    return msda_forward_tile2(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, output, d, stream);
   if (use_tile_forward(value_dtype, loc_dtype, d, variant))
     return msda_forward_tile(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, output, d, nullptr,
                              variant >= 700 && variant <= 702 ? variant - 700 : 0, stream);
