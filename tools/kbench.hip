@@ -104,6 +104,18 @@ __global__ void to_fused(const float* loc, const float* attn, float* off, float*
     logit[s] = logf(fmaxf(attn[s], 1e-30f));
   }
 }
+// --dtype bf16: value / grad_out / out / grad_value in bf16 (locations and weights stay fp32: the autocast case, BASELINE config 3)
+__global__ void f32_to_bf16(const float* src, uint16_t* dst, size_t n) {
+  for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
+    uint32_t u = __float_as_uint(src[i]);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    dst[i] = uint16_t(u >> 16);
+  }
+}
+__global__ void bf16_to_f32(const uint16_t* src, float* dst, size_t n) {
+  for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x)
+    dst[i] = __uint_as_float(uint32_t(src[i]) << 16);
+}
 __global__ void fill_const(float* p, size_t n, float v) {
   for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) p[i] = v;
 }
@@ -232,10 +244,11 @@ extern "C" int vnx_debug_read_rec_stamps(unsigned long long* host, int n);
 struct Set {
   float *value, *loc, *attn, *go, *out, *gv, *gl, *ga, *off, *logit;
   void* ws;
+  uint16_t *value16, *go16, *out16, *gv16;     // --dtype bf16
 };
 
 int main(int argc, char** argv) {
-  std::string shape = "dec360", dist = "U", op = "fwd", variants = "0";
+  std::string shape = "dec360", dist = "U", op = "fwd", variants = "0", dtype = "f32";
   int B = 5, lq = 0, inner = 24, reps = 15, voff = 0;   // voff: floats added to every `value` base (alignment experiments)
   double warm_s = 0.06;
   bool check = false, cold_only = false, dma = false, stamps = false, timeline = false, hbm = false;
@@ -246,6 +259,7 @@ int main(int argc, char** argv) {
     else if (a == "--dist") dist = next();
     else if (a == "--op") op = next();
     else if (a == "--variants") variants = next();
+    else if (a == "--dtype") dtype = next();
     else if (a == "--B") B = atoi(next().c_str());
     else if (a == "--lq") lq = atoi(next().c_str());
     else if (a == "--inner") inner = atoi(next().c_str());
@@ -277,8 +291,11 @@ int main(int argc, char** argv) {
   const int M = 8, D = 32, L = 4, P = 4;
   const int Lq = lq > 0 ? lq : (shape.substr(0, 3) == "dec" ? 300 : S);
   const int idist = dist == "U" ? 0 : 1;
+  const bool b16 = dtype == "bf16";
+  const int VDT = b16 ? VNX_BF16 : VNX_F32;
+  const double ve = b16 ? 2.0 : 4.0;
   const size_t n_value = size_t(B) * S * M * D, n_s = size_t(B) * Lq * M * L * P, n_out = size_t(B) * Lq * M * D;
-  const double bytes_fwd = 4.0 * (n_value + 3 * n_s + n_out), bytes_bwd = 4.0 * (2 * n_value + n_out + 6 * n_s);
+  const double bytes_fwd = ve * (n_value + n_out) + 4.0 * 3 * n_s, bytes_bwd = ve * (2 * n_value + n_out) + 4.0 * 6 * n_s;
   const size_t set_bytes = 4 * (n_value + 3 * n_s + 2 * n_out);
   int nsets = int(std::max<size_t>(2, (size_t(320) << 20) / set_bytes + 1));
   nsets = std::min(nsets, inner);
@@ -293,12 +310,12 @@ int main(int argc, char** argv) {
       size_t c = variants.find(',', pos0);
       if (c == std::string::npos) c = variants.size();
       vnx_set_kernel_variant(atoi(variants.substr(pos0, c - pos0).c_str()));
-      ws_bytes = std::max(ws_bytes, vnx_msda_backward_workspace_bytes(VNX_F32, VNX_F32, B, S, M, D, L, Lq, P, VNX_MSDA_LEVELS_PACKED));
+      ws_bytes = std::max(ws_bytes, vnx_msda_backward_workspace_bytes(VDT, VNX_F32, B, S, M, D, L, Lq, P, VNX_MSDA_LEVELS_PACKED));
       pos0 = c + 1;
     }
     for (int v : {0, 1, 412}) {
       vnx_set_kernel_variant(v);
-      ws_bytes = std::max(ws_bytes, vnx_msda_backward_workspace_bytes(VNX_F32, VNX_F32, B, S, M, D, L, Lq, P, VNX_MSDA_LEVELS_PACKED));
+      ws_bytes = std::max(ws_bytes, vnx_msda_backward_workspace_bytes(VDT, VNX_F32, B, S, M, D, L, Lq, P, VNX_MSDA_LEVELS_PACKED));
     }
     vnx_set_kernel_variant(0);
   }
@@ -312,6 +329,13 @@ int main(int argc, char** argv) {
     hipLaunchKernelGGL(fill_gauss, dim3(2048), dim3(256), 0, 0, s.go, n_out, 917u + i);
     hipLaunchKernelGGL(fill_samples, dim3(2048), dim3(128), 0, 0, s.loc, s.attn, B, Lq, M, L, P, py, S, idist, 31u + 7u * i);
     s.off = s.logit = nullptr;
+    s.value16 = s.go16 = s.out16 = s.gv16 = nullptr;
+    if (b16) {
+      CK(hipMalloc(&s.value16, n_value * 2 + 4096)); CK(hipMalloc(&s.go16, n_out * 2)); CK(hipMalloc(&s.out16, n_out * 2));
+      CK(hipMalloc(&s.gv16, n_value * 2));
+      hipLaunchKernelGGL(f32_to_bf16, dim3(2048), dim3(256), 0, 0, s.value, s.value16, n_value);
+      hipLaunchKernelGGL(f32_to_bf16, dim3(2048), dim3(256), 0, 0, s.go, s.go16, n_out);
+    }
     if (op == "ffwd") {
       CK(hipMalloc(&s.off, n_s * 8)); CK(hipMalloc(&s.logit, n_s * 4));
       hipLaunchKernelGGL(to_fused, dim3(2048), dim3(256), 0, 0, s.loc, s.attn, s.off, s.logit, n_s, L, P, py);
@@ -323,7 +347,7 @@ int main(int argc, char** argv) {
     hipLaunchKernelGGL(fill_const, dim3(1024), dim3(256), 0, 0, refpts, size_t(B) * Lq * L * 2, 0.5f);
   }
   CK(hipDeviceSynchronize());
-  printf("shape=%s dist=%s B=%d Lq=%d S=%d points=%zu  alg MB fwd=%.1f bwd=%.1f  sets=%d inner=%d\n", shape.c_str(), dist.c_str(), B,
+  printf("shape=%s dtype=%s dist=%s B=%d Lq=%d S=%d points=%zu  alg MB fwd=%.1f bwd=%.1f  sets=%d inner=%d\n", shape.c_str(), dtype.c_str(), dist.c_str(), B,
          Lq, S, n_s, bytes_fwd / 1e6, bytes_bwd / 1e6, nsets, inner);
   hipStream_t st;
   CK(hipStreamCreate(&st));
@@ -332,11 +356,23 @@ int main(int argc, char** argv) {
       VK(vnx_msda_fused_forward(VNX_F32, VNX_F32, s.value, dshapes, dlsi, s.off, s.logit, refpts, s.out, B, S, M, D, L, Lq, P, 2, 1, st));
       return;
     }
+    if (b16) { VK(vnx_msda_forward(VNX_BF16, VNX_F32, s.value16, dshapes, dlsi, s.loc, s.attn, s.out16, B, S, M, D, L, Lq, P, st)); return; }
     VK(vnx_msda_forward(VNX_F32, VNX_F32, s.value, dshapes, dlsi, s.loc, s.attn, s.out, B, S, M, D, L, Lq, P, st));
   };
   auto bwd = [&](Set& s) {
+    if (b16) {
+      VK(vnx_msda_backward(VNX_BF16, VNX_F32, s.value16, dshapes, dlsi, s.loc, s.attn, s.go16, s.gv16, s.gl, s.ga, B, S, M, D, L, Lq, P,
+                           VNX_MSDA_LEVELS_PACKED, s.ws, ws_bytes, st));
+      return;
+    }
     VK(vnx_msda_backward(VNX_F32, VNX_F32, s.value, dshapes, dlsi, s.loc, s.attn, s.go, s.gv, s.gl, s.ga, B, S, M, D, L, Lq, P,
                          VNX_MSDA_LEVELS_PACKED, s.ws, ws_bytes, st));
+  };
+  // bf16 results of set 0 -> its fp32 buffers (for the cross-check)
+  auto widen = [&](Set& s, bool is_bwd) {
+    if (!b16) return;
+    if (!is_bwd) hipLaunchKernelGGL(bf16_to_f32, dim3(2048), dim3(256), 0, st, s.out16, s.out, n_out);
+    else hipLaunchKernelGGL(bf16_to_f32, dim3(2048), dim3(256), 0, st, s.gv16, s.gv, n_value);
   };
   // reference results from the generic kernels (variant 1) on set 0
   float *r_out = nullptr, *r_gv = nullptr, *r_gl = nullptr, *r_ga = nullptr, *dd = nullptr;
@@ -344,8 +380,8 @@ int main(int argc, char** argv) {
   if (check) {
     CK(hipMalloc(&r_out, n_out * 4)); CK(hipMalloc(&r_gv, n_value * 4)); CK(hipMalloc(&r_gl, n_s * 8)); CK(hipMalloc(&r_ga, n_s * 4));
     vnx_set_kernel_variant(1);
-    fwd(sets[0]);
-    if (op != "ffwd") bwd(sets[0]);
+    fwd(sets[0]); widen(sets[0], false);
+    if (op != "ffwd") { bwd(sets[0]); widen(sets[0], true); }
     CK(hipStreamSynchronize(st));
     CK(hipMemcpy(r_out, sets[0].out, n_out * 4, hipMemcpyDeviceToDevice)); CK(hipMemcpy(r_gv, sets[0].gv, n_value * 4, hipMemcpyDeviceToDevice));
     CK(hipMemcpy(r_gl, sets[0].gl, n_s * 8, hipMemcpyDeviceToDevice)); CK(hipMemcpy(r_ga, sets[0].ga, n_s * 4, hipMemcpyDeviceToDevice));
@@ -390,9 +426,9 @@ int main(int argc, char** argv) {
       if ((is_bwd && (op == "fwd" || op == "ffwd")) || (!is_bwd && op == "bwd")) continue;
       char chk[256] = "";
       if (check) {
-        if (!is_bwd) { fwd(sets[0]); CK(hipStreamSynchronize(st)); snprintf(chk, sizeof chk, " | relerr out %.2e", diff(sets[0].out, r_out, n_out)); }
+        if (!is_bwd) { fwd(sets[0]); widen(sets[0], false); CK(hipStreamSynchronize(st)); snprintf(chk, sizeof chk, " | relerr out %.2e", diff(sets[0].out, r_out, n_out)); }
         else {
-          bwd(sets[0]); CK(hipStreamSynchronize(st));
+          bwd(sets[0]); widen(sets[0], true); CK(hipStreamSynchronize(st));
           snprintf(chk, sizeof chk, " | relerr gv %.2e gloc %.2e gattn %.2e", diff(sets[0].gv, r_gv, n_value), diff(sets[0].gl, r_gl, 2 * n_s),
                    diff(sets[0].ga, r_ga, n_s));
         }

@@ -92,6 +92,38 @@ __device__ __forceinline__ void store_row4<f16_t>(f16_t* p, float4_t v) {
   __builtin_nontemporal_store(r, reinterpret_cast<uint2_t*>(p));
 }
 
+// 16-bit rows, 4 lanes x 16 B (LPR == 4): one lane holds 8 consecutive channels = 4 dwords of two elements each
+template <typename TV>
+__device__ __forceinline__ void unpack8(uint4_t r, float4_t& lo, float4_t& hi);
+template <>
+__device__ __forceinline__ void unpack8<bf16_t>(uint4_t r, float4_t& lo, float4_t& hi) {
+  lo = float4_t{__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u)};
+  hi = float4_t{__uint_as_float(r.z << 16), __uint_as_float(r.z & 0xffff0000u), __uint_as_float(r.w << 16), __uint_as_float(r.w & 0xffff0000u)};
+}
+template <>
+__device__ __forceinline__ void unpack8<f16_t>(uint4_t r, float4_t& lo, float4_t& hi) {
+  lo = float4_t{half_bits_to_float(r.x & 0xffffu), half_bits_to_float(r.x >> 16), half_bits_to_float(r.y & 0xffffu), half_bits_to_float(r.y >> 16)};
+  hi = float4_t{half_bits_to_float(r.z & 0xffffu), half_bits_to_float(r.z >> 16), half_bits_to_float(r.w & 0xffffu), half_bits_to_float(r.w >> 16)};
+}
+template <>
+__device__ __forceinline__ void unpack8<float>(uint4_t, float4_t&, float4_t&) {}      // never instantiated with LPR == 4
+template <typename TV>
+__device__ __forceinline__ uint4_t pack8(float4_t lo, float4_t hi);
+template <>
+__device__ __forceinline__ uint4_t pack8<bf16_t>(float4_t lo, float4_t hi) {
+  return uint4_t{uint32_t(f32_to_bf16_bits(lo.x)) | (uint32_t(f32_to_bf16_bits(lo.y)) << 16),
+                 uint32_t(f32_to_bf16_bits(lo.z)) | (uint32_t(f32_to_bf16_bits(lo.w)) << 16),
+                 uint32_t(f32_to_bf16_bits(hi.x)) | (uint32_t(f32_to_bf16_bits(hi.y)) << 16),
+                 uint32_t(f32_to_bf16_bits(hi.z)) | (uint32_t(f32_to_bf16_bits(hi.w)) << 16)};
+}
+template <>
+__device__ __forceinline__ uint4_t pack8<f16_t>(float4_t lo, float4_t hi) {
+  return uint4_t{float_to_half_bits(lo.x) | (float_to_half_bits(lo.y) << 16), float_to_half_bits(lo.z) | (float_to_half_bits(lo.w) << 16),
+                 float_to_half_bits(hi.x) | (float_to_half_bits(hi.y) << 16), float_to_half_bits(hi.z) | (float_to_half_bits(hi.w) << 16)};
+}
+template <>
+__device__ __forceinline__ uint4_t pack8<float>(float4_t, float4_t) { return uint4_t{0u, 0u, 0u, 0u}; }
+
 // -----------------------------------------------------------------------------
 // forward
 // -----------------------------------------------------------------------------
@@ -212,18 +244,22 @@ __device__ __forceinline__ void fused_decode(const TL* __restrict__ raw_off, con
 // PF: stream this wave's share of the head's rows towards L2 while the locations are in flight
 // (see "phase 0" below); built for the one-pass case (QPW * L*P <= 64), unfused.
 constexpr int kPfSteps = 3;       // LDS-DMA instructions per wave, 32 rows (2 x 64-B halves) each
-template <typename TV, typename TL, int QPW, int WPB, int LP_T, bool FUSED = false, bool PF = false>
+// LPR = lanes per row.  8: a row is 8 x 16 B (fp32) or 8 x 8 B (16-bit values: the round-1 map, as many load
+// instructions and L1 cycles as fp32 -- bf16 bought nothing).  4: 16-bit rows as 4 x 16 B -- a wave instruction
+// covers 16 rows instead of 8, a sample's four taps cost a lane 4 loads of 16 B instead of 8 of 8 B (L*P == 16 only).
+template <typename TV, typename TL, int QPW, int WPB, int LP_T, bool FUSED = false, bool PF = false, int LPR = 8>
 __global__ void VNX_FWD_BOUNDS(64 * WPB)
 msda_fwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ shapes,
                     const int64_t* __restrict__ lsi, const TL* __restrict__ loc,
                     const TL* __restrict__ attn, TV* __restrict__ out, MsdaDims d,
                     int tiles_per_batch, int prefetch_rows, unsigned long long* stamps, FusedArgs fa) {
   static_assert(!FUSED || LP_T == 16, "the fused prologue is built for L*P == 16");
+  static_assert(LPR == 8 || (LPR == 4 && sizeof(TV) == 2 && LP_T == 16 && !PF), "4 lanes per row: 16-bit values, L*P == 16");
   stamp_begin(stamps);
   constexpr int D = 32;
-  constexpr int PG = 8 / QPW;            // sample groups per query
+  constexpr int PG = (64 / LPR) / QPW;   // sample groups per query
   constexpr int kRowBytes = D * int(sizeof(TV));
-  constexpr int kLaneBytes = kRowBytes / 8;
+  constexpr int kLaneBytes = kRowBytes / LPR;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int LP = LP_T > 0 ? LP_T : d.L * d.P;
@@ -366,15 +402,64 @@ msda_fwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
   __builtin_amdgcn_wave_barrier();
 
   // ---- phase 2: gather ----------------------------------------------------------
-  const int ch = lane & 7;
-  const int qi = (lane >> 3) % QPW;
-  const int pg = lane / (8 * QPW);
+  const int ch = lane & (LPR - 1);
+  const int qi = (lane / LPR) % QPW;
+  const int pg = lane / (LPR * QPW);
   const int q = q0 + qi;
 
   const int per_group = LP / PG;  // host guarantees LP % PG == 0
   const uint4_t* g_off = s_off + qi * (LP + 1) + pg * per_group;
   const float4_t* g_wt = s_wt + qi * (LP + 1) + pg * per_group;
   const uint32_t lane_off = uint32_t(ch * kLaneBytes);
+
+  if constexpr (LPR == 4) {
+    // 16-bit rows, 8 channels per lane: the taps stay packed (4 dwords) until they are used
+    constexpr int kPer = LP_T / PG;
+    constexpr int kWant = WPB == 1 ? VNX_FWD_BATCH : 2;
+    constexpr int kBatch = kPer < kWant ? kPer : kWant;
+    static_assert(kPer % kBatch == 0, "whole batches");
+    float4_t acc_lo = {0.f, 0.f, 0.f, 0.f}, acc_hi = acc_lo;
+#pragma unroll
+    for (int i0 = 0; i0 < kPer; i0 += kBatch) {
+      uint4_t o[kBatch];
+      float4_t w[kBatch];
+      uint4_t raw[kBatch][4];
+#pragma unroll
+      for (int j = 0; j < kBatch; ++j) { o[j] = g_off[i0 + j]; w[j] = g_wt[i0 + j]; }
+#pragma unroll
+      for (int j = 0; j < kBatch; ++j) {
+        raw[j][0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, int(o[j].x + lane_off), 0, 0);
+        raw[j][1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, int(o[j].y + lane_off), 0, 0);
+        raw[j][2] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, int(o[j].z + lane_off), 0, 0);
+        raw[j][3] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, int(o[j].w + lane_off), 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < kBatch; ++j) {
+        const float wt[4] = {w[j].x, w[j].y, w[j].z, w[j].w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          float4_t lo, hi;
+          unpack8<TV>(raw[j][t], lo, hi);
+          acc_lo += wt[t] * lo;
+          acc_hi += wt[t] * hi;
+        }
+      }
+    }
+#pragma unroll
+    for (int off = LPR * QPW; off < 64; off <<= 1) {
+      acc_lo.x += __shfl_xor(acc_lo.x, off, 64); acc_lo.y += __shfl_xor(acc_lo.y, off, 64);
+      acc_lo.z += __shfl_xor(acc_lo.z, off, 64); acc_lo.w += __shfl_xor(acc_lo.w, off, 64);
+      acc_hi.x += __shfl_xor(acc_hi.x, off, 64); acc_hi.y += __shfl_xor(acc_hi.y, off, 64);
+      acc_hi.z += __shfl_xor(acc_hi.z, off, 64); acc_hi.w += __shfl_xor(acc_hi.w, off, 64);
+    }
+    if (pg == 0 && q < d.Lq) {
+      TV* o = out + ((int64_t(b) * d.Lq + q) * d.M + m) * D + ch * 8;
+      __builtin_nontemporal_store(pack8<TV>(acc_lo, acc_hi), reinterpret_cast<uint4_t*>(o));
+    }
+    stamp_end(stamps);
+    return;
+  }
 
   float4_t acc = {0.f, 0.f, 0.f, 0.f};
   if constexpr (LP_T > 0 && QPW <= 4) {
@@ -450,6 +535,7 @@ static FwdCfg pick_fwd_cfg(const MsdaDims& d, int variant) {
   FwdCfg c{8, 4};
   if (variant >= 20 && variant < 60) variant = (variant - 20) % 20;  // prefetch on/off wrappers
   if (variant >= 60 && variant < 69) variant = 13;
+  if (variant == 69) variant = 0;                                    // automatic configuration, 8-lane map for 16-bit rows
   if (variant >= 2 && variant <= 5) c = FwdCfg{8 >> (variant - 2), 4};
   else if (variant >= 12 && variant <= 15) c = FwdCfg{8 >> (variant - 12), 1};
   else {
@@ -499,7 +585,14 @@ static int launch_fwd_cfg(const void* value, const int64_t* shapes, const int64_
       return check_launch("msda_fwd_d32_pf");
     }
   }
-  if (LP == 16)
+  // 16-bit values: rows as 4 lanes x 16 B (variant 69 keeps the 8 x 8 B map for A/B runs)
+  constexpr int kLpr = sizeof(TV) == 2 ? 4 : 8;
+  if (LP == 16 && kLpr == 4 && variant != 69)
+    hipLaunchKernelGGL((msda_fwd_d32_kernel<TV, TL, QPW, WPB, 16, false, false, kLpr>), dim3(uint32_t(blocks)),
+                       dim3(64 * WPB), lds, stream, (const TV*)value, shapes, lsi,
+                       (const TL*)loc, (const TL*)attn, (TV*)out, d, tiles_per_batch, prefetch_rows,
+                       take_stamp_region(kStampFwd, blocks), FusedArgs{});
+  else if (LP == 16)
     hipLaunchKernelGGL((msda_fwd_d32_kernel<TV, TL, QPW, WPB, 16>), dim3(uint32_t(blocks)),
                        dim3(64 * WPB), lds, stream, (const TV*)value, shapes, lsi,
                        (const TL*)loc, (const TL*)attn, (TV*)out, d, tiles_per_batch, prefetch_rows,
@@ -587,6 +680,23 @@ __device__ __forceinline__ void group8_sum4(float4_t& v) {
   v = float4_t{a, b, c, d};
 }
 
+// the 4-lane form (rows of 16-bit values as 4 lanes x 16 B): two quad permutes
+__device__ __forceinline__ void group4_sum4(float4_t& v) {
+  float a = v.x, b = v.y, c = v.z, d = v.w;
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+      : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+  v = float4_t{a, b, c, d};
+}
+
 template <typename TV>
 __device__ __forceinline__ float4_t load_row4(const TV* p);
 template <>
@@ -625,7 +735,7 @@ __device__ __forceinline__ void store_loc(TL* p, float v) { *p = from_acc<TL>(v)
 //      cuh:376-394, become 9 DPP adds).
 // grad_value accumulates in fp32 (`gv`: grad_value itself for fp32, the workspace
 // image for 16-bit values), laid out [B,S,M,32] fp32.
-template <typename TV, typename TL, int QPW, int WPB, int LP_T, bool ATOMICS, bool FUSED = false>
+template <typename TV, typename TL, int QPW, int WPB, int LP_T, bool ATOMICS, bool FUSED = false, int LPR = 8>
 __global__ void VNX_K1_BOUNDS(64 * WPB)
 msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ shapes,
                     const int64_t* __restrict__ lsi, const TL* __restrict__ loc,
@@ -635,11 +745,12 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
                     uint32_t* __restrict__ sample_units, uint32_t* __restrict__ tile_summary, int units_min,
                     unsigned long long* stamps, FusedArgs fa) {
   static_assert(!FUSED || (LP_T == 16 && !ATOMICS), "the fused prologue is built for L*P == 16, record-fed grad_value");
+  static_assert(LPR == 8 || (LPR == 4 && sizeof(TV) == 2 && LP_T == 16 && !ATOMICS), "4 lanes per row: 16-bit values, L*P == 16");
   stamp_begin(stamps);
   constexpr int D = 32;
-  constexpr int PG = 8 / QPW;
+  constexpr int PG = (64 / LPR) / QPW;
   constexpr int kRowBytes = D * int(sizeof(TV));
-  constexpr int kLaneBytes = kRowBytes / 8;
+  constexpr int kLaneBytes = kRowBytes / LPR;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int LP = LP_T > 0 ? LP_T : d.L * d.P;
@@ -784,9 +895,9 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
   }
 
   // ---- phase 2 ------------------------------------------------------------------
-  const int ch = lane & 7;
-  const int qi = (lane >> 3) % QPW;
-  const int pg = lane / (8 * QPW);
+  const int ch = lane & (LPR - 1);
+  const int qi = (lane / LPR) % QPW;
+  const int pg = lane / (LPR * QPW);
   const int q = q0 + qi;
 
   const int64_t head_elem = (int64_t(b) * d.S * d.M + m) * D;
@@ -796,13 +907,61 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
   const __amdgpu_buffer_rsrc_t vsrc = uniform_rsrc(vbase, head_elems * uint32_t(sizeof(TV)));
   const __amdgpu_buffer_rsrc_t gsrc = uniform_rsrc(gbase, head_elems * 4u);
 
-  float4_t top = {0.f, 0.f, 0.f, 0.f};
-  if (q < d.Lq) top = load_row4<TV>(grad_out + ((int64_t(b) * d.Lq + q) * d.M + m) * D + ch * 4);
-
   const int per_group = LP / PG;
   const uint4_t* g_off = s_off + qi * (LP + 1) + pg * per_group;
   const float4_t* g_geo = s_geo + qi * (LP + 1) + pg * per_group;
   float4_t* g_res = s_res + qi * (LP + 1) + pg * per_group;
+
+  if constexpr (LPR == 4) {
+    // 16-bit rows as 4 lanes x 16 B: 8 channels of grad_out and of every tap per lane, the four dots of a sample
+    // reduced over 4 lanes (two quad permutes) instead of 8
+    float4_t t_lo = {0.f, 0.f, 0.f, 0.f}, t_hi = t_lo;
+    if (q < d.Lq) {
+      const uint4_t r = *reinterpret_cast<const uint4_t*>(grad_out + ((int64_t(b) * d.Lq + q) * d.M + m) * D + ch * 8);
+      unpack8<TV>(r, t_lo, t_hi);
+    }
+    const float2_t ta = {t_lo.x, t_lo.y}, tb = {t_lo.z, t_lo.w}, tc = {t_hi.x, t_hi.y}, td = {t_hi.z, t_hi.w};
+    auto dot8 = [&](const uint4_t raw) {
+      float4_t lo, hi;
+      unpack8<TV>(raw, lo, hi);
+      float2_t a2 = ta * float2_t{lo.x, lo.y};
+      a2 = tb * float2_t{lo.z, lo.w} + a2;
+      a2 = tc * float2_t{hi.x, hi.y} + a2;
+      a2 = td * float2_t{hi.z, hi.w} + a2;
+      return a2.x + a2.y;
+    };
+    constexpr int kPer = LP_T / PG;
+    constexpr int kWant = WPB == 1 ? VNX_K1_BATCH : VNX_K1_BATCH_LARGE;
+    constexpr int kBatch = kPer < kWant ? kPer : kWant;
+    static_assert(kPer % kBatch == 0, "whole batches");
+    const uint32_t lane_off = uint32_t(ch * kLaneBytes);
+#pragma unroll
+    for (int i0 = 0; i0 < kPer; i0 += kBatch) {
+      uint4_t o[kBatch];
+      uint4_t raw[kBatch][4];
+#pragma unroll
+      for (int j = 0; j < kBatch; ++j) o[j] = g_off[i0 + j];
+#pragma unroll
+      for (int j = 0; j < kBatch; ++j) {
+        raw[j][0] = __builtin_amdgcn_raw_buffer_load_b128(vsrc, int(o[j].x * 2u + lane_off), 0, 0);
+        raw[j][1] = __builtin_amdgcn_raw_buffer_load_b128(vsrc, int(o[j].y * 2u + lane_off), 0, 0);
+        raw[j][2] = __builtin_amdgcn_raw_buffer_load_b128(vsrc, int(o[j].z * 2u + lane_off), 0, 0);
+        raw[j][3] = __builtin_amdgcn_raw_buffer_load_b128(vsrc, int(o[j].w * 2u + lane_off), 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < kBatch; ++j) {
+        float4_t dd = {dot8(raw[j][0]), dot8(raw[j][1]), dot8(raw[j][2]), dot8(raw[j][3])};
+        group4_sum4(dd);
+        if (ch == 0) g_res[i0 + j] = dd;
+      }
+    }
+  }
+
+  float4_t top = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (LPR == 8) {
+    if (q < d.Lq) top = load_row4<TV>(grad_out + ((int64_t(b) * d.Lq + q) * d.M + m) * D + ch * 4);
+  }
 
   // one sample: the three scalar gradients from its four taps (+ the grad_value atomics of the general path)
   auto one_sample = [&](int i, const uint4_t o, const float4_t geo, const float4_t v1, const float4_t v2,
@@ -839,7 +998,9 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
     }
   };
   auto tap = [&](uint32_t elem_off) { return load_tap<TV>(vsrc, elem_off * uint32_t(sizeof(TV)) + ch * kLaneBytes); };
-  if constexpr (LP_T > 0 && !ATOMICS) {
+  if constexpr (LPR == 4) {
+    // done above
+  } else if constexpr (LP_T > 0 && !ATOMICS) {
     // As in the forward: the row loads of a whole batch of samples are issued before the first use.  (Left
     // to the compiler this loop waited for four loads at a time, eight dependent memory round trips per
     // wave at the decoder shape: 10.9 us per workgroup against the forward's 6.2.)
@@ -969,8 +1130,9 @@ static int launch_bwd_cfg(const void* value, const int64_t* shapes, const int64_
   // grad_value kernel reads them
   void* unit_ids = (records != nullptr && d.P == 4) ? (void*)((char*)records + gv_unit_ids_offset(d)) : nullptr;
   const int units_min = gv_units_min(d);
+  constexpr int kLpr = sizeof(TV) == 2 ? 4 : 8;    // 16-bit rows as 4 lanes x 16 B (variant 69 passes through launch_bwd as 169: 8 x 8 B)
 #define VNX_LAUNCH(LPT, AT)                                                                     \
-  hipLaunchKernelGGL((msda_bwd_d32_kernel<TV, TL, QPW, WPB, LPT, AT>), dim3(uint32_t(blocks)),   \
+  hipLaunchKernelGGL((msda_bwd_d32_kernel<TV, TL, QPW, WPB, LPT, AT, false, ((LPT) == 16 && !(AT)) ? kLpr : 8>), dim3(uint32_t(blocks)),   \
                      dim3(64 * WPB), lds, stream, (const TV*)value, shapes, lsi, (const TL*)loc, \
                      (const TL*)attn, (const TV*)grad_out, (float*)gv, (TL*)grad_loc,            \
                      (TL*)grad_attn, d, tiles_per_batch, (uint4_t*)records, (uint32_t*)unit_ids,                \
@@ -1043,7 +1205,8 @@ static int launch_fwd_fused_cfg(const void* value, const int64_t* shapes, const 
     return VNX_ERR_UNSUPPORTED;
   }
   const size_t lds = size_t(WPB) * 2 * QPW * 17 * 16;
-  hipLaunchKernelGGL((msda_fwd_d32_kernel<TV, TL, QPW, WPB, 16, true>), dim3(uint32_t(blocks)), dim3(64 * WPB), lds,
+  constexpr int kLpr = sizeof(TV) == 2 ? 4 : 8;
+  hipLaunchKernelGGL((msda_fwd_d32_kernel<TV, TL, QPW, WPB, 16, true, false, kLpr>), dim3(uint32_t(blocks)), dim3(64 * WPB), lds,
                      stream, (const TV*)value, shapes, lsi, (const TL*)raw_off, (const TL*)raw_logit, (TV*)out, d,
                      tiles_per_batch, 0, take_stamp_region(kStampFwd, blocks), fa);
   return check_launch("msda_fwd_d32_fused");
@@ -1062,7 +1225,8 @@ static int launch_bwd_fused_cfg(const void* value, const int64_t* shapes, const 
   const size_t lds = size_t(WPB) * 3 * QPW * 17 * 16 + 64;
   void* unit_ids = (records != nullptr && d.P == 4) ? (void*)((char*)records + gv_unit_ids_offset(d)) : nullptr;
   const int units_min = gv_units_min(d);
-  hipLaunchKernelGGL((msda_bwd_d32_kernel<TV, TL, QPW, WPB, 16, false, true>), dim3(uint32_t(blocks)), dim3(64 * WPB),
+  constexpr int kLpr = sizeof(TV) == 2 ? 4 : 8;
+  hipLaunchKernelGGL((msda_bwd_d32_kernel<TV, TL, QPW, WPB, 16, false, true, kLpr>), dim3(uint32_t(blocks)), dim3(64 * WPB),
                      lds, stream, (const TV*)value, shapes, lsi, (const TL*)raw_off, (const TL*)raw_logit,
                      (const TV*)grad_out, (float*)nullptr, (TL*)grad_off, (TL*)grad_logit, d, tiles_per_batch,
                      (uint4_t*)records, (uint32_t*)unit_ids, (uint32_t*)nullptr, units_min,
