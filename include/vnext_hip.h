@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define VNX_ABI_VERSION 9
+#define VNX_ABI_VERSION 10
 
 /* element types */
 enum {
@@ -158,8 +158,8 @@ int vnx_msda_fused_forward(int value_dtype, int query_dtype, const void* value, 
                            const void* attention_logits, const void* reference_points, void* output,
                            int batch, int spatial_size, int num_heads, int channels, int num_levels,
                            int num_query, int num_point, int ref_dim, int reference_batch_div, void* hip_stream);
-size_t vnx_msda_fused_backward_workspace_bytes(int batch, int num_heads, int num_levels, int num_query,
-                                               int num_point);
+size_t vnx_msda_fused_backward_workspace_bytes(int value_dtype, int batch, int spatial_size, int num_heads,
+                                               int num_levels, int num_query, int num_point);
 int vnx_msda_fused_backward(int value_dtype, int query_dtype, const void* value, const int64_t* spatial_shapes,
                             const int64_t* level_start_index, const void* sampling_offsets,
                             const void* attention_logits, const void* reference_points, const void* grad_output,

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libvnext_hip.so")
 
 VNX_F32, VNX_F64, VNX_BF16, VNX_F16 = 0, 1, 2, 3
 VNX_OK = 0
-ABI_VERSION = 9
+ABI_VERSION = 10
 MSDA_LEVELS_PACKED = 1
 
 _vp, _i, _sz, _ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_longlong
@@ -28,7 +28,7 @@ SIGNATURES = {
     "vnx_msda_backward_workspace_bytes": (_sz, [_i] * 10),
     "vnx_msda_backward": (_i, [_i, _i] + [_vp] * 9 + [_i] * 8 + [_vp, _sz, _vp]),
     "vnx_msda_fused_forward": (_i, [_i, _i] + [_vp] * 7 + [_i] * 9 + [_vp]),
-    "vnx_msda_fused_backward_workspace_bytes": (_sz, [_i] * 5),
+    "vnx_msda_fused_backward_workspace_bytes": (_sz, [_i] * 7),
     "vnx_msda_fused_backward": (_i, [_i, _i] + [_vp] * 11 + [_i] * 9 + [_vp, _sz, _vp]),
     "vnx_dynamic_mask_head_forward": (_i, [_i] + [_vp] * 5 + [_i] * 7 + [_vp]),
     "vnx_dynamic_mask_head_backward": (_i, [_i] + [_vp] * 8 + [_i] * 7 + [_vp]),

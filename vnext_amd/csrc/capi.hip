@@ -55,7 +55,7 @@ bool msda_d32_gvtiles_supported(int vdt, int ldt, const MsdaDims& d);
 size_t msda_gvtiles_summary_bytes(const MsdaDims& d, int tile_queries);
 int msda_backward_gvtiles_d32(int vdt, int ldt, const int64_t*, const int64_t*, const void* loc, const void* attn,
                               const void* summaries, const void* grad_out, void* grad_value, MsdaDims,
-                              int tile_queries, hipStream_t);
+                              int tile_queries, float* split_image, hipStream_t);
 bool msda_d32_fused_supported(int vdt, int ldt, const MsdaDims& d);
 int msda_fused_d32(bool backward, int vdt, int ldt, const void* value, const int64_t* shapes, const int64_t* lsi,
                    const void* raw_off, const void* raw_logit, const void* grad_out, void* out_or_grad_off,
@@ -64,7 +64,9 @@ int msda_fused_d32(bool backward, int vdt, int ldt, const void* value, const int
 bool msda_d32_gvrec_supported(int vdt, int ldt, const MsdaDims& d);
 size_t msda_gvrec_record_bytes(const MsdaDims& d);
 int msda_backward_gvrec_d32(int vdt, const int64_t*, const int64_t*, const void* records, const void*,
-                            void*, MsdaDims, int variant, hipStream_t);
+                            void*, MsdaDims, int variant, float* split_image, hipStream_t);
+int msda_split_levels_convert(int vdt, const int64_t*, const int64_t*, const float* image, void* grad_value, MsdaDims,
+                              hipStream_t);
 
 static int check_common(const char* fn, int vdt, int ldt, const void* value,
                         const int64_t* shapes, const int64_t* lsi, const void* loc,
@@ -248,6 +250,12 @@ static bool use_tiles(int vdt, int ldt, const MsdaDims& d, int variant) {
   if (d.P != 4 || d.L * d.P != 16 || !msda_d32_gvtiles_supported(vdt, ldt, d)) return false;
   return variant == 431 || d.Lq >= 1024;
 }
+// 16-bit values with enough queries for the query split of the coarse levels (gv_query_splits): the pieces of such a
+// level meet through fp32 atomics, which need an fp32 target -- the same [B, S, M, 32] fp32 image the general path of
+// unpacked levels uses (the two never run on the same call: one needs packed levels, the other unpacked ones).
+static bool split_image_needed(int vdt, const MsdaDims& d) {
+  return (vdt == VNX_BF16 || vdt == VNX_F16) && d.P == 4 && d.Lq >= 1024;
+}
 static size_t fast_path_scratch_bytes(int vdt, int ldt, const MsdaDims& d, int variant) {
   if (use_tiles(vdt, ldt, d, variant)) return align256(msda_gvtiles_summary_bytes(d, msda_bwd_tile_queries(d, variant)));
   return align256(msda_gvrec_record_bytes(d));
@@ -262,8 +270,8 @@ size_t vnx_msda_backward_workspace_bytes(int value_dtype, int loc_dtype, int bat
   const size_t image = sixteen ? sizeof(float) * size_t(batch) * size_t(spatial_size) * size_t(num_heads) * size_t(channels) : 0;
   if (!bwd_fast_path(value_dtype, loc_dtype, d, variant)) return image;
   const size_t records = fast_path_scratch_bytes(value_dtype, loc_dtype, d, variant);
-  // packed levels promised: the general path never runs, no fp32 image
-  return records + ((flags & VNX_MSDA_LEVELS_PACKED) ? 0 : image);
+  // packed levels promised: the general path never runs, no fp32 image -- unless the query split needs it
+  return records + (((flags & VNX_MSDA_LEVELS_PACKED) && !split_image_needed(value_dtype, d)) ? 0 : image);
 }
 
 int vnx_msda_backward(int value_dtype, int loc_dtype, const void* value,
@@ -321,14 +329,16 @@ int vnx_msda_backward(int value_dtype, int loc_dtype, const void* value,
     const size_t rec_bytes = fast_path_scratch_bytes(value_dtype, loc_dtype, d, variant);
     void* records = tiles ? nullptr : workspace;
     void* tile_words = tiles ? workspace : nullptr;
-    void* image = (sixteen && !(flags & VNX_MSDA_LEVELS_PACKED)) ? (void*)((char*)workspace + rec_bytes) : nullptr;
+    const bool split16 = split_image_needed(value_dtype, d);
+    void* image = (sixteen && (!(flags & VNX_MSDA_LEVELS_PACKED) || split16)) ? (void*)((char*)workspace + rec_bytes) : nullptr;
+    float* split_image = split16 ? (float*)image : nullptr;
     const bool only_gl = variant >= 100 && variant < 200;  // timing ablations
     const bool only_gv = (variant >= 400 && variant < 430) || (variant > 431 && variant < 500);
     // records / tile mode: the accumulation-image argument carries fp32 grad_value itself, whose rows of the
     // query-split levels the kernel zeroes (gv_query_splits)
     st = msda_backward_d32(value_dtype, loc_dtype, value, spatial_shapes, level_start_index,
                            sampling_loc, attn_weight, grad_output,
-                           value_dtype == VNX_F32 ? grad_value : nullptr, grad_sampling_loc,
+                           value_dtype == VNX_F32 ? grad_value : (void*)split_image, grad_sampling_loc,
                            grad_attn_weight, d, only_gl ? variant : 100 + (variant < 100 ? variant : 0),
                            records, tile_words, stream);
     if (st != VNX_OK) return st;
@@ -336,11 +346,15 @@ int vnx_msda_backward(int value_dtype, int loc_dtype, const void* value,
       if (tiles)
         st = msda_backward_gvtiles_d32(value_dtype, loc_dtype, spatial_shapes, level_start_index, sampling_loc,
                                        attn_weight, tile_words, grad_output, grad_value, d,
-                                       msda_bwd_tile_queries(d, variant), stream);
+                                       msda_bwd_tile_queries(d, variant), split_image, stream);
       else
         st = msda_backward_gvrec_d32(value_dtype, spatial_shapes, level_start_index, records, grad_output,
-                                     grad_value, d, variant, stream);
+                                     grad_value, d, variant, split_image, stream);
       if (st != VNX_OK) return st;
+      if (split_image) {
+        st = msda_split_levels_convert(value_dtype, spatial_shapes, level_start_index, split_image, grad_value, d, stream);
+        if (st != VNX_OK) return st;
+      }
     }
     if (!(flags & VNX_MSDA_LEVELS_PACKED) && !only_gl && !only_gv) {
       void* gv_acc = sixteen ? image : grad_value;
@@ -429,10 +443,11 @@ int vnx_msda_fused_forward(int value_dtype, int query_dtype, const void* value, 
                         reference_batch_div, nullptr, (hipStream_t)hip_stream);
 }
 
-size_t vnx_msda_fused_backward_workspace_bytes(int batch, int num_heads, int num_levels, int num_query,
-                                               int num_point) {
-  const MsdaDims d{batch, 0, num_heads, 32, num_levels, num_query, num_point};
-  return align256(msda_gvrec_record_bytes(d));
+size_t vnx_msda_fused_backward_workspace_bytes(int value_dtype, int batch, int spatial_size, int num_heads, int num_levels,
+                                               int num_query, int num_point) {
+  const MsdaDims d{batch, spatial_size, num_heads, 32, num_levels, num_query, num_point};
+  const size_t image = split_image_needed(value_dtype, d) ? sizeof(float) * size_t(batch) * size_t(spatial_size) * num_heads * 32 : 0;
+  return align256(msda_gvrec_record_bytes(d)) + image;
 }
 
 int vnx_msda_fused_backward(int value_dtype, int query_dtype, const void* value, const int64_t* spatial_shapes,
@@ -465,7 +480,10 @@ int vnx_msda_fused_backward(int value_dtype, int query_dtype, const void* value,
     set_error("vnx_msda_fused_backward: null pointer argument");
     return VNX_ERR_INVALID_ARGUMENT;
   }
-  const size_t need = align256(msda_gvrec_record_bytes(d));
+  const size_t rec_bytes = align256(msda_gvrec_record_bytes(d));
+  const bool split16 = split_image_needed(value_dtype, d);
+  const size_t need = rec_bytes + (split16 ? sizeof(float) * size_t(batch) * size_t(spatial_size) * num_heads * 32 : 0);
+  float* split_image = split16 ? (float*)((char*)workspace + rec_bytes) : nullptr;
   if (!workspace || workspace_bytes < need) {
     set_error("vnx_msda_fused_backward: workspace of %zu bytes needed (got %zu)", need, workspace_bytes);
     return VNX_ERR_WORKSPACE;
@@ -475,10 +493,14 @@ int vnx_msda_fused_backward(int value_dtype, int query_dtype, const void* value,
   st = msda_fused_d32(true, value_dtype, query_dtype, value, spatial_shapes, level_start_index, sampling_offsets,
                       attention_logits, grad_output, grad_sampling_offsets, grad_attention_logits, d, workspace,
                       reference_points, grad_reference_points, ref_dim, reference_batch_div,
-                      value_dtype == VNX_F32 ? grad_value : nullptr, stream);
+                      value_dtype == VNX_F32 ? grad_value : (void*)split_image, stream);
   if (st != VNX_OK) return st;
-  return msda_backward_gvrec_d32(value_dtype, spatial_shapes, level_start_index, workspace, grad_output,
-                                 grad_value, d, g_kernel_variant, stream);
+  st = msda_backward_gvrec_d32(value_dtype, spatial_shapes, level_start_index, workspace, grad_output,
+                               grad_value, d, g_kernel_variant, split_image, stream);
+  if (st != VNX_OK) return st;
+  if (split_image)
+    return msda_split_levels_convert(value_dtype, spatial_shapes, level_start_index, split_image, grad_value, d, stream);
+  return VNX_OK;
 }
 
 }  // extern "C"

@@ -771,7 +771,7 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
 
   // ---- phase 0: zero the grad_value rows of the query-split levels (gv_query_splits) of this (batch, head):
   //      the tiles of a batch element share the rows, eight rows per wave and step -----------------------
-  if constexpr (!ATOMICS && sizeof(TV) == 4) {
+  if constexpr (!ATOMICS) {      // (fp32 values: rows of grad_value itself; 16-bit values: rows of the fp32 split image)
     if (fa.qsplit_zero != nullptr && (sample_units != nullptr || tile_summary != nullptr) && d.Lq >= 1024 &&
         levels_packed(shapes, lsi, d.L, d.S)) {
       const int t_in_b = tile - b * tiles_per_batch;
@@ -1111,9 +1111,9 @@ static int launch_bwd_cfg(const void* value, const int64_t* shapes, const int64_
                           const void* loc, const void* attn, const void* grad_out, void* gv,
                           void* grad_loc, void* grad_attn, const MsdaDims& d, bool atomics,
                           void* records, void* tile_summary, hipStream_t stream) {
-  // records / tile mode: `gv` is not an accumulation image but fp32 grad_value itself (or null), whose rows of the
-  // query-split levels this kernel zeroes for the grad_value kernel's atomics
-  void* qsplit_zero = (!atomics && (records != nullptr || tile_summary != nullptr) && sizeof(TV) == 4) ? gv : nullptr;
+  // records / tile mode: `gv` is not an accumulation image but the fp32 target of the query-split levels' atomics --
+  // grad_value itself for fp32 values, the fp32 split image for 16-bit ones (or null) -- whose rows this kernel zeroes
+  void* qsplit_zero = (!atomics && (records != nullptr || tile_summary != nullptr)) ? gv : nullptr;
   if (tile_summary != nullptr && (d.L * d.P != 16 || d.P != 4 || atomics)) {
     set_error("msda_backward: tile mode needs 4 levels x 4 points");
     return VNX_ERR_UNSUPPORTED;
@@ -1260,8 +1260,9 @@ int msda_fused_d32(bool backward, int vdt, int ldt, const void* value, const int
                    const void* raw_off, const void* raw_logit, const void* grad_out, void* out_or_grad_off,
                    void* grad_logit, MsdaDims d, void* records, const void* reference, float* grad_reference,
                    int ref_dim, int ref_div, void* grad_value_f32, hipStream_t stream) {
-  const FusedArgs fa{reference, grad_reference, ref_dim, ref_div,
-                     (backward && vdt == VNX_F32) ? static_cast<float*>(grad_value_f32) : nullptr};
+  // grad_value_f32: the fp32 target of the query-split levels' atomics (grad_value itself for fp32 values, the split
+  // image for 16-bit ones), or null
+  const FusedArgs fa{reference, grad_reference, ref_dim, ref_div, backward ? static_cast<float*>(grad_value_f32) : nullptr};
 #define VNX_ARGS backward, value, shapes, lsi, raw_off, raw_logit, grad_out, out_or_grad_off, grad_logit, d, records, fa, stream
   if (vdt == VNX_F32) return fused_dispatch<float, float>(VNX_ARGS);
   if (vdt == VNX_BF16 && ldt == VNX_F32) return fused_dispatch<bf16_t, float>(VNX_ARGS);

@@ -334,7 +334,7 @@ __global__ void __launch_bounds__(kThreads, VNX_SEL_UNITS_PER_CU * kWaves / 4)
 msda_bwd_gv_sel_kernel(const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
                        const uint4_t* __restrict__ records, const uint32_t* __restrict__ unit_ids,
                        const TV* __restrict__ grad_out, TV* __restrict__ grad_value, MsdaDims d, int units_min,
-                       int units_bound, int debug) {
+                       float* __restrict__ split_image, int debug) {
   constexpr int D = 32, P = 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float4_t* grows = reinterpret_cast<float4_t*>(smem);                       // [128][8] grad_out rows
@@ -369,7 +369,7 @@ msda_bwd_gv_sel_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
     const int n = H * W;
     const GvSplit sp = gv_level_split(n, units_min);
     const int units = sp.units, rpu = sp.rpu;
-    const int qs = gv_query_splits(units, d.Lq, P, sizeof(TV) == 4, d.B * d.M);
+    const int qs = gv_query_splits(units, d.Lq, P, sizeof(TV) == 4 || split_image != nullptr, d.B * d.M);
     meta[4 * tid] = H; meta[4 * tid + 1] = W; meta[4 * tid + 2] = int(lsi[tid]);
     meta[4 * tid + 3] = units | (rpu << 12) | (qs << 24);     // units <= 4000, rpu <= 320, qs <= 8
   }
@@ -599,14 +599,17 @@ msda_bwd_gv_sel_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
   TV* out = grad_value + ((int64_t(b) * d.S + start + r0) * d.M + m) * D;
   const int te = opaque(tid);
   const int grp = te >> 3, ch4 = te & 7;
-  if constexpr (sizeof(TV) == 4) {
+  {
     if (qsplit > 1) {   // pieces of a query-split level meet through fp32 atomics (rows zeroed by the grad_loc kernel);
-                        // a group's 8 lanes x 4 dwords = one row's 32 consecutive dwords per instruction group
+                        // a group's 8 lanes x 4 dwords = one row's 32 consecutive dwords per instruction group.
+                        // 16-bit values: onto the fp32 split image, converted by split_levels_convert_kernel
+      float* out32 = (sizeof(TV) == 4 ? reinterpret_cast<float*>(grad_value) : split_image) +
+                     ((int64_t(b) * d.S + start + r0) * d.M + m) * D;
 #pragma unroll
       for (int k = 0; k < kRpg; ++k) {
         const int row = grp + k * kGroups;
         if (row < rows) {
-          float* p = reinterpret_cast<float*>(out) + __umul24(uint32_t(row), q_stride) + ch4 * 4;
+          float* p = out32 + __umul24(uint32_t(row), q_stride) + ch4 * 4;
           atomic_add(p, racc[k].x); atomic_add(p + 1, racc[k].y); atomic_add(p + 2, racc[k].z); atomic_add(p + 3, racc[k].w);
         }
       }
@@ -649,7 +652,7 @@ bool msda_d32_gvrec_supported(int vdt, int ldt, const MsdaDims& d) {
 template <typename TV>
 static int launch_gvrec(const int64_t* shapes, const int64_t* lsi, const void* records,
                         const void* grad_out, void* grad_value, const MsdaDims& d, int units_min,
-                        int debug, int mode, hipStream_t stream) {
+                        int debug, int mode, float* split_image, hipStream_t stream) {
   // mode 0: per-unit sample selection (P == 4); 3: register slab, every unit scans its level;
   // 1: the LDS-slab form (variants 425 / 420 select the last two)
   const int units_bound = msda_gvrec_units_bound(d, units_min);
@@ -658,7 +661,7 @@ static int launch_gvrec(const int64_t* shapes, const int64_t* lsi, const void* r
     const uint32_t* unit_ids = reinterpret_cast<const uint32_t*>((const char*)records + gv_unit_ids_offset(d));
     hipLaunchKernelGGL((rec::msda_bwd_gv_sel_kernel<TV>), dim3(uint32_t(blocks)), dim3(rec::kThreads),
                        rec::kSelLdsBytes, stream, shapes, lsi, (const rec::uint4_t*)records, unit_ids,
-                       (const TV*)grad_out, (TV*)grad_value, d, units_min, units_bound, debug);
+                       (const TV*)grad_out, (TV*)grad_value, d, units_min, split_image, debug);
     return check_launch("msda_bwd_gv_sel");
   }
 #define VNX_LAUNCH(PT, RS)                                                                             \
@@ -674,16 +677,55 @@ static int launch_gvrec(const int64_t* shapes, const int64_t* lsi, const void* r
 
 // grad_value from the sample records; a no-op on the device when the levels are not packed.
 int msda_backward_gvrec_d32(int vdt, const int64_t* shapes, const int64_t* lsi, const void* records,
-                            const void* grad_out, void* grad_value, MsdaDims d, int variant,
+                            const void* grad_out, void* grad_value, MsdaDims d, int variant, float* split_image,
                             hipStream_t stream) {
   // every level is split into at least gv_units_min(d) units (2: 19 units per (b, head) at 360p = 760
   // workgroups <= the 768 resident at 3 per CU -- one round; 4: 960 workgroups, 39.2 vs 37.3 us)
   const int units_min = gv_units_min(d);
-  if (vdt == VNX_F32) return launch_gvrec<float>(shapes, lsi, records, grad_out, grad_value, d, units_min, (variant == 408 ? 1 : variant == 412 ? 5 : 0), (variant == 420 ? 1 : variant == 425 ? 3 : 0), stream);
-  if (vdt == VNX_BF16) return launch_gvrec<bf16_t>(shapes, lsi, records, grad_out, grad_value, d, units_min, (variant == 408 ? 1 : variant == 412 ? 5 : 0), (variant == 420 ? 1 : variant == 425 ? 3 : 0), stream);
-  if (vdt == VNX_F16) return launch_gvrec<f16_t>(shapes, lsi, records, grad_out, grad_value, d, units_min, (variant == 408 ? 1 : variant == 412 ? 5 : 0), (variant == 420 ? 1 : variant == 425 ? 3 : 0), stream);
+  if (vdt == VNX_F32) return launch_gvrec<float>(shapes, lsi, records, grad_out, grad_value, d, units_min, (variant == 408 ? 1 : variant == 412 ? 5 : 0), (variant == 420 ? 1 : variant == 425 ? 3 : 0), split_image, stream);
+  if (vdt == VNX_BF16) return launch_gvrec<bf16_t>(shapes, lsi, records, grad_out, grad_value, d, units_min, (variant == 408 ? 1 : variant == 412 ? 5 : 0), (variant == 420 ? 1 : variant == 425 ? 3 : 0), split_image, stream);
+  if (vdt == VNX_F16) return launch_gvrec<f16_t>(shapes, lsi, records, grad_out, grad_value, d, units_min, (variant == 408 ? 1 : variant == 412 ? 5 : 0), (variant == 420 ? 1 : variant == 425 ? 3 : 0), split_image, stream);
   set_error("msda_backward_gvrec_d32: unsupported dtype %d", vdt);
   return VNX_ERR_INVALID_ARGUMENT;
+}
+
+// ---- 16-bit values: the rows of the query-split levels, accumulated in the fp32 split image, -> grad_value --------
+// (fp atomics need an fp32 target; every other row of a 16-bit grad_value is written once by its owner.  Without the
+//  split a coarse-level unit of a 16-bit encoder call sorted all 40 (360p) / 153 (720p) chunks of its level alone:
+//  bf16 encoder backward 231 vs 191 us fp32 at 360p, 703 vs 339 us at 720p B = 2.)
+template <typename TV>
+__global__ void __launch_bounds__(256)
+split_levels_convert_kernel(const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
+                            const float* __restrict__ image, TV* __restrict__ grad_value, MsdaDims d, int units_min) {
+  if (!levels_packed(shapes, lsi, d.L, d.S)) return;
+  const int64_t n4 = int64_t(d.B) * d.S * d.M * 8;       // pieces of 4 channels
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n4; i += int64_t(gridDim.x) * blockDim.x) {
+    const int s = int((i / (int64_t(d.M) * 8)) % d.S);
+    bool split = false;
+    for (int l = 0; l < d.L; ++l) {
+      const int st = int(lsi[l]), n = int(shapes[2 * l]) * int(shapes[2 * l + 1]);
+      if (s >= st && s < st + n) split = gv_query_splits(gv_level_split(n, units_min).units, d.Lq, d.P, true, d.B * d.M) > 1;
+    }
+    if (split) rec::store4<TV>(grad_value + i * 4, *reinterpret_cast<const rec::float4_t*>(image + i * 4));
+  }
+}
+
+int msda_split_levels_convert(int vdt, const int64_t* shapes, const int64_t* lsi, const float* image, void* grad_value,
+                              MsdaDims d, hipStream_t stream) {
+  const int units_min = gv_units_min(d);
+  const int64_t n4 = int64_t(d.B) * d.S * d.M * 8;
+  int64_t blocks = (n4 + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  if (blocks < 1) blocks = 1;
+  if (vdt == VNX_BF16)
+    hipLaunchKernelGGL((split_levels_convert_kernel<bf16_t>), dim3(uint32_t(blocks)), dim3(256), 0, stream, shapes, lsi, image,
+                       (bf16_t*)grad_value, d, units_min);
+  else if (vdt == VNX_F16)
+    hipLaunchKernelGGL((split_levels_convert_kernel<f16_t>), dim3(uint32_t(blocks)), dim3(256), 0, stream, shapes, lsi, image,
+                       (f16_t*)grad_value, d, units_min);
+  else
+    return VNX_OK;
+  return check_launch("split_levels_convert");
 }
 
 // development aid, not part of the public header

@@ -38,7 +38,8 @@ __global__ void __launch_bounds__(kThreads, VNX_SEL_UNITS_PER_CU * kWaves / 4)
 msda_bwd_gv_tiles_kernel(const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
                          const TL* __restrict__ loc, const TL* __restrict__ attn,
                          const uint32_t* __restrict__ summaries, const TV* __restrict__ grad_out,
-                         TV* __restrict__ grad_value, MsdaDims d, int units_min, int tile_shift, int n_tiles) {
+                         TV* __restrict__ grad_value, MsdaDims d, int units_min, int tile_shift, int n_tiles,
+                         float* __restrict__ split_image) {
   constexpr int D = 32, P = 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float4_t* grows = reinterpret_cast<float4_t*>(smem);                       // [128][8] grad_out rows
@@ -64,7 +65,7 @@ msda_bwd_gv_tiles_kernel(const int64_t* __restrict__ shapes, const int64_t* __re
   if (tid < d.L) {
     const int H = int(shapes[2 * tid]), W = int(shapes[2 * tid + 1]);
     const GvSplit sp = gv_level_split(H * W, units_min);
-    const int qs = gv_query_splits(sp.units, d.Lq, P, sizeof(TV) == 4, d.B * d.M);
+    const int qs = gv_query_splits(sp.units, d.Lq, P, sizeof(TV) == 4 || split_image != nullptr, d.B * d.M);
     meta[4 * tid] = H; meta[4 * tid + 1] = W; meta[4 * tid + 2] = int(lsi[tid]);
     meta[4 * tid + 3] = sp.units | (sp.rpu << 12) | (qs << 24);     // units <= 4000, rpu <= 320, qs <= 8
   }
@@ -280,13 +281,16 @@ msda_bwd_gv_tiles_kernel(const int64_t* __restrict__ shapes, const int64_t* __re
   TV* out = grad_value + ((int64_t(b) * d.S + start + r0) * d.M + m) * D;
   const int te = opaque(tid);
   const int grp = te >> 3, ch4 = te & 7;
-  if constexpr (sizeof(TV) == 4) {
-    if (qsplit > 1) {   // pieces of a query-split level meet through fp32 atomics (rows zeroed by the grad_loc kernel)
+  {
+    if (qsplit > 1) {   // pieces of a query-split level meet through fp32 atomics (rows zeroed by the grad_loc kernel):
+                        // on grad_value itself (fp32) or on the fp32 split image (16-bit values; converted afterwards)
+      float* out32 = (sizeof(TV) == 4 ? reinterpret_cast<float*>(grad_value) : split_image) +
+                     ((int64_t(b) * d.S + start + r0) * d.M + m) * D;
 #pragma unroll
       for (int k = 0; k < kRpg; ++k) {
         const int row = grp + k * kGroups;
         if (row < rows) {
-          float* p = reinterpret_cast<float*>(out) + __umul24(uint32_t(row), q_stride) + ch4 * 4;
+          float* p = out32 + __umul24(uint32_t(row), q_stride) + ch4 * 4;
           atomic_add(p, racc[k].x); atomic_add(p + 1, racc[k].y); atomic_add(p + 2, racc[k].z); atomic_add(p + 3, racc[k].w);
         }
       }
@@ -325,7 +329,7 @@ bool msda_d32_gvtiles_supported(int vdt, int ldt, const MsdaDims& d) {
 template <typename TV, typename TL>
 static int launch_gvtiles(const int64_t* shapes, const int64_t* lsi, const void* loc, const void* attn,
                           const void* summaries, const void* grad_out, void* grad_value, const MsdaDims& d,
-                          int units_min, int tile_queries, hipStream_t stream) {
+                          int units_min, int tile_queries, float* split_image, hipStream_t stream) {
   int tile_shift = 0;
   while ((1 << tile_shift) < tile_queries) ++tile_shift;
   if ((1 << tile_shift) != tile_queries || tile_queries > rec::kQcMax) {
@@ -336,16 +340,17 @@ static int launch_gvtiles(const int64_t* shapes, const int64_t* lsi, const void*
   const int64_t blocks = int64_t(d.B) * d.M * msda_gvrec_units_bound(d, units_min);
   hipLaunchKernelGGL((rec::msda_bwd_gv_tiles_kernel<TV, TL>), dim3(uint32_t(blocks)), dim3(rec::kThreads),
                      rec::kTilesLdsBytes, stream, shapes, lsi, (const TL*)loc, (const TL*)attn,
-                     (const uint32_t*)summaries, (const TV*)grad_out, (TV*)grad_value, d, units_min, tile_shift, n_tiles);
+                     (const uint32_t*)summaries, (const TV*)grad_out, (TV*)grad_value, d, units_min, tile_shift, n_tiles,
+                     split_image);
   return check_launch("msda_bwd_gv_tiles");
 }
 
 // grad_value from the op's inputs and the tile words; a no-op on the device when the levels are not packed.
 int msda_backward_gvtiles_d32(int vdt, int ldt, const int64_t* shapes, const int64_t* lsi, const void* loc,
                               const void* attn, const void* summaries, const void* grad_out, void* grad_value,
-                              MsdaDims d, int tile_queries, hipStream_t stream) {
+                              MsdaDims d, int tile_queries, float* split_image, hipStream_t stream) {
   const int units_min = gv_units_min(d);
-#define VNX_ARGS shapes, lsi, loc, attn, summaries, grad_out, grad_value, d, units_min, tile_queries, stream
+#define VNX_ARGS shapes, lsi, loc, attn, summaries, grad_out, grad_value, d, units_min, tile_queries, split_image, stream
   if (vdt == VNX_F32) return launch_gvtiles<float, float>(VNX_ARGS);
   if (vdt == VNX_BF16 && ldt == VNX_F32) return launch_gvtiles<bf16_t, float>(VNX_ARGS);
   if (vdt == VNX_BF16 && ldt == VNX_BF16) return launch_gvtiles<bf16_t, bf16_t>(VNX_ARGS);

@@ -214,7 +214,7 @@ def ms_deform_attn_fused_backward(value, spatial_shapes, level_start_index, samp
     glog = torch.empty_like(attention_logits)
     gref = torch.empty((B, Lq, L, 2), dtype=torch.float32, device=value.device) if want_reference_grad else None
     lib = _lib.lib()
-    n = lib.vnx_msda_fused_backward_workspace_bytes(B, M, L, Lq, P)
+    n = lib.vnx_msda_fused_backward_workspace_bytes(_DT[value.dtype], B, S, M, L, Lq, P)
     ws = torch.empty(max(n, 1), dtype=torch.uint8, device=value.device)
     with torch.cuda.device(value.device):
         st = lib.vnx_msda_fused_backward(
