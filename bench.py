@@ -203,14 +203,15 @@ def model_step_leg(rank, local_rank, world, device, steps, warmup=3, clips_per_r
     torch.manual_seed(0)
     cfg = get_seqformer_cfg(**{"MODEL.DEVICE": str(device)})
     model = build_model(cfg).train()
-    ddp = T.wrap_ddp(model, local_rank)
+    timer = T.CommTimer() if world > 1 else None
+    ddp = T.wrap_ddp(model, local_rank, comm_timer=timer)
     opt = T.build_optimizer(model)
     clips = T.synthetic_clips(clips_per_rank, 5, 360, 640, device, seed=100 + rank, num_instances=4)
     def step():
         if bf16:
             with torch.autocast("cuda", dtype=torch.bfloat16):
-                return T.train_step(ddp, opt, clips)
-        return T.train_step(ddp, opt, clips)
+                return T.train_step(ddp, opt, clips, comm_timer=timer)
+        return T.train_step(ddp, opt, clips, comm_timer=timer)
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
@@ -230,6 +231,7 @@ def model_step_leg(rank, local_rank, world, device, steps, warmup=3, clips_per_r
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     n_params = sum(p.numel() for p in model.parameters() if p.requires_grad)
+    comm = timer.report() if timer is not None else None      # the last timed step's all-reduces (rank 0's view)
     launches = None
     if count:       # one more step on every rank (the gradient all-reduce needs them all); rank 0 counts its launches
         if rank == 0:
@@ -245,6 +247,8 @@ def model_step_leg(rank, local_rank, world, device, steps, warmup=3, clips_per_r
             "launches_per_step": launches,
             "clips_per_rank": clips_per_rank, "n_gpus": world, "trainable_params": n_params,
             "grad_allreduce_MB_per_step": round(n_params * 4 / 1e6, 1),
+            "ddp_bucket_cap_MB": T.ddp_bucket_mb() if world > 1 else None,
+            "ddp_comm": comm,
             "config": "SeqFormer R50 (random init), T=5, 360x640 -> 384x640, 300 queries, 6+6 layers, fp32; "
                       "SetCriterion on 4 synthetic tracks per clip (matcher + focal/L1/GIoU/mask losses, deep supervision); DDP static_graph + gradient_as_bucket_view over RCCL"}
 
@@ -763,8 +767,11 @@ def main():
         raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPUs visible")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    affinity = None
     if world > 1:
         import torch.distributed as dist
+        from vnext_amd.train import set_rank_affinity
+        affinity = set_rank_affinity(local_rank, world)     # this rank's host threads next to its GPU
         dist.init_process_group("nccl", device_id=device)
     n_gpus = world if world > 1 else 1
 
@@ -795,6 +802,7 @@ def main():
     ms_per_step = elapsed * 1e3 / a.steps
     line = headline_line(a, n_gpus, dist.get_world_size() if world > 1 else 1, ms_per_step, S, nsets, input_bytes,
                          "nccl (RCCL)")
+    line["rank_cpu_affinity"] = affinity      # rank 0's share of the host cores (None at one GPU: nothing pinned)
 
     # ---- model-level leg: SeqFormer-R50 T=5 360p training step under DDP (all ranks) ----------
     model_leg = None

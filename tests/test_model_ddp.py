@@ -116,6 +116,81 @@ def _ddp_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
+def _ddp_timer_worker(rank, world, port, out):
+    """A small dense model (no MSDA stand-ins needed): 4 ranks, 1 MB buckets, CommTimer hook."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    T.init_distributed("gloo")
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(256, 512), torch.nn.ReLU(), torch.nn.Linear(512, 512), torch.nn.ReLU(),
+                                torch.nn.Linear(512, 256))
+    timer = T.CommTimer()
+    ddp = T.wrap_ddp(model, bucket_cap_mb=1, comm_timer=timer)
+    x = torch.randn(8, 256, generator=torch.Generator().manual_seed(100 + rank))
+    reports = []
+    for _ in range(4):          # DDP rebuilds its buckets (to the requested cap) after the first iterations
+        timer.begin_step()
+        model.zero_grad()
+        ddp(x).square().mean().backward()
+        reports.append(timer.report())
+    flat = torch.cat([p.grad.flatten() for p in model.parameters()])
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    if rank == 0:
+        torch.save({"grads": gathered, "reports": reports}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ddp_world_size_4_gloo_buckets_and_comm_timer(tmp_path):
+    """Four CPU processes over gloo (the widest world this container's 8 cores run comfortably): explicit bucket
+    cap, the timing hook in place of DDP's own all-reduce -- every rank still ends with the mean of the four shards'
+    gradients, and the timer reports one span per bucket and the exposed tail."""
+    out = str(tmp_path / "ddp4.pt")
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_ddp_timer_worker, args=(4, port, out), nprocs=4, join=True)
+    res = torch.load(out)
+    for g in res["grads"][1:]:
+        assert torch.equal(g, res["grads"][0])
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(256, 512), torch.nn.ReLU(), torch.nn.Linear(512, 512), torch.nn.ReLU(),
+                                torch.nn.Linear(512, 256))
+    acc = None
+    for r in range(4):
+        model.zero_grad()
+        x = torch.randn(8, 256, generator=torch.Generator().manual_seed(100 + r))
+        model(x).square().mean().backward()
+        flat = torch.cat([p.grad.flatten() for p in model.parameters()])
+        acc = flat if acc is None else acc + flat
+    torch.testing.assert_close(res["grads"][0], acc / 4, rtol=1e-5, atol=1e-7)
+    rep = res["reports"][-1]
+    # 0.53 M parameters = 2.1 MB in 1 MB buckets: at least two all-reduces per step, all of them timed
+    assert rep["buckets"] >= 2 and rep["allreduce_ms_sum"] > 0 and rep["exposed_allreduce_ms"] is not None
+    assert 0 <= rep["exposed_allreduce_ms"] <= rep["allreduce_ms_sum"] + 1e-6
+
+
+def test_rank_affinity_partitions_the_allowed_cores():
+    """set_rank_affinity without a GPU: the allowed cores divided evenly, restored afterwards."""
+    if not hasattr(os, "sched_setaffinity"):
+        pytest.skip("no sched_setaffinity on this platform")
+    before = os.sched_getaffinity(0)
+    threads = torch.get_num_threads()
+    try:
+        seen = []
+        for r in range(2):
+            os.sched_setaffinity(0, before)
+            info = T.set_rank_affinity(r, 2)
+            assert info is not None and info["cpus"] == max(1, len(before) // 2)
+            seen.append(os.sched_getaffinity(0))
+        if len(before) >= 2:
+            assert not (seen[0] & seen[1])
+    finally:
+        os.sched_setaffinity(0, before)
+        torch.set_num_threads(threads)
+
+
 def test_ddp_world_size_2_gloo_averages_shard_gradients(tmp_path):
     """Two CPU processes over gloo: after backward every rank holds the same gradient, and it is
     the mean of the two shards' single-process gradients."""

@@ -75,13 +75,131 @@ def synthetic_clips(num_clips: int, num_frames: int, height: int, width: int, de
     return clips
 
 
-def wrap_ddp(model, local_rank: int | None = None):
+# Gradient buckets.  xGMI is point to point (7 links x ~153 GB/s per GPU): a ring all-reduce of b bytes over 8 GPUs
+# moves 2 * 7/8 * b over every link, ~11.4 us per MB, on top of ~30 us of launch + synchronisation per collective.
+# SeqFormer-R50 has 188 MB of fp32 gradients per step and ~45 ms of backward to hide them under: 48 MB buckets =
+# 4 collectives of ~0.55 ms each (DDP's default 25 MB would make 8; the FIRST bucket also closes later with larger
+# buckets, but only the LAST one is exposed, and its size is what remains after the others -- the head's ~20 MB).
+# VNX_DDP_BUCKET_MB overrides it for sweeps on hardware.
+DEFAULT_BUCKET_MB = 48
+
+
+def ddp_bucket_mb() -> int:
+    return int(os.environ.get("VNX_DDP_BUCKET_MB", DEFAULT_BUCKET_MB))
+
+
+class CommTimer:
+    """DDP communication hook that times the gradient all-reduces: every bucket's span (hook call -> collective done,
+    device events on GPU, wall clock on CPU) and the part of the communication nothing can hide -- from the moment the
+    LAST bucket is ready (the backward has no gradient left to compute) to the end of the last all-reduce.
+    `report()` after a synchronisation -> {"buckets", "allreduce_ms_sum", "exposed_allreduce_ms"} of the last step."""
+
+    def __init__(self, process_group=None):
+        self.group = process_group
+        self.spans = []          # [(start, end)] of the current step: events or floats
+        self._last = None
+
+    def begin_step(self):
+        self.spans = []
+
+    def hook(self, state, bucket):
+        import time
+        buf = bucket.buffer()
+        group = self.group if self.group is not None else dist.group.WORLD
+        world = dist.get_world_size(group)
+        on_gpu = buf.is_cuda
+        if on_gpu:
+            start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            start.record()
+        else:
+            start, end = [time.perf_counter()], [None]
+        buf.div_(world)
+        fut = dist.all_reduce(buf, group=group, async_op=True).get_future()
+        span = (start, end)
+        self.spans.append(span)
+
+        def done(f):
+            if on_gpu:
+                end.record()          # the future's callback runs ordered after the collective on its stream
+            else:
+                end[0] = time.perf_counter()
+            return f.value()[0]
+        return fut.then(done)
+
+    def report(self):
+        if not self.spans:
+            return None
+        first = self.spans[0][0]
+        if isinstance(first, list):
+            sums = sum((e[0] - s[0]) * 1e3 for s, e in self.spans if e[0] is not None)
+            exposed = (self.spans[-1][1][0] - self.spans[-1][0][0]) * 1e3 if self.spans[-1][1][0] is not None else None
+        else:
+            sums = sum(s.elapsed_time(e) for s, e in self.spans)
+            exposed = self.spans[-1][0].elapsed_time(self.spans[-1][1])
+        return {"buckets": len(self.spans), "allreduce_ms_sum": round(sums, 3),
+                "exposed_allreduce_ms": None if exposed is None else round(exposed, 3)}
+
+
+def wrap_ddp(model, local_rank: int | None = None, bucket_cap_mb: int | None = None, comm_timer: CommTimer | None = None):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return model
     on_gpu = next(model.parameters()).is_cuda
-    return DistributedDataParallel(
+    ddp = DistributedDataParallel(
         model, device_ids=[local_rank] if on_gpu else None, broadcast_buffers=False,
-        find_unused_parameters=False, static_graph=True, gradient_as_bucket_view=True)
+        find_unused_parameters=False, static_graph=True, gradient_as_bucket_view=True,
+        bucket_cap_mb=bucket_cap_mb if bucket_cap_mb is not None else ddp_bucket_mb())
+    if comm_timer is not None:
+        ddp.register_comm_hook(None, comm_timer.hook)
+    return ddp
+
+
+def set_rank_affinity(local_rank: int, local_world: int):
+    """Pin this rank's host threads to the cores next to its GPU: the cores of the GPU's NUMA node (sysfs, through the
+    device's PCI address), divided among the ranks whose GPUs share that node; all cores divided evenly when the
+    topology cannot be read.  8 Python processes each issuing ~3 600 launches per step on one host are the first
+    thing that bites at 8 GPUs (the reference leaves placement to the OS: detectron2/engine/launch.py:67-80).
+    -> {"numa_node", "cpus"} for the bench line, or None when the platform has no sched_setaffinity."""
+    if not hasattr(os, "sched_setaffinity"):
+        return None
+    allowed = sorted(os.sched_getaffinity(0))
+
+    def node_of(idx):
+        try:
+            p = torch.cuda.get_device_properties(idx)
+            bdf = f"{getattr(p, 'pci_domain_id', 0):04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+            with open(f"/sys/bus/pci/devices/{bdf}/numa_node") as f:
+                return int(f.read().strip())
+        except Exception:
+            return -1
+
+    def cpus_of(node):
+        try:
+            with open(f"/sys/devices/system/node/node{node}/cpulist") as f:
+                out = []
+                for part in f.read().strip().split(","):
+                    lo, _, hi = part.partition("-")
+                    out.extend(range(int(lo), int(hi or lo) + 1))
+                return [c for c in out if c in allowed]
+        except Exception:
+            return []
+
+    node = node_of(local_rank) if torch.cuda.is_available() else -1
+    pool, share, slot = [], local_world, local_rank
+    if node >= 0:
+        pool = cpus_of(node)
+        mates = [r for r in range(local_world) if node_of(r) == node]
+        if pool and local_rank in mates:
+            share, slot = len(mates), mates.index(local_rank)
+    if not pool:
+        pool, node = allowed, -1
+    per = max(1, len(pool) // max(1, share))
+    mine = pool[slot * per:(slot + 1) * per] or pool
+    try:
+        os.sched_setaffinity(0, mine)
+        torch.set_num_threads(max(1, min(len(mine), 16)))
+    except OSError:
+        return None
+    return {"numa_node": node, "cpus": len(mine)}
 
 
 def build_optimizer(model, base_lr=2e-4, backbone_multiplier=0.1, weight_decay=1e-4):
@@ -97,8 +215,10 @@ def build_optimizer(model, base_lr=2e-4, backbone_multiplier=0.1, weight_decay=1
                              fused=True if on_gpu else None)   # one multi-tensor kernel chain per group
 
 
-def train_step(model, optimizer, clips, clip_max_norm: float = 0.01):
+def train_step(model, optimizer, clips, clip_max_norm: float = 0.01, comm_timer: CommTimer | None = None):
     """SimpleTrainer.run_step without the host synchronisations."""
+    if comm_timer is not None:
+        comm_timer.begin_step()
     loss_dict = model(clips)
     losses = sum(loss_dict.values())
     optimizer.zero_grad(set_to_none=True)
