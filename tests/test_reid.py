@@ -108,3 +108,16 @@ def test_batched_loss_matches_reference_loss_reid():
     np.testing.assert_allclose(float(aux) / n, g["loss_reid_aux"], rtol=2e-5)
     (contrast + aux).backward()
     assert torch.isfinite(ref.grad).all() and torch.isfinite(key.grad).all() and float(ref.grad.abs().sum()) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,k", [(1, 1), (50, 50), (7, 300), (110, 111), (111, 111), (300, 300)])
+def test_bisoftmax_staged_and_global_forms(n, k):
+    """vnx_reid_bisoftmax (tracker.py:232-235: the mean of the row softmax and the column softmax) on both sides of the
+    12 288-element limit below which the matrix is staged in LDS, against float64 softmaxes."""
+    from vnext_amd.heads.reid import bisoftmax
+    g = torch.Generator().manual_seed(n * 1000 + k)
+    s = 3.0 * torch.randn(n, k, generator=g)
+    got = bisoftmax(s.cuda()).double().cpu()
+    want = 0.5 * (s.double().softmax(1) + s.double().softmax(0))
+    torch.testing.assert_close(got, want, rtol=0, atol=2e-6)

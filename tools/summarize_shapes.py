@@ -32,14 +32,29 @@ with open(dst + "_kernel_stats.csv", "w") as f:
     w = csv.writer(f)
     w.writerow(["case", "kernel", "calls", "avg_us", "min_us", "max_us", "workload"])
     w.writerows(rows)
+# HBM traffic per launch of the MSDA kernels at the non-headline shapes: FETCH_SIZE / WRITE_SIZE, separate passes
+# (*_pmcfetch / *_pmcwrite).  Units and the gfx950 correction as /opt/skills/guides/MI355X_MICROARCH.md (HBM) prescribes:
+# both counters are in KiB; FETCH_SIZE reports half of the bytes of wide coalesced reads on gfx950 -> doubled.
 pmc = {}
-path = os.path.join(src, "heads_pmc_counter_collection.csv")
-if os.path.exists(path):
+for path in sorted(glob.glob(os.path.join(src, "*_pmc*_counter_collection.csv"))):
+    case = os.path.basename(path).split("_pmc")[0]
     acc = {}
     for r in csv.DictReader(open(path)):
         if "vnx::" in r["Kernel_Name"]:
             acc.setdefault((short(r["Kernel_Name"]), r["Counter_Name"]), []).append(float(r["Counter_Value"]))
     for (k, c), v in acc.items():
-        pmc.setdefault(k, {})[c] = {"dispatches": len(v), "mean": sum(v) / len(v)}
-json.dump({"kernel_trace": table, "heads_pmc": pmc}, open(dst + "_kernel_avg_us.json", "w"), indent=1, sort_keys=True)
+        mean = sum(v) / len(v)
+        e = pmc.setdefault(case, {}).setdefault(k, {})
+        e[c + "_KiB_raw"] = mean
+        e["dispatches"] = len(v)
+        if c == "FETCH_SIZE":
+            e["read_MB"] = 2 * mean * 1024 / 1e6
+        elif c == "WRITE_SIZE":
+            e["write_MB"] = mean * 1024 / 1e6
+for case in pmc.values():
+    for e in case.values():
+        if "read_MB" in e and "write_MB" in e:
+            e["traffic_MB"] = e["read_MB"] + e["write_MB"]
+json.dump({"kernel_trace": table, "pmc_hbm": pmc}, open(dst + "_kernel_avg_us.json", "w"), indent=1, sort_keys=True)
 print(open(dst + "_kernel_stats.csv").read())
+print(json.dumps(pmc, indent=1, sort_keys=True))
