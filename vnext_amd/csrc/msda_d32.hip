@@ -680,6 +680,28 @@ __device__ __forceinline__ void group8_sum4(float4_t& v) {
   v = float4_t{a, b, c, d};
 }
 
+// Four values summed over the 8 lanes of a set in EIGHT DPP adds instead of twelve: the half-row mirror step first, with
+// bank masks -- the even quad of a set keeps (a, b), the odd quad (c, d), each adding the other quad's copy -- leaves two
+// values per lane, which two quad permutes finish.  Afterwards every lane of the even quad holds (sum a, sum b) in
+// (t0, t1), every lane of the odd quad (sum c, sum d).
+__device__ __forceinline__ void group8_sum4_split(const float4_t v, float& t0, float& t1) {
+  const float a = v.x, b = v.y, c = v.z, d = v.w;
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %2, %2 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+      "v_add_f32_dpp %0, %4, %4 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+      "v_add_f32_dpp %1, %3, %3 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+      "v_add_f32_dpp %1, %5, %5 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+      : "=&v"(t0), "=&v"(t1)
+      : "v"(a), "v"(b), "v"(c), "v"(d));
+}
+
 // the 4-lane form (rows of 16-bit values as 4 lanes x 16 B): two quad permutes
 __device__ __forceinline__ void group4_sum4(float4_t& v) {
   float a = v.x, b = v.y, c = v.z, d = v.w;
@@ -1038,9 +1060,10 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < kBatch; ++j) {
-        float4_t dd = {dot(v[j][0]), dot(v[j][1]), dot(v[j][2]), dot(v[j][3])};
-        group8_sum4(dd);
-        if (ch == 0) g_res[i0 + j] = dd;
+        const float4_t dd = {dot(v[j][0]), dot(v[j][1]), dot(v[j][2]), dot(v[j][3])};
+        float t0, t1;
+        group8_sum4_split(dd, t0, t1);        // lanes 0..3 of the set: (d1, d2); lanes 4..7: (d3, d4)
+        if ((ch & 3) == 0) reinterpret_cast<float2_t*>(g_res + i0 + j)[ch >> 2] = float2_t{t0, t1};
       }
     }
   } else {

@@ -378,7 +378,7 @@ msda_bwd_gv_sel_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
   __syncthreads();
   VNX_SEL_STAMP(1);
 
-  int lvl = -1, r0 = 0, r1 = 0, Hl = 0, Wl = 0, start = 0, u_lvl = 0, qsplit = 1, qpiece = 0;
+  int lvl = -1, r0 = 0, r1 = 0, Hl = 0, Wl = 0, start = 0, u_lvl = 0, qsplit = 1, qpiece = 0, lvl_units = 0;
   {
     int running = 0;
     bool packed = true;
@@ -392,7 +392,7 @@ msda_bwd_gv_sel_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
       const int n = H * W, units = ur & 0xfff, rpu = (ur >> 12) & 0xfff, qs = ur >> 24;
       if (lvl < 0) {
         if (u < units * qs) {        // a level's workgroups: row-unit major, query piece minor
-          lvl = l; Hl = H; Wl = W; start = st; qsplit = qs;
+          lvl = l; Hl = H; Wl = W; start = st; qsplit = qs; lvl_units = units;
           u_lvl = u / qs; qpiece = u - u_lvl * qs;
           r0 = u_lvl * rpu;
           r1 = r0 + rpu < n ? r0 + rpu : n;
@@ -409,6 +409,11 @@ msda_bwd_gv_sel_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
   Hl = __builtin_amdgcn_readfirstlane(Hl); Wl = __builtin_amdgcn_readfirstlane(Wl); start = __builtin_amdgcn_readfirstlane(start);
   u_lvl = __builtin_amdgcn_readfirstlane(u_lvl); qsplit = __builtin_amdgcn_readfirstlane(qsplit);
   qpiece = __builtin_amdgcn_readfirstlane(qpiece);
+  // A level of at most two units (the coarse ones: 240 and 60 pixels at 360p): more than half of ALL samples of the
+  // level land in a unit, so selecting them buys nothing and costs the unit its longest latency chain (tag loads, ballots,
+  // scan: 3.4 us of the 12-15 us a coarse unit of the T=5 decoder call takes -- the kernel's critical path).  Such a unit
+  // takes every sample of a window in order: identity tables, no loads, no ballots, no scan.
+  const bool dense = __builtin_amdgcn_readfirstlane(lvl_units) <= 2;
   const int rows = r1 - r0;
   constexpr int kRpg = (kRowsMax + kGroups - 1) / kGroups;
   float4_t racc[kRpg];
@@ -438,6 +443,19 @@ msda_bwd_gv_sel_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
   for (int win0 = s_lo; win0 < s_hi; win0 += kWin) {
     const int n_w = s_hi - win0 < kWin ? s_hi - win0 : kWin;
     const int tw = opaque(tid);
+    int n_sel, n_q;
+    if (dense) {
+#pragma unroll
+      for (int r = 0; r < kSelRounds; ++r) {
+        const int sidx = r * kThreads + tw;
+        if (sidx < n_w) { sel_id[sidx] = uint16_t(sidx); sel_qr[sidx] = uint16_t(sidx >> 2); }
+      }
+      if (4 * tw < n_w) {              // kThreads == kWinQueries: one query of the window per thread
+        selq[tw] = uint16_t(tw);
+        if ((tw & (kQcMax - 1)) == 0) cs[tw / kQcMax] = uint32_t(4 * tw);
+      }
+      n_sel = n_w; n_q = (n_w + 3) >> 2;
+    } else {
     // ---- selection: which samples of this window touch my rows -----------------------------
     unsigned long long bal[kSelRounds], balf[kSelRounds];
     uint32_t hitbits = 0;
@@ -464,7 +482,7 @@ msda_bwd_gv_sel_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
       if (tid == kSelParts - 1) { cs[8] = is; cs[9] = iq; }
     }
     __syncthreads();
-    const int n_sel = int(cs[8]), n_q = int(cs[9]);
+    n_sel = int(cs[8]); n_q = int(cs[9]);
     if (n_sel == 0) continue;                         // uniform: nothing of this window lands here
 #pragma unroll
     for (int r = 0; r < kSelRounds; ++r) {
@@ -484,6 +502,7 @@ msda_bwd_gv_sel_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
         }
       }
     }
+    }   // !dense
     const int n_chunks = (n_q + kQcMax - 1) / kQcMax;
     if (tid == 0) cs[n_chunks] = uint32_t(n_sel);
     __syncthreads();
