@@ -375,11 +375,37 @@ def make_case(res, B, Lq, dist, vdtype, seed, device):
                 out=out, gv=gv, gl=gl, ga=ga, S=S, vdt=vdt)
 
 
-def addressable_bytes(B, S, Lq, e=4, e_loc=4, M=8, D=32, L=4, K=4):
+def touched_rows(case, res):
+    """Distinct (batch, pixel, head) rows of `value` the taps of this case's samples land on (counted on the device
+    from the locations: floor, the in-map test of ms_deform_im2col_cuda.cuh:288 and the four corner tests :55-78)."""
+    loc = case["loc"].float()                                   # [B, Lq, M, L, K, 2]
+    B, Lq, M, L, K, _ = loc.shape
+    S = case["S"]
+    seen = torch.zeros(B * S * M, dtype=torch.bool, device=loc.device)
+    bm = (torch.arange(B, device=loc.device).view(B, 1, 1, 1) * S * M + torch.arange(M, device=loc.device).view(1, 1, M, 1))
+    start = 0
+    for l, (H, W) in enumerate(SHAPES[res]):
+        h = loc[:, :, :, l, :, 1] * H - 0.5
+        w = loc[:, :, :, l, :, 0] * W - 0.5
+        ok = (h > -1) & (w > -1) & (h < H) & (w < W)
+        h0, w0 = h.floor().long(), w.floor().long()
+        for dy in (0, 1):
+            for dx in (0, 1):
+                y, x = h0 + dy, w0 + dx
+                inside = ok & (y >= 0) & (y <= H - 1) & (x >= 0) & (x <= W - 1)
+                idx = (bm + (start + y * W + x) * M)[inside]
+                seen[idx] = True
+        start += H * W
+    return int(seen.sum())
+
+
+def addressable_bytes(B, S, Lq, e=4, e_loc=4, M=8, D=32, L=4, K=4, rows=None):
     """SURVEY 8(d)'s byte count assumes the whole `value` is read.  A call with few queries on a large map cannot touch
-    it all: 4 taps per point reach at most min(4 * points, B * S * M) rows.  -> (forward, backward) bytes with the
-    value READ counted for those rows only (grad_value is still written in full: every row has an owner)."""
-    rows = min(4 * B * Lq * M * L * K, B * S * M)
+    it all (decoder 720p: 768 K taps on 782 K rows reach 63 % of them).  -> (forward, backward) bytes with the value
+    READ counted for the rows the samples really touch (`rows`, from touched_rows; at most min(4 * points, B S M));
+    grad_value is still written in full: every row has an owner."""
+    if rows is None:
+        rows = min(4 * B * Lq * M * L * K, B * S * M)
     samples = B * Lq * M * L * K
     fwd = e * D * rows + e_loc * 3 * samples + e * B * Lq * M * D
     bwd = e * D * rows + e * D * B * S * M + e * B * Lq * M * D + e_loc * 6 * samples
@@ -411,7 +437,8 @@ def op_case_rooflines(op, device):
         sets = [probe] + [make_case(res, B, Lq, dist, vdtype, 1 + i, device) for i in range(1, nsets)]
         inner = max(nsets, 8)
         nominal_fwd, nominal_bwd = algorithmic_bytes(B, S, Lq, e=e)
-        bytes_fwd, bytes_bwd = addressable_bytes(B, S, Lq, e=e)
+        rows_touched = touched_rows(probe, res)
+        bytes_fwd, bytes_bwd = addressable_bytes(B, S, Lq, e=e, rows=rows_touched)
         g_fwd = capture([(lambda s=sets[i % nsets]: op.fwd(s, B, Lq)) for i in range(inner)])
         g_bwd = capture([(lambda s=sets[i % nsets]: op.bwd(s, B, Lq)) for i in range(inner)])
         us_f, us_b = event_time_us(g_fwd, inner, reps=9), event_time_us(g_bwd, inner, reps=9)
@@ -419,8 +446,9 @@ def op_case_rooflines(op, device):
         out[key] = {
             "what": what, "B": B, "Lq": Lq, "S": S, "loc": dist, "value_dtype": "f32" if e == 4 else "bf16",
             "points": points, "input_rotation_sets": nsets,
-            # bytes = SURVEY 8(d)'s count with the value read limited to the rows 4 taps per point can reach
-            # (addressable_bytes); `nominal_*` = the unlimited count (equal whenever the call can touch every row)
+            "value_rows_touched": rows_touched, "value_rows": B * S * 8,
+            # bytes = SURVEY 8(d)'s count with the value read limited to the rows this case's samples touch
+            # (touched_rows / addressable_bytes); `nominal_*` = the count that assumes the whole `value` is read
             "fwd": {"us_per_launch": us_f, "algorithmic_bytes": bytes_fwd, "achieved_GBs": bytes_fwd / us_f / 1e3,
                     "frac_of_hbm_peak": bytes_fwd / us_f / 1e3 / HBM_PEAK_GBS, "gpoints_per_s": points / us_f / 1e3,
                     "nominal_bytes": nominal_fwd, "nominal_frac": nominal_fwd / us_f / 1e3 / HBM_PEAK_GBS},

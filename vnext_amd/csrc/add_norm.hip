@@ -138,25 +138,30 @@ add_dropout_layernorm_bwd_kernel(const float* __restrict__ grad_y, const float* 
   }
 }
 
-// grad_gamma[c] = sum_b partial[b][0][c], grad_beta[c] = sum_b partial[b][1][c], b ascending (deterministic)
-__global__ void __launch_bounds__(256)
+// grad_gamma[c] = sum_b partial[b][0][c], grad_beta[c] = sum_b partial[b][1][c], in a fixed order (deterministic).
+// 16 workgroups x 1 024 threads: a workgroup owns 32 of the 512 columns (gamma | beta), thread (slice, column) adds the
+// partial rows  slice, slice + 32, ...  -- 32 independent chains per column -- and the slices meet in a fixed-order tree.
+// (Round 2's form walked all 1 024 partial rows with four chains per column on 4 workgroups: 122 us per call at the
+// encoder's 25 500 rows, seven times the backward kernel it finishes -- 30 calls per training step; rocprofv3,
+// profiles/r03_shapes.)
+constexpr int kPgBlocks = 16, kPgCols = 2 * kAnC / kPgBlocks, kPgSlices = 1024 / kPgCols;     // 16, 32, 32
+__global__ void __launch_bounds__(1024)
 layernorm_param_grad_kernel(const float* __restrict__ partial, float* __restrict__ grad_gamma,
                             float* __restrict__ grad_beta, int blocks) {
-  __shared__ float red[4][128];
-  // 512 columns (gamma | beta) x 4 interleaved block-subsets: thread t owns column t & 127 of quarter blockIdx.x,
-  // subset t >> 7
-  const int col = int(blockIdx.x) * 128 + (threadIdx.x & 127);     // 0..511
-  const int sub = threadIdx.x >> 7;                                // 0..1
-  float s0 = 0.f, s1 = 0.f;
-  for (int b = sub; b < blocks; b += 4) s0 += partial[int64_t(b) * 2 * kAnC + col];
-  for (int b = sub + 2; b < blocks; b += 4) s1 += partial[int64_t(b) * 2 * kAnC + col];
-  red[sub][threadIdx.x & 127] = s0;
-  red[sub + 2][threadIdx.x & 127] = s1;
+  __shared__ float red[kPgSlices][kPgCols];
+  const int c = threadIdx.x % kPgCols, slice = threadIdx.x / kPgCols;
+  const int col = int(blockIdx.x) * kPgCols + c;                    // 0..511
+  float s = 0.f;
+  for (int b = slice; b < blocks; b += kPgSlices) s += partial[int64_t(b) * 2 * kAnC + col];
+  red[slice][c] = s;
   __syncthreads();
-  if (sub == 0) {
-    const int c = threadIdx.x & 127;
-    const float s = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
-    if (col < kAnC) grad_gamma[col] = s; else grad_beta[col - kAnC] = s;
+#pragma unroll
+  for (int step = kPgSlices / 2; step > 0; step >>= 1) {
+    if (slice < step) red[slice][c] += red[slice + step][c];
+    __syncthreads();
+  }
+  if (slice == 0) {
+    if (col < kAnC) grad_gamma[col] = red[0][c]; else grad_beta[col - kAnC] = red[0][c];
   }
 }
 
@@ -223,7 +228,7 @@ extern "C" int vnx_add_dropout_layernorm_backward(int dtype, const void* grad_y,
   } else {
     blocks = 0;
   }
-  hipLaunchKernelGGL(layernorm_param_grad_kernel, dim3(4), dim3(256), 0, stream, (const float*)partial,
+  hipLaunchKernelGGL(layernorm_param_grad_kernel, dim3(kPgBlocks), dim3(1024), 0, stream, (const float*)partial,
                      (float*)grad_gamma, (float*)grad_beta, blocks);
   return check_launch("add_dropout_layernorm_bwd");
 }
