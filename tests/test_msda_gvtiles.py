@@ -163,3 +163,35 @@ def test_not_promised_packed_and_run_to_run():
     a, b = run(big, 0), run(big, 0)
     assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
     np.testing.assert_allclose(a[0], b[0], rtol=0, atol=2e-6 * scale(a[0]))
+
+
+@pytest.mark.parametrize("vdt", [torch.float32, torch.bfloat16])
+def test_fused_backward_records_path_and_tiles_path_agree(vdt):
+    """The fused prologue never materialises sampling_locations / attention_weights; in tile mode its grad_loc kernel
+    leaves them (fp32) next to the tile words for the grad_value kernel.  Same gradients as with per-sample records."""
+    from vnext_amd.ops.functions import MSDeformAttnFusedFunction, level_tensors
+    shapes, B, Lq, M, L, P = PYR, 2, 1275, 8, 4, 4
+    g = torch.Generator().manual_seed(77)
+    S = sum(h * w for h, w in shapes)
+    value = torch.randn(B, S, M, 32, generator=g).to(vdt)
+    offsets = torch.randn(B, Lq, M, L, P, 2, generator=g) * 2
+    logits = torch.randn(B, Lq, M, L * P, generator=g) * 2
+    ref = torch.rand(B, Lq, L, 2, generator=g)
+    gout = torch.randn(B, Lq, M * 32, generator=g).to(vdt)
+    shapes_t, lsi = level_tensors(shapes, "cuda")
+    res = {}
+    for variant in (430, 0):
+        _lib.set_kernel_variant(variant)
+        try:
+            leaves = [value.cuda().requires_grad_(True), offsets.cuda().requires_grad_(True), logits.cuda().requires_grad_(True),
+                      ref.cuda().requires_grad_(True)]
+            out = MSDeformAttnFusedFunction.apply(leaves[0], shapes_t, lsi, leaves[1], leaves[2], leaves[3])
+            out.backward(gout.cuda())
+            torch.cuda.synchronize()
+            res[variant] = [t.grad.float().cpu().numpy() for t in leaves]
+        finally:
+            _lib.set_kernel_variant(0)
+    tol = 3e-6 if vdt == torch.float32 else 1e-2
+    for a, b in zip(res[430], res[0]):
+        np.testing.assert_allclose(a, b, rtol=0, atol=tol * scale(b))
+    assert np.array_equal(res[430][1], res[0][1]) and np.array_equal(res[430][2], res[0][2])   # same kernel, same order

@@ -1,7 +1,7 @@
 // tools/kbench.hip -- stand-alone A/B timing + cross-check harness for the MSDA kernels of
 // libvnext_hip.so (development tool; no torch, starts in a second on a fresh GPU box).
 //
-//   kbench [--shape dec360|enc360|dec720|enc720] [--B 5] [--lq N] [--dist U|M] [--op fwd|bwd|both]
+//   kbench [--shape dec360|enc360|dec720|enc720] [--B 5] [--lq N] [--dist U|M] [--op fwd|bwd|both|ffwd|fbwd]
 //          [--variants 0,1,...] [--inner 24] [--reps 15] [--check] [--dma-test]
 //
 // Inputs are generated on the device (hash RNG): value ~ N(0,1); locations U[0,1)^2 (the reference
@@ -318,6 +318,7 @@ int main(int argc, char** argv) {
       ws_bytes = std::max(ws_bytes, vnx_msda_backward_workspace_bytes(VDT, VNX_F32, B, S, M, D, L, Lq, P, VNX_MSDA_LEVELS_PACKED));
     }
     vnx_set_kernel_variant(0);
+    ws_bytes = std::max(ws_bytes, vnx_msda_fused_backward_workspace_bytes(VDT, B, S, M, L, Lq, P));
   }
   std::vector<Set> sets(nsets);
   for (int i = 0; i < nsets; ++i) {
@@ -336,13 +337,13 @@ int main(int argc, char** argv) {
       hipLaunchKernelGGL(f32_to_bf16, dim3(2048), dim3(256), 0, 0, s.value, s.value16, n_value);
       hipLaunchKernelGGL(f32_to_bf16, dim3(2048), dim3(256), 0, 0, s.go, s.go16, n_out);
     }
-    if (op == "ffwd") {
+    if (op == "ffwd" || op == "fbwd") {
       CK(hipMalloc(&s.off, n_s * 8)); CK(hipMalloc(&s.logit, n_s * 4));
       hipLaunchKernelGGL(to_fused, dim3(2048), dim3(256), 0, 0, s.loc, s.attn, s.off, s.logit, n_s, L, P, py);
     }
   }
   float* refpts = nullptr;
-  if (op == "ffwd") {
+  if (op == "ffwd" || op == "fbwd") {
     CK(hipMalloc(&refpts, size_t(B) * Lq * L * 2 * 4));
     hipLaunchKernelGGL(fill_const, dim3(1024), dim3(256), 0, 0, refpts, size_t(B) * Lq * L * 2, 0.5f);
   }
@@ -360,6 +361,12 @@ int main(int argc, char** argv) {
     VK(vnx_msda_forward(VNX_F32, VNX_F32, s.value, dshapes, dlsi, s.loc, s.attn, s.out, B, S, M, D, L, Lq, P, st));
   };
   auto bwd = [&](Set& s) {
+    if (op == "fbwd" && vnx_get_kernel_variant() != 1) {     // fused prologue: gradients of the Linear outputs land in gl / ga
+      VK(vnx_msda_fused_backward(b16 ? VNX_BF16 : VNX_F32, VNX_F32, b16 ? (void*)s.value16 : (void*)s.value, dshapes, dlsi, s.off, s.logit,
+                                 refpts, b16 ? (void*)s.go16 : (void*)s.go, b16 ? (void*)s.gv16 : (void*)s.gv, s.gl, s.ga, nullptr, B, S, M, D,
+                                 L, Lq, P, 2, 1, s.ws, ws_bytes, st));
+      return;
+    }
     if (b16) {
       VK(vnx_msda_backward(VNX_BF16, VNX_F32, s.value16, dshapes, dlsi, s.loc, s.attn, s.go16, s.gv16, s.gl, s.ga, B, S, M, D, L, Lq, P,
                            VNX_MSDA_LEVELS_PACKED, s.ws, ws_bytes, st));
@@ -380,8 +387,8 @@ int main(int argc, char** argv) {
   if (check) {
     CK(hipMalloc(&r_out, n_out * 4)); CK(hipMalloc(&r_gv, n_value * 4)); CK(hipMalloc(&r_gl, n_s * 8)); CK(hipMalloc(&r_ga, n_s * 4));
     vnx_set_kernel_variant(1);
-    fwd(sets[0]); widen(sets[0], false);
-    if (op != "ffwd") { bwd(sets[0]); widen(sets[0], true); }
+    if (op != "fbwd") { fwd(sets[0]); widen(sets[0], false); }
+    if (op != "ffwd") { bwd(sets[0]); widen(sets[0], true); }     // (fbwd: only grad_value is comparable)
     CK(hipStreamSynchronize(st));
     CK(hipMemcpy(r_out, sets[0].out, n_out * 4, hipMemcpyDeviceToDevice)); CK(hipMemcpy(r_gv, sets[0].gv, n_value * 4, hipMemcpyDeviceToDevice));
     CK(hipMemcpy(r_gl, sets[0].gl, n_s * 8, hipMemcpyDeviceToDevice)); CK(hipMemcpy(r_ga, sets[0].ga, n_s * 4, hipMemcpyDeviceToDevice));
@@ -423,7 +430,7 @@ int main(int argc, char** argv) {
     pos = c + 1;
     vnx_set_kernel_variant(v);
     for (int is_bwd = 0; is_bwd < 2; ++is_bwd) {
-      if ((is_bwd && (op == "fwd" || op == "ffwd")) || (!is_bwd && op == "bwd")) continue;
+      if ((is_bwd && (op == "fwd" || op == "ffwd")) || (!is_bwd && (op == "bwd" || op == "fbwd"))) continue;
       char chk[256] = "";
       if (check) {
         if (!is_bwd) { fwd(sets[0]); widen(sets[0], false); CK(hipStreamSynchronize(st)); snprintf(chk, sizeof chk, " | relerr out %.2e", diff(sets[0].out, r_out, n_out)); }

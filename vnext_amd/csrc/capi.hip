@@ -60,7 +60,8 @@ bool msda_d32_fused_supported(int vdt, int ldt, const MsdaDims& d);
 int msda_fused_d32(bool backward, int vdt, int ldt, const void* value, const int64_t* shapes, const int64_t* lsi,
                    const void* raw_off, const void* raw_logit, const void* grad_out, void* out_or_grad_off,
                    void* grad_logit, MsdaDims d, void* records, const void* reference, float* grad_reference,
-                   int ref_dim, int ref_div, void* grad_value_f32, hipStream_t stream);
+                   int ref_dim, int ref_div, void* grad_value_f32, void* tile_summary, float* tile_loc, float* tile_attn,
+                   hipStream_t stream);
 bool msda_d32_gvrec_supported(int vdt, int ldt, const MsdaDims& d);
 size_t msda_gvrec_record_bytes(const MsdaDims& d);
 int msda_backward_gvrec_d32(int vdt, const int64_t*, const int64_t*, const void* records, const void*,
@@ -440,14 +441,36 @@ int vnx_msda_fused_forward(int value_dtype, int query_dtype, const void* value, 
   }
   return msda_fused_d32(false, value_dtype, query_dtype, value, spatial_shapes, level_start_index, sampling_offsets,
                         attention_logits, nullptr, output, nullptr, d, nullptr, reference_points, nullptr, ref_dim,
-                        reference_batch_div, nullptr, (hipStream_t)hip_stream);
+                        reference_batch_div, nullptr, nullptr, nullptr, nullptr, (hipStream_t)hip_stream);
+}
+
+// Scratch of the fused backward.  Record-fed grad_value: the sample records.  Tile-fed (use_tiles; the fused launcher
+// always takes the automatic configuration, hence tile queries of variant 0): [tile words | decoded locations, fp32,
+// 8 B per sample | softmax weights, fp32, 4 B per sample] -- the two tensors the fused prologue otherwise never
+// materialises, 12 B per sample against the records' 16 + 4.
+struct FusedScratch { bool tiles; size_t words, loc, attn, total; };
+static FusedScratch fused_scratch(int vdt, const MsdaDims& d, int variant) {
+  FusedScratch f{};
+  f.tiles = use_tiles(vdt, VNX_F32, d, variant);
+  if (f.tiles) {
+    const size_t samples = size_t(d.B) * d.Lq * d.M * d.L * d.P;
+    f.words = align256(msda_gvtiles_summary_bytes(d, msda_bwd_tile_queries(d, 0)));
+    f.loc = align256(samples * 8);
+    f.attn = align256(samples * 4);
+    f.total = f.words + f.loc + f.attn;
+  } else {
+    f.total = align256(msda_gvrec_record_bytes(d));
+  }
+  return f;
 }
 
 size_t vnx_msda_fused_backward_workspace_bytes(int value_dtype, int batch, int spatial_size, int num_heads, int num_levels,
                                                int num_query, int num_point) {
   const MsdaDims d{batch, spatial_size, num_heads, 32, num_levels, num_query, num_point};
   const size_t image = split_image_needed(value_dtype, d) ? sizeof(float) * size_t(batch) * size_t(spatial_size) * num_heads * 32 : 0;
-  return align256(msda_gvrec_record_bytes(d)) + image;
+  // the larger of the two layouts: the variant may change between this call and the backward (A/B runs)
+  const size_t a = fused_scratch(value_dtype, d, 430).total, b = fused_scratch(value_dtype, d, 0).total;
+  return (a > b ? a : b) + image;
 }
 
 int vnx_msda_fused_backward(int value_dtype, int query_dtype, const void* value, const int64_t* spatial_shapes,
@@ -480,23 +503,39 @@ int vnx_msda_fused_backward(int value_dtype, int query_dtype, const void* value,
     set_error("vnx_msda_fused_backward: null pointer argument");
     return VNX_ERR_INVALID_ARGUMENT;
   }
-  const size_t rec_bytes = align256(msda_gvrec_record_bytes(d));
+  const FusedScratch fs = fused_scratch(value_dtype, d, g_kernel_variant);
+  const size_t rec_bytes = fs.total;
   const bool split16 = split_image_needed(value_dtype, d);
   const size_t need = rec_bytes + (split16 ? sizeof(float) * size_t(batch) * size_t(spatial_size) * num_heads * 32 : 0);
-  float* split_image = split16 ? (float*)((char*)workspace + rec_bytes) : nullptr;
   if (!workspace || workspace_bytes < need) {
     set_error("vnx_msda_fused_backward: workspace of %zu bytes needed (got %zu)", need, workspace_bytes);
     return VNX_ERR_WORKSPACE;
   }
-  // (1) grad of the Linear outputs (+ reference points) and the sample records; (2) grad_value from
-  // the records.  Packed levels are required (the records-fed kernel is a no-op on the device otherwise).
-  st = msda_fused_d32(true, value_dtype, query_dtype, value, spatial_shapes, level_start_index, sampling_offsets,
-                      attention_logits, grad_output, grad_sampling_offsets, grad_attention_logits, d, workspace,
-                      reference_points, grad_reference_points, ref_dim, reference_batch_div,
-                      value_dtype == VNX_F32 ? grad_value : (void*)split_image, stream);
-  if (st != VNX_OK) return st;
-  st = msda_backward_gvrec_d32(value_dtype, spatial_shapes, level_start_index, workspace, grad_output,
-                               grad_value, d, g_kernel_variant, split_image, stream);
+  float* split_image = split16 ? (float*)((char*)workspace + rec_bytes) : nullptr;
+  void* fp32_target = value_dtype == VNX_F32 ? grad_value : (void*)split_image;
+  if (fs.tiles) {
+    // (1) grad of the Linear outputs (+ reference points), one word per (level, tile of queries) and the decoded
+    // locations / weights; (2) grad_value from those.  Packed levels are required (no-op on the device otherwise).
+    void* words = workspace;
+    float* tile_loc = (float*)((char*)workspace + fs.words);
+    float* tile_attn = (float*)((char*)workspace + fs.words + fs.loc);
+    st = msda_fused_d32(true, value_dtype, query_dtype, value, spatial_shapes, level_start_index, sampling_offsets,
+                        attention_logits, grad_output, grad_sampling_offsets, grad_attention_logits, d, nullptr,
+                        reference_points, grad_reference_points, ref_dim, reference_batch_div, fp32_target, words, tile_loc,
+                        tile_attn, stream);
+    if (st != VNX_OK) return st;
+    st = msda_backward_gvtiles_d32(value_dtype, VNX_F32, spatial_shapes, level_start_index, tile_loc, tile_attn, words,
+                                   grad_output, grad_value, d, msda_bwd_tile_queries(d, 0), split_image, stream);
+  } else {
+    // (1) grad of the Linear outputs (+ reference points) and the sample records; (2) grad_value from the records
+    st = msda_fused_d32(true, value_dtype, query_dtype, value, spatial_shapes, level_start_index, sampling_offsets,
+                        attention_logits, grad_output, grad_sampling_offsets, grad_attention_logits, d, workspace,
+                        reference_points, grad_reference_points, ref_dim, reference_batch_div, fp32_target, nullptr, nullptr,
+                        nullptr, stream);
+    if (st != VNX_OK) return st;
+    st = msda_backward_gvrec_d32(value_dtype, spatial_shapes, level_start_index, workspace, grad_output,
+                                 grad_value, d, g_kernel_variant, split_image, stream);
+  }
   if (st != VNX_OK) return st;
   if (split_image)
     return msda_split_levels_convert(value_dtype, spatial_shapes, level_start_index, split_image, grad_value, d, stream);

@@ -829,6 +829,10 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
       fused_decode<TL>(loc, attn, fa, wi, b, q, l, valid ? int(shapes[2 * l]) : 1, valid ? int(shapes[2 * l + 1]) : 1,
                        d, valid, x, y, a, sx, sy);
       g4.w = a;   // the softmax weight of every sample, in or out of the map (softmax backward, phase 3)
+      if (fa.tile_loc != nullptr && valid) {      // what the tile-fed grad_value kernel decodes again (fp32: the same bits)
+        *reinterpret_cast<float2_t*>(fa.tile_loc + 2 * wi) = float2_t{x, y};
+        fa.tile_attn[wi] = a;
+      }
     }
     if (q < d.Lq) {
       if constexpr (!FUSED) {
@@ -1238,7 +1242,8 @@ static int launch_fwd_fused_cfg(const void* value, const int64_t* shapes, const 
 template <typename TV, typename TL, int QPW, int WPB>
 static int launch_bwd_fused_cfg(const void* value, const int64_t* shapes, const int64_t* lsi, const void* raw_off,
                                 const void* raw_logit, const void* grad_out, void* grad_off, void* grad_logit,
-                                const MsdaDims& d, void* records, const FusedArgs& fa, hipStream_t stream) {
+                                const MsdaDims& d, void* records, void* tile_summary, const FusedArgs& fa,
+                                hipStream_t stream) {
   const int tiles_per_batch = (d.Lq + QPW * WPB - 1) / (QPW * WPB);
   const int64_t blocks = int64_t(d.B) * tiles_per_batch * d.M;
   if (blocks >= (int64_t(1) << 31)) {
@@ -1252,7 +1257,7 @@ static int launch_bwd_fused_cfg(const void* value, const int64_t* shapes, const 
   hipLaunchKernelGGL((msda_bwd_d32_kernel<TV, TL, QPW, WPB, 16, false, true, kLpr>), dim3(uint32_t(blocks)), dim3(64 * WPB),
                      lds, stream, (const TV*)value, shapes, lsi, (const TL*)raw_off, (const TL*)raw_logit,
                      (const TV*)grad_out, (float*)nullptr, (TL*)grad_off, (TL*)grad_logit, d, tiles_per_batch,
-                     (uint4_t*)records, (uint32_t*)unit_ids, (uint32_t*)nullptr, units_min,
+                     (uint4_t*)records, (uint32_t*)unit_ids, (uint32_t*)tile_summary, units_min,
                      take_stamp_region(kStampGradLoc, blocks), fa);
   return check_launch("msda_bwd_d32_fused");
 }
@@ -1260,12 +1265,13 @@ static int launch_bwd_fused_cfg(const void* value, const int64_t* shapes, const 
 template <typename TV, typename TL>
 static int fused_dispatch(bool backward, const void* value, const int64_t* shapes, const int64_t* lsi,
                           const void* raw_off, const void* raw_logit, const void* grad_out, void* out_or_grad_off,
-                          void* grad_logit, const MsdaDims& d, void* records, const FusedArgs& fa, hipStream_t stream) {
+                          void* grad_logit, const MsdaDims& d, void* records, void* tile_summary, const FusedArgs& fa,
+                          hipStream_t stream) {
   const FwdCfg c = pick_fwd_cfg(d, 0);
 #define VNX_CASE(Q, W)                                                                                   \
   if (c.qpw == Q && c.wpb == W)                                                                          \
     return backward ? launch_bwd_fused_cfg<TV, TL, Q, W>(value, shapes, lsi, raw_off, raw_logit, grad_out, \
-                                                         out_or_grad_off, grad_logit, d, records, fa, stream) \
+                                                         out_or_grad_off, grad_logit, d, records, tile_summary, fa, stream) \
                     : launch_fwd_fused_cfg<TV, TL, Q, W>(value, shapes, lsi, raw_off, raw_logit,           \
                                                          out_or_grad_off, d, fa, stream);
   VNX_CASE(4, 1) VNX_CASE(4, 4) VNX_CASE(8, 4)
@@ -1282,11 +1288,14 @@ bool msda_d32_fused_supported(int vdt, int ldt, const MsdaDims& d) {
 int msda_fused_d32(bool backward, int vdt, int ldt, const void* value, const int64_t* shapes, const int64_t* lsi,
                    const void* raw_off, const void* raw_logit, const void* grad_out, void* out_or_grad_off,
                    void* grad_logit, MsdaDims d, void* records, const void* reference, float* grad_reference,
-                   int ref_dim, int ref_div, void* grad_value_f32, hipStream_t stream) {
+                   int ref_dim, int ref_div, void* grad_value_f32, void* tile_summary, float* tile_loc, float* tile_attn,
+                   hipStream_t stream) {
   // grad_value_f32: the fp32 target of the query-split levels' atomics (grad_value itself for fp32 values, the split
-  // image for 16-bit ones), or null
-  const FusedArgs fa{reference, grad_reference, ref_dim, ref_div, backward ? static_cast<float*>(grad_value_f32) : nullptr};
-#define VNX_ARGS backward, value, shapes, lsi, raw_off, raw_logit, grad_out, out_or_grad_off, grad_logit, d, records, fa, stream
+  // image for 16-bit ones), or null.  Backward: either `records` (record-fed grad_value kernel) or tile_summary +
+  // tile_loc + tile_attn (tile-fed one: queries per tile = msda_bwd_tile_queries(d, 0))
+  const FusedArgs fa{reference, grad_reference, ref_dim, ref_div, backward ? static_cast<float*>(grad_value_f32) : nullptr,
+                     backward ? tile_loc : nullptr, backward ? tile_attn : nullptr};
+#define VNX_ARGS backward, value, shapes, lsi, raw_off, raw_logit, grad_out, out_or_grad_off, grad_logit, d, records, tile_summary, fa, stream
   if (vdt == VNX_F32) return fused_dispatch<float, float>(VNX_ARGS);
   if (vdt == VNX_BF16 && ldt == VNX_F32) return fused_dispatch<bf16_t, float>(VNX_ARGS);
   if (vdt == VNX_BF16 && ldt == VNX_BF16) return fused_dispatch<bf16_t, bf16_t>(VNX_ARGS);

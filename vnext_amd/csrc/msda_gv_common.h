@@ -41,7 +41,11 @@ template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, float4_t v
   uint2_t r;
   r.x = uint32_t(f32_to_bf16_bits(v.x)) | (uint32_t(f32_to_bf16_bits(v.y)) << 16);
   r.y = uint32_t(f32_to_bf16_bits(v.z)) | (uint32_t(f32_to_bf16_bits(v.w)) << 16);
+#ifdef VNX_GV_STORE16_PLAIN      // A/B build (tools/r3_call23.sh)
+  *reinterpret_cast<uint2_t*>(p) = r;
+#else
   __builtin_nontemporal_store(r, reinterpret_cast<uint2_t*>(p));
+#endif
 }
 template <> __device__ __forceinline__ void store4<f16_t>(f16_t* p, float4_t v) {
   uint2_t r;

@@ -116,6 +116,8 @@ struct FusedArgs {
   int ref_dim;             // 2 or 4
   int ref_div;             // consecutive batch elements sharing one reference row (frames of a clip)
   float* qsplit_zero;      // backward, fp32 grad_value: rows of the query-split levels are zeroed here (or null)
+  float* tile_loc;         // backward, tile mode of grad_value (msda_d32_gvtiles.hip): the decoded locations [B,Lq,M,L,P,2]
+  float* tile_attn;        //   and softmax weights [B,Lq,M,L,P] are left here in fp32 for that kernel (or null)
 };
 
 // Query split of the grad_value units (msda_d32_gvrec.hip).  A level of at most two row-units (the coarse
