@@ -141,10 +141,10 @@ typedef unsigned short ushort2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {     // v_pk_min_u16
   return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(ushort2_t, a), __builtin_bit_cast(ushort2_t, b)));
 }
-// rows per unit of the grad_value kernels for a level of n pixels = gv_level_split(n, units_min).rpu
+// rows per unit of the grad_value kernels for a level of n pixels = gv_level_split(n, units_min, rows_max).rpu
 // (vnx_common.h), here without the integer-division sequence (one lane per sample evaluates it)
-__device__ __forceinline__ int gv_rows_per_unit(int n, int units_min) {
-  int units = (n + kGvRowsMax - 1) / kGvRowsMax;
+__device__ __forceinline__ int gv_rows_per_unit(int n, int units_min, int rows_max) {
+  int units = (n + rows_max - 1) / rows_max;
   if (units < units_min) units = units_min;
   if (units > n) units = n;
   return units > 0 ? small_div(n + units - 1, units) : 1;
@@ -799,7 +799,7 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
       const int t_in_b = tile - b * tiles_per_batch;
       for (int l = 0; l < d.L; ++l) {
         const int n = int(shapes[2 * l]) * int(shapes[2 * l + 1]);
-        if (gv_query_splits(gv_level_split(n, units_min).units, d.Lq, d.P, true, d.B * d.M) > 1) {
+        if (gv_query_splits(gv_level_split(n, units_min, tile_summary != nullptr ? kGvTileRowsMax : kGvRowsMax).units, d.Lq, d.P, true, d.B * d.M) > 1) {
           float* rows = fa.qsplit_zero + ((int64_t(b) * d.S + int(lsi[l])) * d.M + m) * D;
           for (int r = (t_in_b * WPB + wave) * 8 + (lane >> 3); r < n; r += tiles_per_batch * WPB * 8)
             *reinterpret_cast<float4_t*>(rows + int64_t(r) * d.M * D + (lane & 7) * 4) = float4_t{0.f, 0.f, 0.f, 0.f};
@@ -863,7 +863,7 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
             const int p00 = h0 * W + w0;
             const int lo = (top && lef) ? p00 : (top && rig) ? p00 + 1 : (bot && lef) ? p00 + W : p00 + W + 1;
             const int hi = (bot && rig) ? p00 + W + 1 : (bot && lef) ? p00 + W : (top && rig) ? p00 + 1 : p00;
-            const int rpu = gv_rows_per_unit(H * W, units_min);
+            const int rpu = gv_rows_per_unit(H * W, units_min, kGvTileRowsMax);
             const uint32_t key = uint32_t(small_div(lo, rpu)) | ((0xffffu - uint32_t(small_div(hi, rpu))) << 16);
             tile_key = pk_min_u16(tile_key, key);
           }
@@ -885,7 +885,7 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
             const int p00 = h0 * W + w0;
             const int lo = (top && lef) ? p00 : (top && rig) ? p00 + 1 : (bot && lef) ? p00 + W : p00 + W + 1;
             const int hi = (bot && rig) ? p00 + W + 1 : (bot && lef) ? p00 + W : (top && rig) ? p00 + 1 : p00;
-            const int rpu = gv_rows_per_unit(H * W, units_min);
+            const int rpu = gv_rows_per_unit(H * W, units_min, kGvRowsMax);
             uu = uint32_t(small_div(lo, rpu)) | (uint32_t(small_div(hi, rpu)) << 16);
           }
           sample_units[ri] = uu;

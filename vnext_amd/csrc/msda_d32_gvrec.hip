@@ -93,7 +93,7 @@ msda_bwd_gv_rec_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
   if (tid < d.L) {
     const int H = int(shapes[2 * tid]), W = int(shapes[2 * tid + 1]);
     const int n = H * W;
-    const GvSplit sp = gv_level_split(n, units_min);
+    const GvSplit sp = gv_level_split(n, units_min, kRowsMax);
     const int units = sp.units, rpu = sp.rpu;
     meta[4 * tid] = H; meta[4 * tid + 1] = W; meta[4 * tid + 2] = int(lsi[tid]);
     meta[4 * tid + 3] = units | (rpu << 12);
@@ -367,7 +367,7 @@ msda_bwd_gv_sel_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
   if (tid < d.L) {
     const int H = int(shapes[2 * tid]), W = int(shapes[2 * tid + 1]);
     const int n = H * W;
-    const GvSplit sp = gv_level_split(n, units_min);
+    const GvSplit sp = gv_level_split(n, units_min, kRowsMax);
     const int units = sp.units, rpu = sp.rpu;
     const int qs = gv_query_splits(units, d.Lq, P, sizeof(TV) == 4 || split_image != nullptr, d.B * d.M);
     meta[4 * tid] = H; meta[4 * tid + 1] = W; meta[4 * tid + 2] = int(lsi[tid]);
@@ -646,10 +646,10 @@ msda_bwd_gv_sel_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
 
 }  // namespace rec
 
-int msda_gvrec_units_bound(const MsdaDims& d, int units_min) {
-  // row-units of all levels, plus the extra pieces of the query-split levels (at most two row-units each)
+int msda_gvrec_units_bound(const MsdaDims& d, int units_min, int rows_max) {
+  // row-units of all levels, plus the extra pieces of the query-split levels (at most four row-units each)
   const int qs = gv_query_splits(1, d.Lq, d.P, true, d.B * d.M);
-  return d.L * (units_min + 1) + (d.S + rec::kRowsMax - 1) / rec::kRowsMax + d.L * 4 * (qs - 1);
+  return d.L * (units_min + 1) + (d.S + rows_max - 1) / rows_max + d.L * 4 * (qs - 1);
 }
 
 size_t msda_gvrec_record_bytes(const MsdaDims& d) {   // records + (aligned) unit ranges
@@ -664,7 +664,7 @@ bool msda_d32_gvrec_supported(int vdt, int ldt, const MsdaDims& d) {
   if (int64_t(d.Lq) * d.P >= (int64_t(1) << 31)) return false;
   // 24-bit stride multiplies in the selection kernel: query index and heads x channels below 2^24, offsets below 2^32
   if (d.Lq >= (1 << 24) || d.M * 32 >= (1 << 24) || int64_t(d.Lq) * d.M * 32 >= (int64_t(1) << 32)) return false;
-  const int64_t blocks = int64_t(d.B) * d.M * msda_gvrec_units_bound(d, 16);
+  const int64_t blocks = int64_t(d.B) * d.M * msda_gvrec_units_bound(d, 16, rec::kRowsMax);
   return blocks < (int64_t(1) << 31);
 }
 
@@ -674,7 +674,7 @@ static int launch_gvrec(const int64_t* shapes, const int64_t* lsi, const void* r
                         int debug, int mode, float* split_image, hipStream_t stream) {
   // mode 0: per-unit sample selection (P == 4); 3: register slab, every unit scans its level;
   // 1: the LDS-slab form (variants 425 / 420 select the last two)
-  const int units_bound = msda_gvrec_units_bound(d, units_min);
+  const int units_bound = msda_gvrec_units_bound(d, units_min, rec::kRowsMax);
   const int64_t blocks = int64_t(d.B) * d.M * units_bound;
   if (mode == 0 && d.P == 4 && d.L <= rec::kLevelsMax) {
     const uint32_t* unit_ids = reinterpret_cast<const uint32_t*>((const char*)records + gv_unit_ids_offset(d));
@@ -715,7 +715,8 @@ int msda_backward_gvrec_d32(int vdt, const int64_t* shapes, const int64_t* lsi, 
 template <typename TV>
 __global__ void __launch_bounds__(256)
 split_levels_convert_kernel(const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
-                            const float* __restrict__ image, TV* __restrict__ grad_value, MsdaDims d, int units_min) {
+                            const float* __restrict__ image, TV* __restrict__ grad_value, MsdaDims d, int units_min,
+                            int rows_max) {
   if (!levels_packed(shapes, lsi, d.L, d.S)) return;
   // the split levels' pixel ranges, once per workgroup (the first form evaluated the level table per element, with its
   // loads: 14 us per 360p call for 6 MB of rows)
@@ -723,7 +724,7 @@ split_levels_convert_kernel(const int64_t* __restrict__ shapes, const int64_t* _
   if (int(threadIdx.x) < d.L) {
     const int l = threadIdx.x;
     const int st = int(lsi[l]), n = int(shapes[2 * l]) * int(shapes[2 * l + 1]);
-    const bool split = gv_query_splits(gv_level_split(n, units_min).units, d.Lq, d.P, true, d.B * d.M) > 1;
+    const bool split = gv_query_splits(gv_level_split(n, units_min, rows_max).units, d.Lq, d.P, true, d.B * d.M) > 1;
     s_lo[l] = split ? st : 0; s_hi[l] = split ? st + n : 0;
   }
   __syncthreads();
@@ -738,7 +739,7 @@ split_levels_convert_kernel(const int64_t* __restrict__ shapes, const int64_t* _
 }
 
 int msda_split_levels_convert(int vdt, const int64_t* shapes, const int64_t* lsi, const float* image, void* grad_value,
-                              MsdaDims d, hipStream_t stream) {
+                              MsdaDims d, int rows_max, hipStream_t stream) {      // rows_max: of the grad_value path that ran
   const int units_min = gv_units_min(d);
   const int64_t n4 = int64_t(d.B) * d.S * d.M * 8;
   int64_t blocks = (n4 + 255) / 256;
@@ -746,10 +747,10 @@ int msda_split_levels_convert(int vdt, const int64_t* shapes, const int64_t* lsi
   if (blocks < 1) blocks = 1;
   if (vdt == VNX_BF16)
     hipLaunchKernelGGL((split_levels_convert_kernel<bf16_t>), dim3(uint32_t(blocks)), dim3(256), 0, stream, shapes, lsi, image,
-                       (bf16_t*)grad_value, d, units_min);
+                       (bf16_t*)grad_value, d, units_min, rows_max);
   else if (vdt == VNX_F16)
     hipLaunchKernelGGL((split_levels_convert_kernel<f16_t>), dim3(uint32_t(blocks)), dim3(256), 0, stream, shapes, lsi, image,
-                       (f16_t*)grad_value, d, units_min);
+                       (f16_t*)grad_value, d, units_min, rows_max);
   else
     return VNX_OK;
   return check_launch("split_levels_convert");

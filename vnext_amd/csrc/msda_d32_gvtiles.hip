@@ -28,13 +28,21 @@
 namespace vnx {
 namespace rec {
 
-constexpr int kTileWin = 4 * kThreads;            // tile words examined per selection round: 2 048
-constexpr int kTileParts = 4 * kWaves;            // (round, wave) pieces per selection
-constexpr size_t kTilesLdsBytes = size_t(kQcMax) * 128 + size_t(kThreads) * 32 + size_t(kRowsMax) * 12 + 16 +
+#ifndef VNX_TILE_ROUNDS
+#define VNX_TILE_ROUNDS 2
+#endif
+#ifndef VNX_TILE_UNITS_PER_CU
+#define VNX_TILE_UNITS_PER_CU 4
+#endif
+constexpr int kTileRowsMax = kGvTileRowsMax;      // 256 rows per unit: 4 per 8-lane group
+constexpr int kTileRounds = VNX_TILE_ROUNDS;
+constexpr int kTileWin = kTileRounds * kThreads;  // tile words examined per selection round: 1 024
+constexpr int kTileParts = kTileRounds * kWaves;  // (round, wave) pieces per selection
+constexpr size_t kTilesLdsBytes = size_t(kQcMax) * 128 + size_t(kThreads) * 32 + size_t(kTileRowsMax) * 12 + 16 +
                                   4 * kLevelsMax * 4 + size_t(kTileWin) * 2 + size_t(kTileParts) * 8 + 16;
 
 template <typename TV, typename TL>
-__global__ void __launch_bounds__(kThreads, VNX_SEL_UNITS_PER_CU * kWaves / 4)
+__global__ void __launch_bounds__(kThreads, VNX_TILE_UNITS_PER_CU * kWaves / 4)
 msda_bwd_gv_tiles_kernel(const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
                          const TL* __restrict__ loc, const TL* __restrict__ attn,
                          const uint32_t* __restrict__ summaries, const TV* __restrict__ grad_out,
@@ -45,8 +53,8 @@ msda_bwd_gv_tiles_kernel(const int64_t* __restrict__ shapes, const int64_t* __re
   float4_t* grows = reinterpret_cast<float4_t*>(smem);                       // [128][8] grad_out rows
   uint2_t* list = reinterpret_cast<uint2_t*>(grows + kQcMax * 8);            // [4*threads] taps
   uint32_t* cnt2 = reinterpret_cast<uint32_t*>(list + 4 * kThreads);         // [2][rows]
-  uint32_t* offs = cnt2 + 2 * kRowsMax;                                      // [rows]
-  uint32_t* alloc = offs + kRowsMax;                                         // [4]
+  uint32_t* offs = cnt2 + 2 * kTileRowsMax;                                      // [rows]
+  uint32_t* alloc = offs + kTileRowsMax;                                         // [4]
   int* meta = reinterpret_cast<int*>(alloc + 4);                             // [4*L]
   uint16_t* hit = reinterpret_cast<uint16_t*>(meta + 4 * kLevelsMax);        // [kTileWin] window-relative tile
   uint32_t* part_s = reinterpret_cast<uint32_t*>(hit + kTileWin);            // [32] kept tiles per piece
@@ -64,12 +72,12 @@ msda_bwd_gv_tiles_kernel(const int64_t* __restrict__ shapes, const int64_t* __re
 
   if (tid < d.L) {
     const int H = int(shapes[2 * tid]), W = int(shapes[2 * tid + 1]);
-    const GvSplit sp = gv_level_split(H * W, units_min);
+    const GvSplit sp = gv_level_split(H * W, units_min, kTileRowsMax);
     const int qs = gv_query_splits(sp.units, d.Lq, P, sizeof(TV) == 4 || split_image != nullptr, d.B * d.M);
     meta[4 * tid] = H; meta[4 * tid + 1] = W; meta[4 * tid + 2] = int(lsi[tid]);
     meta[4 * tid + 3] = sp.units | (sp.rpu << 12) | (qs << 24);     // units <= 4000, rpu <= 320, qs <= 8
   }
-  for (int i = tid; i < 2 * kRowsMax; i += kThreads) cnt2[i] = 0;
+  for (int i = tid; i < 2 * kTileRowsMax; i += kThreads) cnt2[i] = 0;
   if (tid == 0) alloc[0] = 0;
   __syncthreads();
 
@@ -105,7 +113,7 @@ msda_bwd_gv_tiles_kernel(const int64_t* __restrict__ shapes, const int64_t* __re
   u_lvl = __builtin_amdgcn_readfirstlane(u_lvl); qsplit = __builtin_amdgcn_readfirstlane(qsplit);
   qpiece = __builtin_amdgcn_readfirstlane(qpiece);
   const int rows = r1 - r0;
-  constexpr int kRpg = (kRowsMax + kGroups - 1) / kGroups;
+  constexpr int kRpg = (kTileRowsMax + kGroups - 1) / kGroups;
   float4_t racc[kRpg];
 #pragma unroll
   for (int k = 0; k < kRpg; ++k) racc[k] = float4_t{0.f, 0.f, 0.f, 0.f};
@@ -133,10 +141,10 @@ msda_bwd_gv_tiles_kernel(const int64_t* __restrict__ shapes, const int64_t* __re
     const int n_w = t_hi - win0 < kTileWin ? t_hi - win0 : kTileWin;
     const int tw = opaque(tid);
     // ---- selection: which tiles of this round touch my rows -----------------------------------
-    unsigned long long bal[4];
+    unsigned long long bal[kTileRounds];
     uint32_t hitbits = 0;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < kTileRounds; ++r) {
       const int ti = r * kThreads + tw;
       // word = unit_lo | (0xffff - unit_hi) << 16 (what a packed 16-bit minimum reduces); 0xffffffff = no taps
       const uint32_t v = ti < n_w ? summ[win0 + ti] : 0xffffffffu;
@@ -158,7 +166,7 @@ msda_bwd_gv_tiles_kernel(const int64_t* __restrict__ shapes, const int64_t* __re
     const int n_hit = int(tot[0]);
     if (n_hit == 0) continue;                         // uniform: no tile of this round lands here
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < kTileRounds; ++r) {
       if (hitbits & (1u << r)) {
         const uint32_t lo32 = __builtin_amdgcn_mbcnt_lo(uint32_t(bal[r]), 0u);
         const uint32_t pos = pre_s[r * kWaves + wave] + __builtin_amdgcn_mbcnt_hi(uint32_t(bal[r] >> 32), lo32);
@@ -195,8 +203,8 @@ msda_bwd_gv_tiles_kernel(const int64_t* __restrict__ shapes, const int64_t* __re
     };
     prefetch(0);
     for (int c = 0; c < n_chunks; ++c, ++gchunk) {
-      uint32_t* cnt = cnt2 + (gchunk & 1) * kRowsMax;
-      uint32_t* cnt_next = cnt2 + ((gchunk + 1) & 1) * kRowsMax;
+      uint32_t* cnt = cnt2 + (gchunk & 1) * kTileRowsMax;
+      uint32_t* cnt_next = cnt2 + ((gchunk + 1) & 1) * kTileRowsMax;
       const float x = nx, y = ny, a = na;
       const bool valid = nvalid;
       const int tc = opaque(tid);
@@ -306,7 +314,7 @@ msda_bwd_gv_tiles_kernel(const int64_t* __restrict__ shapes, const int64_t* __re
 
 }  // namespace rec
 
-int msda_gvrec_units_bound(const MsdaDims& d, int units_min);
+int msda_gvrec_units_bound(const MsdaDims& d, int units_min, int rows_max);
 
 // bytes of the tile words: [batch][head][level][tile]
 size_t msda_gvtiles_summary_bytes(const MsdaDims& d, int tile_queries) {
@@ -318,11 +326,11 @@ bool msda_d32_gvtiles_supported(int vdt, int ldt, const MsdaDims& d) {
   if (d.D != 32 || d.P != 4 || vdt == VNX_F64) return false;
   if (vdt == VNX_F32 && ldt != VNX_F32) return false;
   if (d.L > rec::kLevelsMax) return false;
-  if (d.S > rec::kRowsMax * 4000) return false;     // units and rows/unit share one word
+  if (d.S > rec::kTileRowsMax * 4000) return false;     // units and rows/unit share one word
   // 24-bit stride multiplies: query index, heads x channels and heads x samples below 2^24; element offsets below 2^32
   if (d.Lq >= (1 << 24) || d.M * 32 >= (1 << 24) || d.M * d.L * 4 >= (1 << 24)) return false;
   if (int64_t(d.Lq) * d.M * 32 >= (int64_t(1) << 32) || int64_t(d.Lq) * d.M * d.L * 8 >= (int64_t(1) << 32)) return false;
-  const int64_t blocks = int64_t(d.B) * d.M * msda_gvrec_units_bound(d, 16);
+  const int64_t blocks = int64_t(d.B) * d.M * msda_gvrec_units_bound(d, 16, rec::kTileRowsMax);
   return blocks < (int64_t(1) << 31);
 }
 
@@ -337,7 +345,7 @@ static int launch_gvtiles(const int64_t* shapes, const int64_t* lsi, const void*
     return VNX_ERR_UNSUPPORTED;
   }
   const int n_tiles = (d.Lq + tile_queries - 1) / tile_queries;
-  const int64_t blocks = int64_t(d.B) * d.M * msda_gvrec_units_bound(d, units_min);
+  const int64_t blocks = int64_t(d.B) * d.M * msda_gvrec_units_bound(d, units_min, rec::kTileRowsMax);
   hipLaunchKernelGGL((rec::msda_bwd_gv_tiles_kernel<TV, TL>), dim3(uint32_t(blocks)), dim3(rec::kThreads),
                      rec::kTilesLdsBytes, stream, shapes, lsi, (const TL*)loc, (const TL*)attn,
                      (const uint32_t*)summaries, (const TV*)grad_out, (TV*)grad_value, d, units_min, tile_shift, n_tiles,

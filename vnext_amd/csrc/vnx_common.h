@@ -140,16 +140,21 @@ struct FusedArgs {
 // 123 -> 109 us at 360p, 450 -> 412 us at 720p; at B = 5 (a full grid) 4 pieces measured 1-2 % slower than 2.
 // The unit split of a level of n pixels, the ONE definition shared by the grad_loc kernel (which zeroes the rows of
 // query-split levels and tags every sample with the units it touches), the grad_value kernels' level tables and the
-// launcher's grid bound: at most kGvRowsMax rows per unit, at least units_min units, then normalised so that no unit is
+// launcher's grid bound: at most rows_max rows per unit (kGvRowsMax / kGvTileRowsMax by grad_value path), at least units_min units, then normalised so that no unit is
 // empty (units = ceil(n / rows_per_unit)).  (Round 2 had the zeroing phase use the count BEFORE normalisation: with
 // units_min = 5 a 16-pixel level gave 5 there and 4 in the grad_value kernel -- different sides of the query-split
 // threshold, atomics onto rows nobody had zeroed.  Latent at the default units_min = 2)
+// Rows per unit: 320 for the record-fed kernel (5 rows per 8-lane group, 72 VGPRs, 3 units per CU; 19 units per (batch,
+// head) at 360p = 760 workgroups, one round of the 768 resident), 256 for the tile-fed kernel (4 rows per group: 62 VGPRs
+// and 39 KB of LDS, FOUR units per CU -- encoder-360p backward 190.5 -> 176.8 us, 720p B = 2 341 -> 325 us; at 720p B = 5
+// the thinner strips cost 2 %: 718 -> 732 us).
 constexpr int kGvRowsMax = 320;
+constexpr int kGvTileRowsMax = 256;
 struct GvSplit { int units, rpu; };
-__host__ __device__ inline GvSplit gv_level_split(int n, int units_min) {
+__host__ __device__ inline GvSplit gv_level_split(int n, int units_min, int rows_max) {
   GvSplit s{0, 1};
   if (n > 0) {
-    int units = (n + kGvRowsMax - 1) / kGvRowsMax;
+    int units = (n + rows_max - 1) / rows_max;
     if (units < units_min) units = units_min;
     if (units > n) units = n;
     s.rpu = (n + units - 1) / units;
