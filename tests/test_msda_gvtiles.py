@@ -195,3 +195,39 @@ def test_fused_backward_records_path_and_tiles_path_agree(vdt):
     for a, b in zip(res[430], res[0]):
         np.testing.assert_allclose(a, b, rtol=0, atol=tol * scale(b))
     assert np.array_equal(res[430][1], res[0][1]) and np.array_equal(res[430][2], res[0][2])   # same kernel, same order
+
+
+# the unit grid of gv_level_grid (vnx_common.h): levels from 128 pixels of width up are cut into blocks of about
+# 32 x 8 pixels, flat wide levels (H < 8) into wider blocks, narrow levels into bands of whole image rows
+WIDE = [(20, 130), (10, 65), (5, 33), (3, 17)]           # S = 3466: level 0 in blocks of 26 x 9 (5 x 3 of them)
+FLAT = [(5, 300), (3, 150), (2, 75), (1, 38)]            # S = 2138: levels 0 and 1 in flat blocks, H < 8
+LINE = [(1, 700), (1, 350), (1, 175), (1, 88)]           # S = 1313: one-row levels
+
+
+@pytest.mark.parametrize("name,shapes", [("wide", WIDE), ("flat", FLAT), ("line", LINE)])
+@pytest.mark.parametrize("vdt", [torch.float32, torch.bfloat16])
+def test_block_units_of_wide_levels(name, shapes, vdt):
+    S = sum(h * w for h, w in shapes)
+    case = pixel_queries(shapes, 2, S, seed=len(name))
+    if vdt == torch.float32:
+        # fp32 pixel coordinates x * W - 0.5 carry ulp(W) of rounding: 6e-5 px at W = 700, which the bilinear weights and the
+        # attention gradient inherit (both grad_value paths show the same 1.3e-5 / 3.8e-5 there; the reference computes in fp32 too)
+        tol = 8e-5 if name == "line" else 2e-5
+        check(run(case, 0), oracle(case), case, tol)
+        units3 = run(case, 203)                            # at least three units per level
+        check(units3, oracle(case), case, tol)
+    else:
+        gv, gl, ga = run(case, 0, vdt)
+        rv, rl, ra = oracle(case, vdt)
+        np.testing.assert_allclose(gv, rv, rtol=0, atol=1e-2 * scale(rv))
+        np.testing.assert_allclose(ga, ra, rtol=0, atol=1e-2 * scale(ra))
+
+
+def test_block_units_with_far_and_border_samples():
+    """samples far from their query (any block may be hit), on the border and outside of a wide level"""
+    sh, lsi, value, loc, attn, go = pixel_queries(WIDE, 1, 3466, seed=9, far=0.3)
+    g = torch.Generator().manual_seed(10)
+    loc = loc.clone()
+    loc[:, ::7] = torch.rand(loc[:, ::7].shape, generator=g) * 1.2 - 0.1       # in and around the map, incl. its edges
+    case = (sh, lsi, value, loc, attn, go)
+    check(run(case, 0), oracle(case), case)

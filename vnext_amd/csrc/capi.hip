@@ -66,7 +66,7 @@ bool msda_d32_gvrec_supported(int vdt, int ldt, const MsdaDims& d);
 size_t msda_gvrec_record_bytes(const MsdaDims& d);
 int msda_backward_gvrec_d32(int vdt, const int64_t*, const int64_t*, const void* records, const void*,
                             void*, MsdaDims, int variant, float* split_image, hipStream_t);
-int msda_split_levels_convert(int vdt, const int64_t*, const int64_t*, const float* image, void* grad_value, MsdaDims, int rows_max,
+int msda_split_levels_convert(int vdt, const int64_t*, const int64_t*, const float* image, void* grad_value, MsdaDims, bool tiles,
                               hipStream_t);
 
 static int check_common(const char* fn, int vdt, int ldt, const void* value,
@@ -354,7 +354,7 @@ int vnx_msda_backward(int value_dtype, int loc_dtype, const void* value,
       if (st != VNX_OK) return st;
       if (split_image) {
         st = msda_split_levels_convert(value_dtype, spatial_shapes, level_start_index, split_image, grad_value, d,
-                                       tiles ? kGvTileRowsMax : kGvRowsMax, stream);
+                                       tiles, stream);
         if (st != VNX_OK) return st;
       }
     }
@@ -540,7 +540,7 @@ int vnx_msda_fused_backward(int value_dtype, int query_dtype, const void* value,
   if (st != VNX_OK) return st;
   if (split_image)
     return msda_split_levels_convert(value_dtype, spatial_shapes, level_start_index, split_image, grad_value, d,
-                                     fs.tiles ? kGvTileRowsMax : kGvRowsMax, stream);
+                                     fs.tiles, stream);
   return VNX_OK;
 }
 

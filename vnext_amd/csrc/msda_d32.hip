@@ -798,8 +798,8 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
         levels_packed(shapes, lsi, d.L, d.S)) {
       const int t_in_b = tile - b * tiles_per_batch;
       for (int l = 0; l < d.L; ++l) {
-        const int n = int(shapes[2 * l]) * int(shapes[2 * l + 1]);
-        if (gv_query_splits(gv_level_split(n, units_min, tile_summary != nullptr ? kGvTileRowsMax : kGvRowsMax).units, d.Lq, d.P, true, d.B * d.M) > 1) {
+        const int Hz = int(shapes[2 * l]), Wz = int(shapes[2 * l + 1]), n = Hz * Wz;
+        if (gv_query_splits(gv_level_units(Hz, Wz, units_min, tile_summary != nullptr), d.Lq, d.P, true, d.B * d.M) > 1) {
           float* rows = fa.qsplit_zero + ((int64_t(b) * d.S + int(lsi[l])) * d.M + m) * D;
           for (int r = (t_in_b * WPB + wave) * 8 + (lane >> 3); r < n; r += tiles_per_batch * WPB * 8)
             *reinterpret_cast<float4_t*>(rows + int64_t(r) * d.M * D + (lane & 7) * 4) = float4_t{0.f, 0.f, 0.f, 0.f};
@@ -812,9 +812,11 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
   const int pairs = QPW * LP;
   int keep_H = 1, keep_W = 1;      // level size of this lane's sample: reused by phase 3 when pairs <= 64
   // tile mode of the grad_value path (msda_d32_gvtiles.hip; L*P == 16, P == 4): instead of a record and a unit range per
-  // SAMPLE, this workgroup leaves per level ONE word: the range of grad_value units the corners of its queries' samples
-  // touch, as  unit_lo | (0xffff - unit_hi) << 16  -- the form a packed 16-bit minimum reduces; 0xffffffff = no taps
-  uint32_t tile_key = 0xffffffffu;
+  // SAMPLE, this workgroup leaves per level the BOUNDING BOX of the pixels its queries' samples touch, two words:
+  //   x_lo | (0xffff - x_hi) << 16   and   y_lo | (0xffff - y_hi) << 16
+  // -- the form a packed 16-bit minimum reduces; 0xffffffff = no taps.  (Until late in round 3 it was the range of
+  // strip units, which cost two divisions per sample here and tied this kernel to the unit geometry.)
+  uint32_t tile_kx = 0xffffffffu, tile_ky = 0xffffffffu;
   for (int e = lane; e < pairs; e += 64) {
     const int qi = e / LP, p = e - qi * LP;
     const int q = q0 + qi;
@@ -860,12 +862,11 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
                          __float_as_uint(g4.y), __float_as_uint(a)};
         if constexpr (LP_T == 16 && !ATOMICS) {
           if (tile_summary != nullptr) {
-            const int p00 = h0 * W + w0;
-            const int lo = (top && lef) ? p00 : (top && rig) ? p00 + 1 : (bot && lef) ? p00 + W : p00 + W + 1;
-            const int hi = (bot && rig) ? p00 + W + 1 : (bot && lef) ? p00 + W : (top && rig) ? p00 + 1 : p00;
-            const int rpu = gv_rows_per_unit(H * W, units_min, kGvTileRowsMax);
-            const uint32_t key = uint32_t(small_div(lo, rpu)) | ((0xffffu - uint32_t(small_div(hi, rpu))) << 16);
-            tile_key = pk_min_u16(tile_key, key);
+            // coordinates saturate at 0xfffe, which the grad_value kernel reads as "or beyond" (a level side of 65 535+)
+            const uint32_t x_lo = min(uint32_t(lef ? w0 : w0 + 1), 0xfffeu), x_hi = min(uint32_t(rig ? w0 + 1 : w0), 0xfffeu);
+            const uint32_t y_lo = min(uint32_t(top ? h0 : h0 + 1), 0xfffeu), y_hi = min(uint32_t(bot ? h0 + 1 : h0), 0xfffeu);
+            tile_kx = pk_min_u16(tile_kx, x_lo | ((0xffffu - x_hi) << 16));
+            tile_ky = pk_min_u16(tile_ky, y_lo | ((0xffffu - y_hi) << 16));
           }
         }
       }
@@ -895,17 +896,22 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
     s_off[qi * (LP + 1) + p] = o4;
     s_geo[qi * (LP + 1) + p] = g4;
   }
-  uint32_t* s_tile = reinterpret_cast<uint32_t*>(smem + size_t(WPB) * 3 * ent * 16);    // [WPB][4] (tile mode)
+  uint2_t* s_tile = reinterpret_cast<uint2_t*>(smem + size_t(WPB) * 3 * ent * 16);    // [WPB][4] (tile mode)
+  uint2_t* tile_words = reinterpret_cast<uint2_t*>(tile_summary);                       // [b][head][level][tile]
   if constexpr (LP_T == 16 && !ATOMICS) {
     if (tile_summary != nullptr) {       // uniform.  A lane's samples all have level (lane & 15) >> 2 (P == 4):
       // minimum over the 4 points (quad) and over the wave's queries (lane bits 4, 5)
-      tile_key = pk_min_u16(tile_key, uint32_t(__builtin_amdgcn_update_dpp(int(tile_key), int(tile_key), 0xB1, 0xF, 0xF, true)));
-      tile_key = pk_min_u16(tile_key, uint32_t(__builtin_amdgcn_update_dpp(int(tile_key), int(tile_key), 0x4E, 0xF, 0xF, true)));
-      tile_key = pk_min_u16(tile_key, uint32_t(__shfl_xor(int(tile_key), 16, 64)));
-      tile_key = pk_min_u16(tile_key, uint32_t(__shfl_xor(int(tile_key), 32, 64)));
+      tile_kx = pk_min_u16(tile_kx, uint32_t(__builtin_amdgcn_update_dpp(int(tile_kx), int(tile_kx), 0xB1, 0xF, 0xF, true)));
+      tile_ky = pk_min_u16(tile_ky, uint32_t(__builtin_amdgcn_update_dpp(int(tile_ky), int(tile_ky), 0xB1, 0xF, 0xF, true)));
+      tile_kx = pk_min_u16(tile_kx, uint32_t(__builtin_amdgcn_update_dpp(int(tile_kx), int(tile_kx), 0x4E, 0xF, 0xF, true)));
+      tile_ky = pk_min_u16(tile_ky, uint32_t(__builtin_amdgcn_update_dpp(int(tile_ky), int(tile_ky), 0x4E, 0xF, 0xF, true)));
+      tile_kx = pk_min_u16(tile_kx, uint32_t(__shfl_xor(int(tile_kx), 16, 64)));
+      tile_ky = pk_min_u16(tile_ky, uint32_t(__shfl_xor(int(tile_ky), 16, 64)));
+      tile_kx = pk_min_u16(tile_kx, uint32_t(__shfl_xor(int(tile_kx), 32, 64)));
+      tile_ky = pk_min_u16(tile_ky, uint32_t(__shfl_xor(int(tile_ky), 32, 64)));
       if ((lane & 3) == 0 && lane < 16) {
-        if (WPB > 1) s_tile[wave * 4 + (lane >> 2)] = tile_key;
-        else tile_summary[((int64_t(b) * d.M + m) * d.L + (lane >> 2)) * tiles_per_batch + (tile - b * tiles_per_batch)] = tile_key;
+        if (WPB > 1) s_tile[wave * 4 + (lane >> 2)] = uint2_t{tile_kx, tile_ky};
+        else tile_words[((int64_t(b) * d.M + m) * d.L + (lane >> 2)) * tiles_per_batch + (tile - b * tiles_per_batch)] = uint2_t{tile_kx, tile_ky};
       }
     }
   }
@@ -913,10 +919,13 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
   __builtin_amdgcn_wave_barrier();
   if constexpr (LP_T == 16 && !ATOMICS && WPB > 1) {
     if (tile_summary != nullptr && threadIdx.x < 4) {
-      uint32_t k = s_tile[threadIdx.x];
+      uint2_t k = s_tile[threadIdx.x];
 #pragma unroll
-      for (int w2 = 1; w2 < WPB; ++w2) k = pk_min_u16(k, s_tile[w2 * 4 + threadIdx.x]);
-      tile_summary[((int64_t(b) * d.M + m) * d.L + int(threadIdx.x)) * tiles_per_batch + (tile - b * tiles_per_batch)] = k;
+      for (int w2 = 1; w2 < WPB; ++w2) {
+        const uint2_t o = s_tile[w2 * 4 + threadIdx.x];
+        k.x = pk_min_u16(k.x, o.x); k.y = pk_min_u16(k.y, o.y);
+      }
+      tile_words[((int64_t(b) * d.M + m) * d.L + int(threadIdx.x)) * tiles_per_batch + (tile - b * tiles_per_batch)] = k;
     }
   }
 
@@ -1152,7 +1161,7 @@ static int launch_bwd_cfg(const void* value, const int64_t* shapes, const int64_
     set_error("msda_backward: %lld workgroups exceed the grid limit", (long long)blocks);
     return VNX_ERR_UNSUPPORTED;
   }
-  const size_t lds = size_t(WPB) * 3 * QPW * (LP + 1) * 16 + 64;     // + [WPB][4] tile words (tile mode)
+  const size_t lds = size_t(WPB) * 3 * QPW * (LP + 1) * 16 + 128;    // + [WPB][4] tile word pairs (tile mode)
   // the unit ranges sit behind the records in the workspace (gv_unit_ids_offset); only the P == 4
   // grad_value kernel reads them
   void* unit_ids = (records != nullptr && d.P == 4) ? (void*)((char*)records + gv_unit_ids_offset(d)) : nullptr;
@@ -1250,7 +1259,7 @@ static int launch_bwd_fused_cfg(const void* value, const int64_t* shapes, const 
     set_error("msda_fused_backward: %lld workgroups exceed the grid limit", (long long)blocks);
     return VNX_ERR_UNSUPPORTED;
   }
-  const size_t lds = size_t(WPB) * 3 * QPW * 17 * 16 + 64;
+  const size_t lds = size_t(WPB) * 3 * QPW * 17 * 16 + 128;
   void* unit_ids = (records != nullptr && d.P == 4) ? (void*)((char*)records + gv_unit_ids_offset(d)) : nullptr;
   const int units_min = gv_units_min(d);
   constexpr int kLpr = sizeof(TV) == 2 ? 4 : 8;

@@ -716,15 +716,15 @@ template <typename TV>
 __global__ void __launch_bounds__(256)
 split_levels_convert_kernel(const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
                             const float* __restrict__ image, TV* __restrict__ grad_value, MsdaDims d, int units_min,
-                            int rows_max) {
+                            bool tiles) {
   if (!levels_packed(shapes, lsi, d.L, d.S)) return;
   // the split levels' pixel ranges, once per workgroup (the first form evaluated the level table per element, with its
   // loads: 14 us per 360p call for 6 MB of rows)
   __shared__ int s_lo[rec::kLevelsMax], s_hi[rec::kLevelsMax];
   if (int(threadIdx.x) < d.L) {
     const int l = threadIdx.x;
-    const int st = int(lsi[l]), n = int(shapes[2 * l]) * int(shapes[2 * l + 1]);
-    const bool split = gv_query_splits(gv_level_split(n, units_min, rows_max).units, d.Lq, d.P, true, d.B * d.M) > 1;
+    const int st = int(lsi[l]), Hc = int(shapes[2 * l]), Wc = int(shapes[2 * l + 1]), n = Hc * Wc;
+    const bool split = gv_query_splits(gv_level_units(Hc, Wc, units_min, tiles), d.Lq, d.P, true, d.B * d.M) > 1;
     s_lo[l] = split ? st : 0; s_hi[l] = split ? st + n : 0;
   }
   __syncthreads();
@@ -739,7 +739,7 @@ split_levels_convert_kernel(const int64_t* __restrict__ shapes, const int64_t* _
 }
 
 int msda_split_levels_convert(int vdt, const int64_t* shapes, const int64_t* lsi, const float* image, void* grad_value,
-                              MsdaDims d, int rows_max, hipStream_t stream) {      // rows_max: of the grad_value path that ran
+                              MsdaDims d, bool tiles, hipStream_t stream) {      // tiles: the grad_value path that ran
   const int units_min = gv_units_min(d);
   const int64_t n4 = int64_t(d.B) * d.S * d.M * 8;
   int64_t blocks = (n4 + 255) / 256;
@@ -747,10 +747,10 @@ int msda_split_levels_convert(int vdt, const int64_t* shapes, const int64_t* lsi
   if (blocks < 1) blocks = 1;
   if (vdt == VNX_BF16)
     hipLaunchKernelGGL((split_levels_convert_kernel<bf16_t>), dim3(uint32_t(blocks)), dim3(256), 0, stream, shapes, lsi, image,
-                       (bf16_t*)grad_value, d, units_min, rows_max);
+                       (bf16_t*)grad_value, d, units_min, tiles);
   else if (vdt == VNX_F16)
     hipLaunchKernelGGL((split_levels_convert_kernel<f16_t>), dim3(uint32_t(blocks)), dim3(256), 0, stream, shapes, lsi, image,
-                       (f16_t*)grad_value, d, units_min, rows_max);
+                       (f16_t*)grad_value, d, units_min, tiles);
   else
     return VNX_OK;
   return check_launch("split_levels_convert");

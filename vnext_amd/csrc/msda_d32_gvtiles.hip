@@ -9,11 +9,12 @@
 //
 // Here selection works on TILES of queries: a workgroup of the grad_loc kernel handles T consecutive queries (T = 16
 // on large calls) of one (batch, head), and consecutive queries of an encoder call are neighbouring pixels whose
-// samples land next to each other.  That workgroup reduces, per level, the range of grad_value units its samples'
-// corners touch and leaves ONE 4-byte word per (batch, head, level, tile): 319 words per level at 360p where there
-// were 20 400 tags.  A unit of this kernel
-//   1. reads its level's tile words (one load round per 512 tiles), keeps the tiles whose range contains it
-//      (wave ballots + one 32-entry scan: ascending order, so every sum stays deterministic);
+// samples land next to each other.  That workgroup reduces, per level, the bounding box of the pixels its samples'
+// corners touch and leaves TWO 4-byte words per (batch, head, level, tile): 319 word pairs per level at 360p where
+// there were 20 400 tags.  A unit of this kernel -- a rectangle of <= 256 pixels of one level: a band of whole image
+// rows of a narrow level, a block of about 32 x 8 pixels of a wide one (gv_level_grid, vnx_common.h) --
+//   1. reads its level's tile words (one load round per 512 tiles), keeps the tiles whose box meets its rectangle
+//      (wave ballots + one 32-entry scan: ascending order);
 //   2. walks the kept tiles 128 queries (8 tiles) per chunk: one sample per thread -- its location and weight read
 //      from the op's own inputs, the geometry recomputed (15 VALU instructions; the predecessor of the record kernel
 //      was slow because every unit recomputed ALL samples of its level, not because of these) -- the tiles' grad_out
@@ -39,13 +40,13 @@ constexpr int kTileRounds = VNX_TILE_ROUNDS;
 constexpr int kTileWin = kTileRounds * kThreads;  // tile words examined per selection round: 1 024
 constexpr int kTileParts = kTileRounds * kWaves;  // (round, wave) pieces per selection
 constexpr size_t kTilesLdsBytes = size_t(kQcMax) * 128 + size_t(kThreads) * 32 + size_t(kTileRowsMax) * 12 + 16 +
-                                  4 * kLevelsMax * 4 + size_t(kTileWin) * 2 + size_t(kTileParts) * 8 + 16;
+                                  8 * kLevelsMax * 4 + size_t(kTileWin) * 2 + size_t(kTileParts) * 8 + 16;
 
 template <typename TV, typename TL>
 __global__ void __launch_bounds__(kThreads, VNX_TILE_UNITS_PER_CU * kWaves / 4)
 msda_bwd_gv_tiles_kernel(const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
                          const TL* __restrict__ loc, const TL* __restrict__ attn,
-                         const uint32_t* __restrict__ summaries, const TV* __restrict__ grad_out,
+                         const uint2_t* __restrict__ summaries, const TV* __restrict__ grad_out,
                          TV* __restrict__ grad_value, MsdaDims d, int units_min, int tile_shift, int n_tiles,
                          float* __restrict__ split_image) {
   constexpr int D = 32, P = 4;
@@ -55,8 +56,8 @@ msda_bwd_gv_tiles_kernel(const int64_t* __restrict__ shapes, const int64_t* __re
   uint32_t* cnt2 = reinterpret_cast<uint32_t*>(list + 4 * kThreads);         // [2][rows]
   uint32_t* offs = cnt2 + 2 * kTileRowsMax;                                      // [rows]
   uint32_t* alloc = offs + kTileRowsMax;                                         // [4]
-  int* meta = reinterpret_cast<int*>(alloc + 4);                             // [4*L]
-  uint16_t* hit = reinterpret_cast<uint16_t*>(meta + 4 * kLevelsMax);        // [kTileWin] window-relative tile
+  int* meta = reinterpret_cast<int*>(alloc + 4);                             // [8*L]
+  uint16_t* hit = reinterpret_cast<uint16_t*>(meta + 8 * kLevelsMax);        // [kTileWin] window-relative tile
   uint32_t* part_s = reinterpret_cast<uint32_t*>(hit + kTileWin);            // [32] kept tiles per piece
   uint32_t* pre_s = part_s + kTileParts;                                     // [32] exclusive prefixes
   uint32_t* tot = pre_s + kTileParts;                                        // [1] kept tiles of the round
@@ -70,37 +71,42 @@ msda_bwd_gv_tiles_kernel(const int64_t* __restrict__ shapes, const int64_t* __re
   const int b = rest - unit * d.B;
   const int m = (blockIdx.x % d.M + b) % d.M;
 
-  if (tid < d.L) {
+  if (tid < d.L) {     // level table: {H, W, start, workgroups, query pieces, block width, blocks per row, block height}
     const int H = int(shapes[2 * tid]), W = int(shapes[2 * tid + 1]);
-    const GvSplit sp = gv_level_split(H * W, units_min, kTileRowsMax);
-    const int qs = gv_query_splits(sp.units, d.Lq, P, sizeof(TV) == 4 || split_image != nullptr, d.B * d.M);
-    meta[4 * tid] = H; meta[4 * tid + 1] = W; meta[4 * tid + 2] = int(lsi[tid]);
-    meta[4 * tid + 3] = sp.units | (sp.rpu << 12) | (qs << 24);     // units <= 4000, rpu <= 320, qs <= 8
+    const GvGrid g = gv_level_grid(H, W, units_min, kTileRowsMax);
+    const int qs = gv_query_splits(g.nbx * g.nby, d.Lq, P, sizeof(TV) == 4 || split_image != nullptr, d.B * d.M);
+    int* mt = meta + 8 * tid;
+    mt[0] = H; mt[1] = W; mt[2] = int(lsi[tid]); mt[3] = g.nbx * g.nby * qs; mt[4] = qs; mt[5] = g.bw; mt[6] = g.nbx; mt[7] = g.bh;
   }
   for (int i = tid; i < 2 * kTileRowsMax; i += kThreads) cnt2[i] = 0;
   if (tid == 0) alloc[0] = 0;
   __syncthreads();
 
-  int lvl = -1, r0 = 0, r1 = 0, Hl = 0, Wl = 0, start = 0, u_lvl = 0, qsplit = 1, qpiece = 0;
+  // this workgroup's unit: pixels [x0, x1) x [y0, y1) of level lvl (local row = (y - y0) * pitch + x - x0, pitch = the
+  // level's block width), possibly one of `qsplit` query pieces of it
+  int lvl = -1, Hl = 0, Wl = 0, start = 0, qsplit = 1, qpiece = 0, x0 = 0, x1 = 0, y0 = 0, y1 = 0, pitch = 1;
   {
     int running = 0;
     bool packed = true;
     int u = unit;
     for (int l = 0; l < d.L; ++l) {
-      packed = packed && (meta[4 * l + 2] == running);
-      running += meta[4 * l] * meta[4 * l + 1];
+      packed = packed && (meta[8 * l + 2] == running);
+      running += meta[8 * l] * meta[8 * l + 1];
     }
     for (int l = d.L - 1; l >= 0; --l) {       // units are numbered from the last (coarsest) level back
-      const int H = meta[4 * l], W = meta[4 * l + 1], st = meta[4 * l + 2], ur = meta[4 * l + 3];
-      const int n = H * W, units = ur & 0xfff, rpu = (ur >> 12) & 0xfff, qs = ur >> 24;
+      const int* mt = meta + 8 * l;
+      const int total = mt[3];
       if (lvl < 0) {
-        if (u < units * qs) {        // a level's workgroups: row-unit major, query piece minor
-          lvl = l; Hl = H; Wl = W; start = st; qsplit = qs;
-          u_lvl = u / qs; qpiece = u - u_lvl * qs;
-          r0 = u_lvl * rpu;
-          r1 = r0 + rpu < n ? r0 + rpu : n;
+        if (u < total) {             // a level's workgroups: unit major, query piece minor
+          lvl = l; Hl = mt[0]; Wl = mt[1]; start = mt[2]; qsplit = mt[4]; pitch = mt[5];
+          const int nbx = mt[6], bh = mt[7];
+          const int u_lvl = u / qsplit;
+          qpiece = u - u_lvl * qsplit;
+          const int by = u_lvl / nbx, bx = u_lvl - by * nbx;
+          x0 = bx * pitch; x1 = x0 + pitch < Wl ? x0 + pitch : Wl;
+          y0 = by * bh; y1 = y0 + bh < Hl ? y0 + bh : Hl;
         } else {
-          u -= units * qs;
+          u -= total;
         }
       }
     }
@@ -108,18 +114,20 @@ msda_bwd_gv_tiles_kernel(const int64_t* __restrict__ shapes, const int64_t* __re
     if (!packed || lvl < 0) return;  // uniform over the workgroup
   }
   // uniform over the workgroup, but it came through LDS: scalarise (SGPRs, see opaque())
-  lvl = __builtin_amdgcn_readfirstlane(lvl); r0 = __builtin_amdgcn_readfirstlane(r0); r1 = __builtin_amdgcn_readfirstlane(r1);
+  lvl = __builtin_amdgcn_readfirstlane(lvl);
   Hl = __builtin_amdgcn_readfirstlane(Hl); Wl = __builtin_amdgcn_readfirstlane(Wl); start = __builtin_amdgcn_readfirstlane(start);
-  u_lvl = __builtin_amdgcn_readfirstlane(u_lvl); qsplit = __builtin_amdgcn_readfirstlane(qsplit);
-  qpiece = __builtin_amdgcn_readfirstlane(qpiece);
-  const int rows = r1 - r0;
+  qsplit = __builtin_amdgcn_readfirstlane(qsplit); qpiece = __builtin_amdgcn_readfirstlane(qpiece);
+  pitch = __builtin_amdgcn_readfirstlane(pitch);
+  x0 = __builtin_amdgcn_readfirstlane(x0); x1 = __builtin_amdgcn_readfirstlane(x1);
+  y0 = __builtin_amdgcn_readfirstlane(y0); y1 = __builtin_amdgcn_readfirstlane(y1);
+  const int rows = pitch * (y1 - y0);
   constexpr int kRpg = (kTileRowsMax + kGroups - 1) / kGroups;
   float4_t racc[kRpg];
 #pragma unroll
   for (int k = 0; k < kRpg; ++k) racc[k] = float4_t{0.f, 0.f, 0.f, 0.f};
 
   const int LP = d.L * P;
-  const uint32_t* summ = summaries + ((int64_t(b) * d.M + m) * d.L + lvl) * int64_t(n_tiles);
+  const uint2_t* summ = summaries + ((int64_t(b) * d.M + m) * d.L + lvl) * int64_t(n_tiles);
   // sample (q, head m, level lvl, point k) of this batch element: index  base + q * (M * LP) + k  into attn, twice that
   // into loc; q * M * LP * 2 < 2^32 (msda_d32_gvtiles_supported)
   const TL* attn_bm = attn + (int64_t(b) * d.Lq * d.M + m) * LP + lvl * P;
@@ -130,7 +138,7 @@ msda_bwd_gv_tiles_kernel(const int64_t* __restrict__ shapes, const int64_t* __re
   const float Hf = float(Hl), Wf = float(Wl);
   const int tile_mask = (1 << tile_shift) - 1;
   const int tpc_shift = 7 - tile_shift;              // tiles per chunk = 128 >> tile_shift
-  const int dr[4] = {0, 1, Wl, Wl + 1};
+  const int dr[4] = {0, 1, pitch, pitch + 1};
 
   int gchunk = 0;                                    // parity of the double-buffered row counters
 
@@ -146,10 +154,13 @@ msda_bwd_gv_tiles_kernel(const int64_t* __restrict__ shapes, const int64_t* __re
 #pragma unroll
     for (int r = 0; r < kTileRounds; ++r) {
       const int ti = r * kThreads + tw;
-      // word = unit_lo | (0xffff - unit_hi) << 16 (what a packed 16-bit minimum reduces); 0xffffffff = no taps
-      const uint32_t v = ti < n_w ? summ[win0 + ti] : 0xffffffffu;
-      const int lo = int(v & 0xffffu), hi = 0xffff - int(v >> 16);
-      const bool h = lo <= u_lvl && u_lvl <= hi;
+      // words = x_lo | (0xffff - x_hi) << 16, y_lo | (0xffff - y_hi) << 16: the box of the pixels the tile's samples touch
+      // (what packed 16-bit minima reduce; coordinates saturate at 0xfffe = "or beyond"); 0xffffffff = no taps
+      const uint2_t v = ti < n_w ? summ[win0 + ti] : uint2_t{0xffffffffu, 0xffffffffu};
+      const int xl = int(v.x & 0xffffu), yl = int(v.y & 0xffffu);
+      int xh = 0xffff - int(v.x >> 16), yh = 0xffff - int(v.y >> 16);
+      xh = xh >= 0xfffe ? 0x7fffffff : xh; yh = yh >= 0xfffe ? 0x7fffffff : yh;
+      const bool h = v.x != 0xffffffffu && xl < x1 && xh >= x0 && yl < y1 && yh >= y0;
       const unsigned long long bh = __ballot(h);
       bal[r] = bh;
       hitbits |= uint32_t(h) << r;
@@ -223,13 +234,12 @@ msda_bwd_gv_tiles_kernel(const int64_t* __restrict__ shapes, const int64_t* __re
           const float hf = floorf(h), wf = floorf(w);
           const int h0 = int(hf), w0 = int(wf);
           const float lh = h - hf, lw = w - wf, hh = 1.f - lh, hw = 1.f - lw;
-          const bool top = h0 >= 0, bot = h0 + 1 <= Hl - 1, lef = w0 >= 0, rig = w0 + 1 <= Wl - 1;
-          const int p00 = h0 * Wl + w0;
-          mask = (uint32_t(top && lef && p00 >= r0 && p00 < r1)) |
-                 (uint32_t(top && rig && p00 + 1 >= r0 && p00 + 1 < r1) << 1) |
-                 (uint32_t(bot && lef && p00 + Wl >= r0 && p00 + Wl < r1) << 2) |
-                 (uint32_t(bot && rig && p00 + Wl + 1 >= r0 && p00 + Wl + 1 < r1) << 3);
-          row00 = p00 - r0;
+          // a corner counts if it is inside the unit's rectangle (which lies inside the map)
+          const int lx = w0 - x0, ly = h0 - y0, bwx = x1 - x0, bhy = y1 - y0;
+          const bool cl = lx >= 0 && lx < bwx, cr = lx + 1 >= 0 && lx + 1 < bwx;
+          const bool rt = ly >= 0 && ly < bhy, rb = ly + 1 >= 0 && ly + 1 < bhy;
+          mask = uint32_t(rt && cl) | (uint32_t(rt && cr) << 1) | (uint32_t(rb && cl) << 2) | (uint32_t(rb && cr) << 3);
+          row00 = ly * pitch + lx;
           wt[0] = a * (hh * hw); wt[1] = a * (hh * lw); wt[2] = a * (lh * hw); wt[3] = a * (lh * lw);
         }
       }
@@ -286,51 +296,63 @@ msda_bwd_gv_tiles_kernel(const int64_t* __restrict__ shapes, const int64_t* __re
     }
   }
 
-  TV* out = grad_value + ((int64_t(b) * d.S + start + r0) * d.M + m) * D;
+  // local row -> pixel (y0 + row / pitch, x0 + row % pitch); the columns past x1 of an edge block hold nothing
   const int te = opaque(tid);
   const int grp = te >> 3, ch4 = te & 7;
-  {
-    if (qsplit > 1) {   // pieces of a query-split level meet through fp32 atomics (rows zeroed by the grad_loc kernel):
-                        // on grad_value itself (fp32) or on the fp32 split image (16-bit values; converted afterwards)
-      float* out32 = (sizeof(TV) == 4 ? reinterpret_cast<float*>(grad_value) : split_image) +
-                     ((int64_t(b) * d.S + start + r0) * d.M + m) * D;
+  const uint32_t inv = (65536u + uint32_t(pitch) - 1u) / uint32_t(pitch);      // row / pitch exactly for row < 256
+  const int64_t level_elem = ((int64_t(b) * d.S + start) * d.M + m) * D;
+  if (qsplit > 1) {   // pieces of a query-split level meet through fp32 atomics (rows zeroed by the grad_loc kernel):
+                      // on grad_value itself (fp32) or on the fp32 split image (16-bit values; converted afterwards)
+    float* out32 = (sizeof(TV) == 4 ? reinterpret_cast<float*>(grad_value) : split_image) + level_elem;
 #pragma unroll
-      for (int k = 0; k < kRpg; ++k) {
-        const int row = grp + k * kGroups;
-        if (row < rows) {
-          float* p = out32 + __umul24(uint32_t(row), q_stride) + ch4 * 4;
-          atomic_add(p, racc[k].x); atomic_add(p + 1, racc[k].y); atomic_add(p + 2, racc[k].z); atomic_add(p + 3, racc[k].w);
-        }
+    for (int k = 0; k < kRpg; ++k) {
+      const int row = grp + k * kGroups;
+      const int ry = int((uint32_t(row) * inv) >> 16), rx = row - ry * pitch;
+      if (row < rows && rx < x1 - x0) {
+        float* p = out32 + __umul24(uint32_t((y0 + ry) * Wl + x0 + rx), q_stride) + ch4 * 4;
+        atomic_add(p, racc[k].x); atomic_add(p + 1, racc[k].y); atomic_add(p + 2, racc[k].z); atomic_add(p + 3, racc[k].w);
       }
-      return;
     }
+    return;
   }
+  TV* out = grad_value + level_elem;
 #pragma unroll
   for (int k = 0; k < kRpg; ++k) {
     const int row = grp + k * kGroups;
-    if (row < rows) store4<TV>(out + __umul24(uint32_t(row), q_stride) + ch4 * 4, racc[k]);
+    const int ry = int((uint32_t(row) * inv) >> 16), rx = row - ry * pitch;
+    if (row < rows && rx < x1 - x0)
+      store4<TV>(out + __umul24(uint32_t((y0 + ry) * Wl + x0 + rx), q_stride) + ch4 * 4, racc[k]);
   }
 }
 
 }  // namespace rec
 
-int msda_gvrec_units_bound(const MsdaDims& d, int units_min, int rows_max);
 
-// bytes of the tile words: [batch][head][level][tile]
+// bytes of the tile words: [batch][head][level][tile] x 2
 size_t msda_gvtiles_summary_bytes(const MsdaDims& d, int tile_queries) {
   const size_t n_tiles = (size_t(d.Lq) + tile_queries - 1) / tile_queries;
-  return size_t(4) * size_t(d.B) * d.M * d.L * n_tiles;
+  return size_t(8) * size_t(d.B) * d.M * d.L * n_tiles;
+}
+
+// Workgroups per (batch, head): the host knows S, not the level shapes.  gv_level_grid: a narrow level (bands of
+// floor(256 / W) >= 2 rows, W <= 127) has at most n / 129 + 1 units; a wide one at most (W / bw + 1)(H / bh + 1) blocks
+// with bw > 25.6, bw * bh >= 224 and H >= 8, i.e. n / 224 + n / 205 + n / 1024 + 1 <= n / 97 + 1; a flat wide one
+// (H < 8) n / 128 + 1.  So 3 * ceil(S / 256) + 2 per level bounds the units, units_min more when a small level is cut
+// further, and 4 * (pieces - 1) for the query pieces of levels of at most four units.  Workgroups past the real count exit
+// at once; they are the LAST of the grid (units are numbered from the coarsest level back) and overlap the real ones.
+static int gvtiles_units_bound(const MsdaDims& d, int units_min) {
+  const int qs = gv_query_splits(1, d.Lq, d.P, true, d.B * d.M);
+  return d.L * (units_min + 2) + 3 * ((d.S + rec::kTileRowsMax - 1) / rec::kTileRowsMax) + d.L * 4 * (qs - 1);
 }
 
 bool msda_d32_gvtiles_supported(int vdt, int ldt, const MsdaDims& d) {
   if (d.D != 32 || d.P != 4 || vdt == VNX_F64) return false;
   if (vdt == VNX_F32 && ldt != VNX_F32) return false;
   if (d.L > rec::kLevelsMax) return false;
-  if (d.S > rec::kTileRowsMax * 4000) return false;     // units and rows/unit share one word
   // 24-bit stride multiplies: query index, heads x channels and heads x samples below 2^24; element offsets below 2^32
   if (d.Lq >= (1 << 24) || d.M * 32 >= (1 << 24) || d.M * d.L * 4 >= (1 << 24)) return false;
   if (int64_t(d.Lq) * d.M * 32 >= (int64_t(1) << 32) || int64_t(d.Lq) * d.M * d.L * 8 >= (int64_t(1) << 32)) return false;
-  const int64_t blocks = int64_t(d.B) * d.M * msda_gvrec_units_bound(d, 16, rec::kTileRowsMax);
+  const int64_t blocks = int64_t(d.B) * d.M * gvtiles_units_bound(d, 16);
   return blocks < (int64_t(1) << 31);
 }
 
@@ -345,10 +367,10 @@ static int launch_gvtiles(const int64_t* shapes, const int64_t* lsi, const void*
     return VNX_ERR_UNSUPPORTED;
   }
   const int n_tiles = (d.Lq + tile_queries - 1) / tile_queries;
-  const int64_t blocks = int64_t(d.B) * d.M * msda_gvrec_units_bound(d, units_min, rec::kTileRowsMax);
+  const int64_t blocks = int64_t(d.B) * d.M * gvtiles_units_bound(d, units_min);
   hipLaunchKernelGGL((rec::msda_bwd_gv_tiles_kernel<TV, TL>), dim3(uint32_t(blocks)), dim3(rec::kThreads),
                      rec::kTilesLdsBytes, stream, shapes, lsi, (const TL*)loc, (const TL*)attn,
-                     (const uint32_t*)summaries, (const TV*)grad_out, (TV*)grad_value, d, units_min, tile_shift, n_tiles,
+                     (const rec::uint2_t*)summaries, (const TV*)grad_out, (TV*)grad_value, d, units_min, tile_shift, n_tiles,
                      split_image);
   return check_launch("msda_bwd_gv_tiles");
 }

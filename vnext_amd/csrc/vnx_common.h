@@ -163,6 +163,48 @@ __host__ __device__ inline GvSplit gv_level_split(int n, int units_min, int rows
   return s;
 }
 
+// Units of the tile-fed grad_value kernel (msda_d32_gvtiles.hip): RECTANGLES of a level, at most rows_max pixels each.
+// A narrow level (W < 128) is cut into bands of whole image rows; a wide one also into columns of about 32 pixels --
+// blocks of 32 x 8: a band of a 160-pixel-wide level would be 1.6 image rows thin while samples reach +-6 rows, i.e.
+// 8.5 bands' worth of query tiles would hit every band of the 720p level 0 where a block sees 4.7.  (Below 128 pixels
+// a 16-query tile spans most of a block row and columns gain nothing.)  Very flat wide levels (H < 8) get wider
+// blocks so that the unit count stays ~ n / rows_max.  At least units_min units per level when it has the rows.
+// Unit u of a level: block (u % nbx, u / nbx), pixels [bx * bw, ..) x [by * bh, ..), clipped to the level.
+struct GvGrid { int nbx, nby, bw, bh; };
+__host__ __device__ inline GvGrid gv_level_grid(int H, int W, int units_min, int rows_max) {
+  GvGrid g{1, 1, 1, 1};
+  if (H <= 0 || W <= 0) { g.nbx = g.nby = 0; return g; }
+  if (W < 128 && W <= rows_max) {
+    g.nbx = 1; g.bw = W;
+  } else {
+    const int target = H >= 8 ? 32 : rows_max / H;       // H < 8: rows_max / H >= 36
+    g.nbx = (W + target - 1) / target;
+    g.bw = (W + g.nbx - 1) / g.nbx;
+    g.nbx = (W + g.bw - 1) / g.bw;
+  }
+  g.bh = rows_max / g.bw;
+  if (g.bh < 1) g.bh = 1;
+  if (g.bh > H) g.bh = H;
+  g.nby = (H + g.bh - 1) / g.bh;
+  if (g.nbx * g.nby < units_min && g.nby < H) {           // small levels: at least units_min bands
+    int want = (units_min + g.nbx - 1) / g.nbx;
+    if (want > H) want = H;
+    g.bh = (H + want - 1) / want;
+    g.nby = (H + g.bh - 1) / g.bh;
+  }
+  return g;
+}
+
+// units of one level on either grad_value path: what decides its query split (gv_query_splits) -- shared by the grad_loc
+// kernel (zeroing), the grad_value kernels and the 16-bit convert pass
+__host__ __device__ inline int gv_level_units(int H, int W, int units_min, bool tiles) {
+  if (tiles) {
+    const GvGrid g = gv_level_grid(H, W, units_min, kGvTileRowsMax);
+    return g.nbx * g.nby;
+  }
+  return gv_level_split(H * W, units_min, kGvRowsMax).units;
+}
+
 __host__ __device__ inline int gv_query_splits(int row_units, int Lq, int P, bool f32, int batch_heads) {
   if (!f32 || P != 4 || row_units > 4 || Lq < 1024) return 1;
   const int chunks = (Lq + 127) / 128;
