@@ -39,6 +39,14 @@ int vnx_debug_read_tile_stamps(unsigned long long* host, int n);
 int vnx_debug_row_gather_probe(const void* rows, size_t n_rows, const uint32_t* idx, size_t n_idx, int in_flight,
                                float* sink, void* hip_stream);
 
+/* Host-side view of the unit grid of the tile-fed grad_value kernel (vnext_amd/csrc/vnx_common.h: gv_level_grid;
+ * msda_d32_gvtiles.hip): the launcher sizes the grid from the pixel count alone, the kernel derives the units from the
+ * level shapes on the device -- the sum of the latter must never pass the former, or a unit's rows would be lost.
+ * host_shapes: [levels][2] = (H, W) in HOST memory.  Writes the workgroups per (batch, head) the kernel will use and
+ * the launcher's bound; 0 on success.  No GPU needed (tests/test_units_bound.py). */
+int vnx_debug_gvtiles_units(const int64_t* host_shapes, int levels, int num_query, int batch, int heads, int units_min,
+                            int* units_used, int* units_bound);
+
 #ifdef __cplusplus
 }
 #endif

@@ -54,6 +54,7 @@ DEBUG_SIGNATURES = {
     "vnx_debug_read_rec_stamps": (_i, [ctypes.POINTER(ctypes.c_ulonglong), _i]),
     "vnx_debug_read_tile_stamps": (_i, [ctypes.POINTER(ctypes.c_ulonglong), _i]),
     "vnx_debug_row_gather_probe": (_i, [_vp, _sz, _vp, _sz, _i, _vp, _vp]),
+    "vnx_debug_gvtiles_units": (_i, [_vp, _i, _i, _i, _i, _i, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
 }
 
 

@@ -334,13 +334,20 @@ size_t msda_gvtiles_summary_bytes(const MsdaDims& d, int tile_queries) {
   return size_t(8) * size_t(d.B) * d.M * d.L * n_tiles;
 }
 
-// Workgroups per (batch, head): the host knows S, not the level shapes.  gv_level_grid: a narrow level (bands of
-// floor(256 / W) >= 2 rows, W <= 127) has at most n / 129 + 1 units; a wide one at most (W / bw + 1)(H / bh + 1) blocks
-// with bw > 25.6, bw * bh >= 224 and H >= 8, i.e. n / 224 + n / 205 + n / 1024 + 1 <= n / 97 + 1; a flat wide one
-// (H < 8) n / 128 + 1.  So 3 * ceil(S / 256) + 2 per level bounds the units, units_min more when a small level is cut
-// further, and 4 * (pieces - 1) for the query pieces of levels of at most four units.  Workgroups past the real count exit
-// at once; they are the LAST of the grid (units are numbered from the coarsest level back) and overlap the real ones.
-static int gvtiles_units_bound(const MsdaDims& d, int units_min) {
+// Workgroups per (batch, head): the host knows S, not the level shapes.  gv_level_grid: a narrow level (W <= 63: bands
+// of floor(256 / W) >= 4 rows) has at most n / 193 + 1 units; a wider one at most (W / bw + 1)(H / bh + 1) blocks with
+// bw > 21.3, bw * bh >= 224 and H >= 8, i.e. n / 224 + n / 170 + n / 512 + 1 <= n / 81 + 1; a flat wide one (H < 8)
+// n / 128 + 1.  Exhaustively (every H <= 1 200 x W <= 20 000, units_min 1 / 2 / 16: tools/check_units_bound.py) a level
+// has at most 3 n / 256 + units_min units, so 3 * ceil(S / 256) + (units_min + 2) per level bounds them -- a unit past the
+// grid would lose its rows; tests/test_units_bound.py holds the kernel's grid to the launcher's bound through
+// vnx_debug_gvtiles_units on random pyramids -- and
+// 4 * (pieces - 1) for the query pieces of levels of at most four units.  Workgroups past the real count exit at once;
+// they are the LAST of the grid (units are numbered from the coarsest level back) and overlap the real ones: forcing the
+// exact count (42 per (batch, head) at 360p, the bound is 124) changes nothing, 300 costs 4 us (tools/r3_call28.sh).
+int msda_gvtiles_units_bound(const MsdaDims& d, int units_min) {
+#ifdef VNX_TILES_BOUND_FORCE      // A/B build: what the workgroups past the real unit count cost (valid for ONE shape only)
+  return VNX_TILES_BOUND_FORCE;
+#endif
   const int qs = gv_query_splits(1, d.Lq, d.P, true, d.B * d.M);
   return d.L * (units_min + 2) + 3 * ((d.S + rec::kTileRowsMax - 1) / rec::kTileRowsMax) + d.L * 4 * (qs - 1);
 }
@@ -352,7 +359,7 @@ bool msda_d32_gvtiles_supported(int vdt, int ldt, const MsdaDims& d) {
   // 24-bit stride multiplies: query index, heads x channels and heads x samples below 2^24; element offsets below 2^32
   if (d.Lq >= (1 << 24) || d.M * 32 >= (1 << 24) || d.M * d.L * 4 >= (1 << 24)) return false;
   if (int64_t(d.Lq) * d.M * 32 >= (int64_t(1) << 32) || int64_t(d.Lq) * d.M * d.L * 8 >= (int64_t(1) << 32)) return false;
-  const int64_t blocks = int64_t(d.B) * d.M * gvtiles_units_bound(d, 16);
+  const int64_t blocks = int64_t(d.B) * d.M * msda_gvtiles_units_bound(d, 16);
   return blocks < (int64_t(1) << 31);
 }
 
@@ -367,7 +374,7 @@ static int launch_gvtiles(const int64_t* shapes, const int64_t* lsi, const void*
     return VNX_ERR_UNSUPPORTED;
   }
   const int n_tiles = (d.Lq + tile_queries - 1) / tile_queries;
-  const int64_t blocks = int64_t(d.B) * d.M * gvtiles_units_bound(d, units_min);
+  const int64_t blocks = int64_t(d.B) * d.M * msda_gvtiles_units_bound(d, units_min);
   hipLaunchKernelGGL((rec::msda_bwd_gv_tiles_kernel<TV, TL>), dim3(uint32_t(blocks)), dim3(rec::kThreads),
                      rec::kTilesLdsBytes, stream, shapes, lsi, (const TL*)loc, (const TL*)attn,
                      (const rec::uint2_t*)summaries, (const TV*)grad_out, (TV*)grad_value, d, units_min, tile_shift, n_tiles,

@@ -164,20 +164,28 @@ __host__ __device__ inline GvSplit gv_level_split(int n, int units_min, int rows
 }
 
 // Units of the tile-fed grad_value kernel (msda_d32_gvtiles.hip): RECTANGLES of a level, at most rows_max pixels each.
-// A narrow level (W < 128) is cut into bands of whole image rows; a wide one also into columns of about 32 pixels --
+// A narrow level (W < 64) is cut into bands of whole image rows; a wider one also into columns of about 32 pixels --
 // blocks of 32 x 8: a band of a 160-pixel-wide level would be 1.6 image rows thin while samples reach +-6 rows, i.e.
-// 8.5 bands' worth of query tiles would hit every band of the 720p level 0 where a block sees 4.7.  (Below 128 pixels
-// a 16-query tile spans most of a block row and columns gain nothing.)  Very flat wide levels (H < 8) get wider
-// blocks so that the unit count stays ~ n / rows_max.  At least units_min units per level when it has the rows.
+// 8.5 bands' worth of query tiles would hit every band of the 720p level 0 where a block sees 4.7.  Measured (encoder
+// backward, B = 5, cold): blocks from 128 pixels of width up 732 -> 691 us at 720p, from 64 pixels up 651 us (the 80-pixel
+// level 1 is hit mostly by the tiles of the finer level 0, which are only 8 of ITS pixels wide) and 176.7 -> 174.6 us at
+// 360p; block width 16 instead of 32: 699 us.  Very flat levels (H < 8) get wider blocks so that the unit count stays
+// ~ n / rows_max.  At least units_min units per level when it has the rows.
 // Unit u of a level: block (u % nbx, u / nbx), pixels [bx * bw, ..) x [by * bh, ..), clipped to the level.
+#ifndef VNX_GV_BLOCK_MINW
+#define VNX_GV_BLOCK_MINW 64
+#endif
+#ifndef VNX_GV_BLOCK_W
+#define VNX_GV_BLOCK_W 32
+#endif
 struct GvGrid { int nbx, nby, bw, bh; };
 __host__ __device__ inline GvGrid gv_level_grid(int H, int W, int units_min, int rows_max) {
   GvGrid g{1, 1, 1, 1};
   if (H <= 0 || W <= 0) { g.nbx = g.nby = 0; return g; }
-  if (W < 128 && W <= rows_max) {
+  if (W < VNX_GV_BLOCK_MINW && W <= rows_max) {
     g.nbx = 1; g.bw = W;
   } else {
-    const int target = H >= 8 ? 32 : rows_max / H;       // H < 8: rows_max / H >= 36
+    const int target = H >= rows_max / VNX_GV_BLOCK_W ? VNX_GV_BLOCK_W : rows_max / H;       // flat levels: wider blocks
     g.nbx = (W + target - 1) / target;
     g.bw = (W + g.nbx - 1) / g.nbx;
     g.nbx = (W + g.bw - 1) / g.bw;
