@@ -106,7 +106,10 @@ static int check_common(const char* fn, int vdt, int ldt, const void* value,
 using namespace vnx;
 
 namespace vnx {
-int gv_units_min(const MsdaDims& d) {
+#ifndef VNX_TILE_UNITS_MIN
+#define VNX_TILE_UNITS_MIN 2
+#endif
+int gv_units_min(const MsdaDims& d, bool tiles) {
   const int v = g_kernel_variant;
   if (v >= 200 && v < 300) return v - 200 < 1 ? 1 : (v - 200 > 16 ? 16 : v - 200);
   // Tried with per-unit selection: enough units that each expects about one selection window of
@@ -114,7 +117,7 @@ int gv_units_min(const MsdaDims& d) {
   // backward -- because a unit's chunk count is set by its DISTINCT queries (128 staged rows per
   // chunk), and finer units multiply the (query, unit) incidences.
   (void)d;
-  return 2;
+  return tiles ? VNX_TILE_UNITS_MIN : 2;
 }
 }  // namespace vnx
 

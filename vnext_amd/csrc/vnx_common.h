@@ -86,7 +86,7 @@ struct MsdaDims {
 // grad_value units: every level is split into at least this many.  Shared by the grad_loc kernel
 // (which tags every sample with the units it touches) and the grad_value kernels.  2 (variants
 // 200+x: x).
-int gv_units_min(const MsdaDims& d);
+int gv_units_min(const MsdaDims& d, bool tiles);
 // Backward workspace of the record-fed path: [16-B sample records | 256-B aligned | 4-B unit ranges]
 inline size_t gv_unit_ids_offset(const MsdaDims& d) {
   const size_t n = size_t(d.B) * d.M * d.L * d.Lq * d.P;
