@@ -291,17 +291,60 @@ __device__ __forceinline__ float wave_sum_to_last(float v) {
   return v;
 }
 
-__global__ void __launch_bounds__(64)
-dynamic_mask_head_bwd_kernel(const float* __restrict__ feats, const float* __restrict__ ref,
-                             const float* __restrict__ params, const int* __restrict__ inst_image,
-                             const float* __restrict__ grad_out, float* __restrict__ grad_feats,
-                             float* __restrict__ grad_ref, float* __restrict__ grad_params,
-                             int H, int W, int n_inst, int stride, int strips_x, int strips_y) {
+// packed FMA forms of the backward kernel (two FMAs per issued instruction):
+//   pk_fma_sv:  d += (scalar pair of weights) * (pair of inputs)
+//   pk_fma_sb:  d += (scalar pair of weights) * (one gradient, the low / high half of g, for both lanes)
+//   pk_fma_bv:  d += (one gradient, the low / high half of g, for both lanes) * (pair of inputs)
+__device__ __forceinline__ void pk_fma_sv(float2_t& d, uint64_t w_pair, float2_t x) {
+  asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(d) : "s"(w_pair), "v"(x));
+}
+template <bool HI>
+__device__ __forceinline__ void pk_fma_sb(float2_t& d, uint64_t w_pair, float2_t g) {
+  if (HI) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(d) : "s"(w_pair), "v"(g));
+  else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(d) : "s"(w_pair), "v"(g));
+}
+template <bool HI>
+__device__ __forceinline__ void pk_fma_bv(float2_t& d, float2_t g, float2_t x) {
+  if (HI) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(d) : "v"(g), "v"(x));
+  else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(d) : "v"(g), "v"(x));
+}
+
+// four wave sums at once, each valid in lane 63: the steps of wave_sum_to_last as fused DPP adds, the four chains
+// interleaved so that no instruction reads the result of the one before it (a lane without a source keeps its value)
+__device__ __forceinline__ void wave_sum4_to_last(float& a, float& b, float& c, float& d) {
+#define VNX_STEP(ctrl) \
+      "v_add_f32_dpp %0, %0, %0 " ctrl "\n\tv_add_f32_dpp %1, %1, %1 " ctrl "\n\tv_add_f32_dpp %2, %2, %2 " ctrl "\n\tv_add_f32_dpp %3, %3, %3 " ctrl "\n\t"
+  asm volatile(
+      "s_nop 1\n\t"
+      VNX_STEP("row_shr:1 row_mask:0xf bank_mask:0xf")
+      VNX_STEP("row_shr:2 row_mask:0xf bank_mask:0xf")
+      VNX_STEP("row_shr:4 row_mask:0xf bank_mask:0xf")
+      VNX_STEP("row_shr:8 row_mask:0xf bank_mask:0xf")
+      VNX_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
+      VNX_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+      "s_nop 0"
+      : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+#undef VNX_STEP
+}
+
+// PART: the 171 lane-local accumulators + the activations of a pixel were 268 VGPRs -- ONE wave per SIMD, and the
+// training shape (120 instances x 12 strips) is 1.4 waves per SIMD, each a 6 200-instruction dependent sequence: 44.7 us.
+// Two waves per strip instead: part 0 keeps the first layer's weight gradients (80) and sends the feature gradients,
+// part 1 everything else (64 + 8 + 8 + 1 of layers two and three, the first layer's bias, the reference point); both
+// recompute the forward and the data side of the backward chain (+50 % arithmetic), each fits 168 VGPRs: three waves
+// per SIMD, the whole training shape resident at once.
+template <int PART>
+__device__ __forceinline__ void
+mask_head_bwd_part(const int block, const float* __restrict__ feats, const float* __restrict__ ref,
+                   const float* __restrict__ params, const int* __restrict__ inst_image,
+                   const float* __restrict__ grad_out, float* __restrict__ grad_feats,
+                   float* __restrict__ grad_ref, float* __restrict__ grad_params,
+                   int H, int W, int n_inst, int stride, int strips_x, int strips_y) {
   const int lane = threadIdx.x;
   const int strips = strips_x * strips_y;
-  const int j = int(blockIdx.x) / strips;  // instance
+  const int j = block / strips;  // instance
   if (j >= n_inst) return;
-  const int s = int(blockIdx.x) - j * strips;
+  const int s = block - j * strips;
   const int sy = s / strips_x, sx = s - sy * strips_x;
   const int x = sx * kMhStripW + lane;               // lane 63 is the right halo
   const int xc = x > W - 1 ? W - 1 : x;
@@ -329,22 +372,67 @@ dynamic_mask_head_bwd_kernel(const float* __restrict__ feats, const float* __res
     return UpAdj{q + 0.5f * (top.y + bot.x) + bot.y, q + 0.5f * bot.x, q + 0.5f * top.y, q};
   };
 
-  float acc_w0[kMhHidden][kMhChannels + 2], acc_w1[kMhHidden][kMhHidden], acc_w2[kMhHidden];
-  float acc_b0[kMhHidden], acc_b1[kMhHidden], acc_b2 = 0.f, acc_rx = 0.f, acc_ry = 0.f;
+  constexpr bool kHas0 = PART != 1, kHas1 = PART != 0;        // part 0: first-layer weights + features; part 1: the rest
+  constexpr int kA = kHas0 ? kMhHidden : 1, kB = kHas1 ? kMhHidden : 1;     // the other part's arrays shrink to nothing
+  constexpr int kP0 = (kMhChannels + 2) / 2, kP1 = kMhHidden / 2;           // pairs per row of W0 / W1
+  float2_t acc_w0[kA][kP0], acc_w1[kB][kP1], acc_w2[kB > 1 ? kP1 : 1];
+  float acc_b0[kB], acc_b1[kB], acc_b2 = 0.f, acc_rx = 0.f, acc_ry = 0.f;
+  const float2_t zero2 = {0.f, 0.f};
 #pragma unroll
-  for (int o = 0; o < kMhHidden; ++o) {
+  for (int o = 0; o < kA; ++o) {
 #pragma unroll
-    for (int i = 0; i < kMhChannels + 2; ++i) acc_w0[o][i] = 0.f;
-#pragma unroll
-    for (int i = 0; i < kMhHidden; ++i) acc_w1[o][i] = 0.f;
-    acc_w2[o] = 0.f; acc_b0[o] = 0.f; acc_b1[o] = 0.f;
+    for (int k = 0; k < kP0; ++k) acc_w0[o][k] = zero2;
   }
+#pragma unroll
+  for (int o = 0; o < kB; ++o) {
+#pragma unroll
+    for (int k = 0; k < kP1; ++k) acc_w1[o][k] = zero2;
+    acc_b0[o] = 0.f; acc_b1[o] = 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < (kB > 1 ? kP1 : 1); ++k) acc_w2[k] = zero2;
+
+  // Parameters stream through the scalar file as in the forward kernel: groups of the 20 (16) weights of two output
+  // channels (+ their biases), fetched one group ahead (s_load into ga / gb alternately, s_waitcnt by hand -- the loads are
+  // invisible to hipcc's own counting).  Left to the compiler all 169 stayed live across the row loop, 150 of them
+  // spilled into VGPR lanes: ~240 v_readlane per pixel row next to ~330 FMAs.  A pair of neighbouring weights is one
+  // 64-bit scalar operand of a packed FMA over a pair of inputs (forward, data side of the backward); the weight side
+  // multiplies a broadcast gradient with input pairs.
+  struct Group { sgpr16_t w; sgpr4_t w2; sgpr2_t b; };
+  auto fetch20 = [&](Group& g, int w_at, int b_at) {   // 20 consecutive weights, 2 consecutive biases
+    asm volatile("s_load_dwordx16 %0, %3, %4\n\ts_load_dwordx4 %1, %3, %5\n\ts_load_dwordx2 %2, %3, %6"
+                 : "=&s"(g.w), "=&s"(g.w2), "=&s"(g.b)
+                 : "s"(P), "n"(w_at * 4), "n"(w_at * 4 + 64), "n"(b_at * 4)
+                 : "memory");
+  };
+  auto fetch16 = [&](Group& g, int w_at, int b_at) {   // 16 consecutive weights, 2 consecutive biases
+    asm volatile("s_load_dwordx16 %0, %2, %3\n\ts_load_dwordx2 %1, %2, %4"
+                 : "=&s"(g.w), "=&s"(g.b)
+                 : "s"(P), "n"(w_at * 4), "n"(b_at * 4)
+                 : "memory");
+  };
+  auto fetch8 = [&](Group& g, int w_at) {              // the last layer's 8 weights
+    sgpr8_t t;
+    asm volatile("s_load_dwordx8 %0, %1, %2" : "=&s"(t) : "s"(P), "n"(w_at * 4) : "memory");
+#pragma unroll
+    for (int q = 0; q < 8; ++q) g.w[q] = t[q];
+  };
+  auto landed = [&](Group& g) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(g.w), "+s"(g.w2), "+s"(g.b)::"memory");
+  };
+  auto wpair = [](const Group& g, int k) -> uint64_t {   // weights 2k, 2k + 1 of the group as one SGPR pair
+    return k < 8 ? (uint64_t(g.w[2 * k + 1]) << 32) | g.w[2 * k] : (uint64_t(g.w2[2 * (k - 8) + 1]) << 32) | g.w2[2 * (k - 8)];
+  };
+#define VNX_FENCE __builtin_amdgcn_sched_barrier(0);
 
   UpAdj cur = up_adj(y0);
 #pragma unroll 1
   for (int r = 0; r < kMbRows; ++r) {
     const int y = y0 + r;
     if (y >= H) break;
+    Group ga, gb;
+    ga.w2 = sgpr4_t{0u, 0u, 0u, 0u}; gb.w2 = ga.w2;
+    fetch20(ga, W0, B0);
     const UpAdj nxt = up_adj(y + 1);  // zeros below the map
     // d(loss)/d(logit[y][x]) before up-sampling: the transpose of
     //   out[2y][2x] = (a+b+c+d)/4, out[2y][2x+1] = (b+d)/2, out[2y+1][2x] = (c+d)/2, out[2y+1][2x+1] = d
@@ -357,101 +445,191 @@ dynamic_mask_head_bwd_kernel(const float* __restrict__ feats, const float* __res
     if (!owner) gl = 0.f;   // halo lane / columns past the map contribute nothing
     cur = nxt;
 
-    float x0[kMhChannels + 2];
-    x0[0] = relx;
-    x0[1] = refy - (float(y * stride) + half);
+    // inputs of the first layer as pairs: (rel_x, rel_y), (f0, f1), ...
+    float2_t x0[kP0];
+    x0[0] = float2_t{relx, refy - (float(y * stride) + half)};
 #pragma unroll
-    for (int c = 0; c < kMhChannels; ++c) x0[2 + c] = F[(int64_t(c) * H + y) * W + xc];
-    float x1[kMhHidden], x2[kMhHidden];
-#pragma unroll
-    for (int o = 0; o < kMhHidden; ++o) {
-      float a = P[B0 + o];
-#pragma unroll
-      for (int i = 0; i < kMhChannels + 2; ++i) a = fmaf(P[W0 + o * (kMhChannels + 2) + i], x0[i], a);
-      x1[o] = fmaxf(a, 0.f);
-    }
-#pragma unroll
-    for (int o = 0; o < kMhHidden; ++o) {
-      float a = P[B1 + o];
-#pragma unroll
-      for (int i = 0; i < kMhHidden; ++i) a = fmaf(P[W1 + o * kMhHidden + i], x1[i], a);
-      x2[o] = fmaxf(a, 0.f);
-    }
-    // layer 3: logit = w2 . x2 + b2
-    float g2[kMhHidden];
-    acc_b2 += gl;
-#pragma unroll
-    for (int o = 0; o < kMhHidden; ++o) {
-      acc_w2[o] = fmaf(gl, x2[o], acc_w2[o]);
-      g2[o] = x2[o] > 0.f ? P[W2 + o] * gl : 0.f;
-    }
-    // layer 2
-    float g1[kMhHidden];
-#pragma unroll
-    for (int i = 0; i < kMhHidden; ++i) g1[i] = 0.f;
-#pragma unroll
-    for (int o = 0; o < kMhHidden; ++o) {
-      acc_b1[o] += g2[o];
-#pragma unroll
-      for (int i = 0; i < kMhHidden; ++i) {
-        acc_w1[o][i] = fmaf(g2[o], x1[i], acc_w1[o][i]);
-        g1[i] = fmaf(P[W1 + o * kMhHidden + i], g2[o], g1[i]);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < kMhHidden; ++i) g1[i] = x1[i] > 0.f ? g1[i] : 0.f;
-    // layer 1
-    float g0[kMhChannels + 2];
-#pragma unroll
-    for (int i = 0; i < kMhChannels + 2; ++i) g0[i] = 0.f;
-#pragma unroll
-    for (int o = 0; o < kMhHidden; ++o) {
-      acc_b0[o] += g1[o];
-#pragma unroll
-      for (int i = 0; i < kMhChannels + 2; ++i) {
-        acc_w0[o][i] = fmaf(g1[o], x0[i], acc_w0[o][i]);
-        g0[i] = fmaf(P[W0 + o * (kMhChannels + 2) + i], g1[o], g0[i]);
-      }
-    }
-    acc_rx += g0[0];   // rel = ref - pixel centre
-    acc_ry += g0[1];
-    if (owner) {
-#pragma unroll
-      for (int c = 0; c < kMhChannels; ++c) atomic_add(GF + (int64_t(c) * H + y) * W + x, g0[2 + c]);
-    }
-  }
+    for (int c = 0; c < kMhChannels; c += 2)
+      x0[1 + c / 2] = float2_t{F[(int64_t(c) * H + y) * W + xc], F[(int64_t(c + 1) * H + y) * W + xc]};
 
-  // 171 wave reductions; total k lands in lane k % 64 of word k / 64, then three coalesced atomics
+    // ---- forward, recomputed: a dot product is a chain of packed FMAs over input pairs + one add of the halves
+    float2_t x1[kP1], x2[kP1];
+#define VNX_FWD(G, NP, X, OUT, o0)                                                                      \
+    _Pragma("unroll") for (int oo = 0; oo < 2; ++oo) {                                                    \
+      float2_t a = float2_t{__uint_as_float(G.b[oo]), 0.f};                                               \
+      _Pragma("unroll") for (int k = 0; k < NP; ++k) pk_fma_sv(a, wpair(G, oo * NP + k), X[k]);           \
+      const float v = fmaxf(a.x + a.y, 0.f);                                                              \
+      if (oo == 0) OUT[(o0) / 2].x = v; else OUT[(o0) / 2].y = v;                                         \
+    }
+    landed(ga); fetch20(gb, W0 + 20, B0 + 2); VNX_FENCE
+    VNX_FWD(ga, kP0, x0, x1, 0) VNX_FENCE
+    landed(gb); fetch20(ga, W0 + 40, B0 + 4); VNX_FENCE
+    VNX_FWD(gb, kP0, x0, x1, 2) VNX_FENCE
+    landed(ga); fetch20(gb, W0 + 60, B0 + 6); VNX_FENCE
+    VNX_FWD(ga, kP0, x0, x1, 4) VNX_FENCE
+    landed(gb); fetch16(ga, W1, B1); VNX_FENCE
+    VNX_FWD(gb, kP0, x0, x1, 6) VNX_FENCE
+    landed(ga); fetch16(gb, W1 + 16, B1 + 2); VNX_FENCE
+    VNX_FWD(ga, kP1, x1, x2, 0) VNX_FENCE
+    landed(gb); fetch16(ga, W1 + 32, B1 + 4); VNX_FENCE
+    VNX_FWD(gb, kP1, x1, x2, 2) VNX_FENCE
+    landed(ga); fetch16(gb, W1 + 48, B1 + 6); VNX_FENCE
+    VNX_FWD(ga, kP1, x1, x2, 4) VNX_FENCE
+    landed(gb); fetch8(ga, W2); VNX_FENCE
+    VNX_FWD(gb, kP1, x1, x2, 6) VNX_FENCE
+#undef VNX_FWD
+    // ---- layer 3: logit = w2 . x2 + b2
+    landed(ga); fetch16(gb, W1, B1); VNX_FENCE
+    float2_t g2[kP1];
+    const float2_t gl2 = {gl, gl};
+    if constexpr (kHas1) {
+      acc_b2 += gl;
+#pragma unroll
+      for (int k = 0; k < kP1; ++k) acc_w2[k] = gl2 * x2[k] + acc_w2[k];
+    }
+#pragma unroll
+    for (int k = 0; k < kP1; ++k) {
+      g2[k].x = x2[k].x > 0.f ? __uint_as_float(ga.w[2 * k]) * gl : 0.f;
+      g2[k].y = x2[k].y > 0.f ? __uint_as_float(ga.w[2 * k + 1]) * gl : 0.f;
+    }
+    VNX_FENCE
+    // ---- layer 2: weight side (part 1): acc_w1[o] += g2[o] * x1;  data side (both): g1 += W1[o] * g2[o]
+    float2_t g1[kP1];
+#pragma unroll
+    for (int k = 0; k < kP1; ++k) g1[k] = zero2;
+#define VNX_BWD2(G, o0)                                                                                 \
+    {                                                                                                     \
+      if constexpr (kHas1) { acc_b1[(o0)] += g2[(o0) / 2].x; acc_b1[(o0) + 1] += g2[(o0) / 2].y; }        \
+      _Pragma("unroll") for (int k = 0; k < kP1; ++k) {                                                   \
+        if constexpr (kHas1) {                                                                            \
+          pk_fma_bv<false>(acc_w1[(o0)][k], g2[(o0) / 2], x1[k]);                                         \
+          pk_fma_bv<true>(acc_w1[(o0) + 1][k], g2[(o0) / 2], x1[k]);                                      \
+        }                                                                                                 \
+        pk_fma_sb<false>(g1[k], wpair(G, k), g2[(o0) / 2]);                                               \
+        pk_fma_sb<true>(g1[k], wpair(G, kP1 + k), g2[(o0) / 2]);                                          \
+      }                                                                                                   \
+    }
+    landed(gb); fetch16(ga, W1 + 16, B1 + 2); VNX_FENCE
+    VNX_BWD2(gb, 0) VNX_FENCE
+    landed(ga); fetch16(gb, W1 + 32, B1 + 4); VNX_FENCE
+    VNX_BWD2(ga, 2) VNX_FENCE
+    landed(gb); fetch16(ga, W1 + 48, B1 + 6); VNX_FENCE
+    VNX_BWD2(gb, 4) VNX_FENCE
+    landed(ga); fetch20(gb, W0, B0); VNX_FENCE
+    VNX_BWD2(ga, 6) VNX_FENCE
+#undef VNX_BWD2
+#pragma unroll
+    for (int k = 0; k < kP1; ++k) {
+      g1[k].x = x1[k].x > 0.f ? g1[k].x : 0.f;
+      g1[k].y = x1[k].y > 0.f ? g1[k].y : 0.f;
+    }
+    // ---- layer 1: weight side (part 0): acc_w0[o] += g1[o] * x0;  data side: features (part 0), reference point (part 1)
+    float2_t g0[kP0];
+#pragma unroll
+    for (int k = 0; k < kP0; ++k) g0[k] = zero2;
+#define VNX_BWD1(G, o0)                                                                                 \
+    {                                                                                                     \
+      if constexpr (kHas1) { acc_b0[(o0)] += g1[(o0) / 2].x; acc_b0[(o0) + 1] += g1[(o0) / 2].y; }        \
+      _Pragma("unroll") for (int k = 0; k < kP0; ++k) {                                                   \
+        if constexpr (kHas0) {                                                                            \
+          pk_fma_bv<false>(acc_w0[(o0)][k], g1[(o0) / 2], x0[k]);                                         \
+          pk_fma_bv<true>(acc_w0[(o0) + 1][k], g1[(o0) / 2], x0[k]);                                      \
+        }                                                                                                 \
+        if ((kHas0 && k > 0) || (kHas1 && k == 0)) {                                                      \
+          pk_fma_sb<false>(g0[k], wpair(G, k), g1[(o0) / 2]);                                             \
+          pk_fma_sb<true>(g0[k], wpair(G, kP0 + k), g1[(o0) / 2]);                                        \
+        }                                                                                                 \
+      }                                                                                                   \
+    }
+    landed(gb); fetch20(ga, W0 + 20, B0 + 2); VNX_FENCE
+    VNX_BWD1(gb, 0) VNX_FENCE
+    landed(ga); fetch20(gb, W0 + 40, B0 + 4); VNX_FENCE
+    VNX_BWD1(ga, 2) VNX_FENCE
+    landed(gb); fetch20(ga, W0 + 60, B0 + 6); VNX_FENCE
+    VNX_BWD1(gb, 4) VNX_FENCE
+    landed(ga); VNX_FENCE
+    VNX_BWD1(ga, 6) VNX_FENCE
+#undef VNX_BWD1
+    if constexpr (kHas1) { acc_rx += g0[0].x; acc_ry += g0[0].y; }     // rel = ref - pixel centre
+    if constexpr (kHas0) {
+      if (owner) {
+#pragma unroll
+        for (int c = 0; c < kMhChannels; c += 2) {
+          atomic_add(GF + (int64_t(c) * H + y) * W + x, g0[1 + c / 2].x);
+          atomic_add(GF + (int64_t(c + 1) * H + y) * W + x, g0[1 + c / 2].y);
+        }
+      }
+    }
+  }
+#undef VNX_FENCE
+
+  // wave reductions, four at a time (fused v_add_f32_dpp; interleaved, so no dependent pair is back to back); total k
+  // lands in lane k % 64 of word k / 64, then three coalesced atomics
   float res[3] = {0.f, 0.f, 0.f};
-  auto put = [&](int k, float v) {
-    const float t = wave_sum_to_last(v);
+  uint64_t mine[3] = {0, 0, 0};     // slots of this part: word 0 = parameters 0..63, 1 = 64..127, 2 = 128..168 + the reference point
+  auto place = [&](int k, float t) {
     const int tot = __builtin_amdgcn_readlane(__builtin_bit_cast(int, t), 63);
-    if (lane == (k & 63)) res[k >> 6] = __builtin_bit_cast(float, tot);
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(res[k >> 6]) : "s"(tot), "n"(k & 63));     // lane k % 64 of the word takes the total
+    mine[k >> 6] |= uint64_t(1) << (k & 63);
   };
+  auto put4 = [&](int k0, float a, int k1, float b, int k2, float c, int k3, float d) {
+    wave_sum4_to_last(a, b, c, d);
+    place(k0, a); place(k1, b); place(k2, c); place(k3, d);
+  };
+  if constexpr (kHas0) {
 #pragma unroll
-  for (int o = 0; o < kMhHidden; ++o) {
+    for (int o = 0; o < kMhHidden; ++o) {
+      const int base = W0 + o * (kMhChannels + 2);
+      put4(base, acc_w0[o][0].x, base + 1, acc_w0[o][0].y, base + 2, acc_w0[o][1].x, base + 3, acc_w0[o][1].y);
+      put4(base + 4, acc_w0[o][2].x, base + 5, acc_w0[o][2].y, base + 6, acc_w0[o][3].x, base + 7, acc_w0[o][3].y);
+    }
 #pragma unroll
-    for (int i = 0; i < kMhChannels + 2; ++i) put(W0 + o * (kMhChannels + 2) + i, acc_w0[o][i]);
+    for (int o = 0; o < kMhHidden; o += 2) {
+      const int b0 = W0 + o * (kMhChannels + 2) + 8, b1 = b0 + (kMhChannels + 2);
+      put4(b0, acc_w0[o][4].x, b0 + 1, acc_w0[o][4].y, b1, acc_w0[o + 1][4].x, b1 + 1, acc_w0[o + 1][4].y);
+    }
   }
+  if constexpr (kHas1) {
 #pragma unroll
-  for (int o = 0; o < kMhHidden; ++o) {
+    for (int o = 0; o < kMhHidden; ++o) {
+      const int base = W1 + o * kMhHidden;
+      put4(base, acc_w1[o][0].x, base + 1, acc_w1[o][0].y, base + 2, acc_w1[o][1].x, base + 3, acc_w1[o][1].y);
+      put4(base + 4, acc_w1[o][2].x, base + 5, acc_w1[o][2].y, base + 6, acc_w1[o][3].x, base + 7, acc_w1[o][3].y);
+    }
+    put4(W2, acc_w2[0].x, W2 + 1, acc_w2[0].y, W2 + 2, acc_w2[1].x, W2 + 3, acc_w2[1].y);
+    put4(W2 + 4, acc_w2[2].x, W2 + 5, acc_w2[2].y, W2 + 6, acc_w2[3].x, W2 + 7, acc_w2[3].y);
 #pragma unroll
-    for (int i = 0; i < kMhHidden; ++i) put(W1 + o * kMhHidden + i, acc_w1[o][i]);
+    for (int o = 0; o < kMhHidden; o += 4) {
+      put4(B0 + o, acc_b0[o], B0 + o + 1, acc_b0[o + 1], B0 + o + 2, acc_b0[o + 2], B0 + o + 3, acc_b0[o + 3]);
+      put4(B1 + o, acc_b1[o], B1 + o + 1, acc_b1[o + 1], B1 + o + 2, acc_b1[o + 2], B1 + o + 3, acc_b1[o + 3]);
+    }
+    float pad = 0.f;
+    wave_sum4_to_last(acc_b2, acc_rx, acc_ry, pad);
+    place(168, acc_b2); place(169, acc_rx); place(170, acc_ry);  // slots 169, 170 of word 2: the reference point
   }
-#pragma unroll
-  for (int o = 0; o < kMhHidden; ++o) {
-    put(W2 + o, acc_w2[o]);
-    put(B0 + o, acc_b0[o]);
-    put(B1 + o, acc_b1[o]);
-  }
-  put(168, acc_b2);
-  put(169, acc_rx);   // slots 169, 170 of word 2: the reference point
-  put(170, acc_ry);
   float* GP = grad_params + int64_t(j) * kMhParams;
-  atomic_add(GP + lane, res[0]);
-  atomic_add(GP + 64 + lane, res[1]);
-  if (lane < kMhParams - 128) atomic_add(GP + 128 + lane, res[2]);
-  else if (lane < kMhParams - 128 + 2) atomic_add(grad_ref + 2 * j + (lane - (kMhParams - 128)), res[2]);
+  if ((mine[0] >> lane) & 1) atomic_add(GP + lane, res[0]);
+  if ((mine[1] >> lane) & 1) atomic_add(GP + 64 + lane, res[1]);
+  if ((mine[2] >> lane) & 1) {
+    if (lane < kMhParams - 128) atomic_add(GP + 128 + lane, res[2]);
+    else atomic_add(grad_ref + 2 * j + (lane - (kMhParams - 128)), res[2]);
+  }
+}
+
+// one launch, the two parts of a strip in neighbouring workgroups (they read the same features and upstream gradients)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
+dynamic_mask_head_bwd_kernel(const float* __restrict__ feats, const float* __restrict__ ref,
+                             const float* __restrict__ params, const int* __restrict__ inst_image,
+                             const float* __restrict__ grad_out, float* __restrict__ grad_feats,
+                             float* __restrict__ grad_ref, float* __restrict__ grad_params,
+                             int H, int W, int n_inst, int stride, int strips_x, int strips_y) {
+  const int block = int(blockIdx.x >> 1);
+  if (blockIdx.x & 1)
+    mask_head_bwd_part<1>(block, feats, ref, params, inst_image, grad_out, grad_feats, grad_ref, grad_params, H, W, n_inst,
+                          stride, strips_x, strips_y);
+  else
+    mask_head_bwd_part<0>(block, feats, ref, params, inst_image, grad_out, grad_feats, grad_ref, grad_params, H, W, n_inst,
+                          stride, strips_x, strips_y);
 }
 
 }  // namespace vnx
@@ -545,7 +723,7 @@ extern "C" int vnx_dynamic_mask_head_backward(int dtype, const void* mask_feats,
   }
   const int strips_x = (width + kMhStripW - 1) / kMhStripW;
   const int strips_y = (height + kMbRows - 1) / kMbRows;
-  const int64_t blocks = int64_t(num_insts) * strips_x * strips_y;
+  const int64_t blocks = int64_t(num_insts) * strips_x * strips_y * 2;      // two parts per strip
   if (blocks >= (int64_t(1) << 31)) {
     set_error("vnx_dynamic_mask_head_backward: %lld workgroups exceed the grid limit", (long long)blocks);
     return VNX_ERR_UNSUPPORTED;
