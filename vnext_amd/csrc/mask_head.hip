@@ -265,7 +265,10 @@ dynamic_mask_head_kernel(const float* __restrict__ feats, const float* __restric
 // through coalesced fp32 atomics.  Outputs are zero-filled by the C entry point (memset nodes,
 // graph-capturable).  Lane 63 is a one-pixel halo on the right: the transpose of the
 // up-sampling needs the upstream gradient around pixel (y, x+1) and (y+1, x+1).
-constexpr int kMbRows = 8;
+#ifndef VNX_MB_ROWS
+#define VNX_MB_ROWS 8
+#endif
+constexpr int kMbRows = VNX_MB_ROWS;
 
 struct UpAdj { float d, c, b, a; };  // what a pixel's 2x2 output block sends to in[y][x], in[y][x-1], in[y-1][x], in[y-1][x-1]
 
@@ -617,12 +620,23 @@ mask_head_bwd_part(const int block, const float* __restrict__ feats, const float
 }
 
 // one launch, the two parts of a strip in neighbouring workgroups (they read the same features and upstream gradients)
+// (VNX_MH_BWD_SINGLE: A/B build, one wave per strip doing both parts -- no recomputation, 256 VGPRs + 19 spilled)
+#ifdef VNX_MH_BWD_SINGLE
+constexpr int kMbParts = 1;
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+#else
+constexpr int kMbParts = 2;
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
+#endif
 dynamic_mask_head_bwd_kernel(const float* __restrict__ feats, const float* __restrict__ ref,
                              const float* __restrict__ params, const int* __restrict__ inst_image,
                              const float* __restrict__ grad_out, float* __restrict__ grad_feats,
                              float* __restrict__ grad_ref, float* __restrict__ grad_params,
                              int H, int W, int n_inst, int stride, int strips_x, int strips_y) {
+#ifdef VNX_MH_BWD_SINGLE
+  mask_head_bwd_part<2>(int(blockIdx.x), feats, ref, params, inst_image, grad_out, grad_feats, grad_ref, grad_params, H, W, n_inst,
+                        stride, strips_x, strips_y);
+#else
   const int block = int(blockIdx.x >> 1);
   if (blockIdx.x & 1)
     mask_head_bwd_part<1>(block, feats, ref, params, inst_image, grad_out, grad_feats, grad_ref, grad_params, H, W, n_inst,
@@ -630,6 +644,7 @@ dynamic_mask_head_bwd_kernel(const float* __restrict__ feats, const float* __res
   else
     mask_head_bwd_part<0>(block, feats, ref, params, inst_image, grad_out, grad_feats, grad_ref, grad_params, H, W, n_inst,
                           stride, strips_x, strips_y);
+#endif
 }
 
 }  // namespace vnx
@@ -723,7 +738,7 @@ extern "C" int vnx_dynamic_mask_head_backward(int dtype, const void* mask_feats,
   }
   const int strips_x = (width + kMhStripW - 1) / kMhStripW;
   const int strips_y = (height + kMbRows - 1) / kMbRows;
-  const int64_t blocks = int64_t(num_insts) * strips_x * strips_y * 2;      // two parts per strip
+  const int64_t blocks = int64_t(num_insts) * strips_x * strips_y * kMbParts;      // two parts per strip
   if (blocks >= (int64_t(1) << 31)) {
     set_error("vnx_dynamic_mask_head_backward: %lld workgroups exceed the grid limit", (long long)blocks);
     return VNX_ERR_UNSUPPORTED;
