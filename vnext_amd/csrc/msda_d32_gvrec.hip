@@ -358,10 +358,10 @@ msda_bwd_gv_sel_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
   // level back (below), so the coarse levels' units -- three sort chunks each at the decoder shape against
   // one for a fine-level unit, 12-15 us against 6-7 -- start first instead of last (they used to start up
   // to 7 us into the kernel and set its end: 20 us for 8.5 us of mean work per workgroup).
-  const int rest = blockIdx.x / d.M;
+  int rest, b, m;                                  // head <-> XCD map: gv_decode_block (msda_gv_common.h)
+  if (kGvPair16 && sizeof(TV) == 2 && (d.M & 1) == 0) gv_decode_block<true>(blockIdx.x, d.M, d.B, rest, b, m);
+  else gv_decode_block<false>(blockIdx.x, d.M, d.B, rest, b, m);
   const int unit = rest / d.B;
-  const int b = rest - unit * d.B;
-  const int m = (blockIdx.x % d.M + b) % d.M;      // head <-> XCD map rotates with the batch element (msda_d32.hip)
   VNX_STAMP(0);
 
   if (tid < d.L) {
@@ -675,7 +675,7 @@ static int launch_gvrec(const int64_t* shapes, const int64_t* lsi, const void* r
   // mode 0: per-unit sample selection (P == 4); 3: register slab, every unit scans its level;
   // 1: the LDS-slab form (variants 425 / 420 select the last two)
   const int units_bound = msda_gvrec_units_bound(d, units_min, rec::kRowsMax);
-  const int64_t blocks = int64_t(d.B) * d.M * units_bound;
+  const int64_t blocks = ((int64_t(d.B) * units_bound + 1) & ~int64_t(1)) * d.M;     // (unit, batch) pairs: even (gv_decode_block)
   if (mode == 0 && d.P == 4 && d.L <= rec::kLevelsMax) {
     const uint32_t* unit_ids = reinterpret_cast<const uint32_t*>((const char*)records + gv_unit_ids_offset(d));
     hipLaunchKernelGGL((rec::msda_bwd_gv_sel_kernel<TV>), dim3(uint32_t(blocks)), dim3(rec::kThreads),

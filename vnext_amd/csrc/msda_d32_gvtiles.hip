@@ -66,10 +66,10 @@ msda_bwd_gv_tiles_kernel(const int64_t* __restrict__ shapes, const int64_t* __re
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // dispatch order = cost order (units numbered from the last level back), head <-> XCD map rotating with the
   // batch element: as in msda_d32_gvrec.hip
-  const int rest = blockIdx.x / d.M;
+  int rest, b, m;
+  if (kGvPair16 && sizeof(TV) == 2 && (d.M & 1) == 0) gv_decode_block<true>(blockIdx.x, d.M, d.B, rest, b, m);
+  else gv_decode_block<false>(blockIdx.x, d.M, d.B, rest, b, m);
   const int unit = rest / d.B;
-  const int b = rest - unit * d.B;
-  const int m = (blockIdx.x % d.M + b) % d.M;
 
   if (tid < d.L) {     // level table: {H, W, start, workgroups, query pieces, block width, blocks per row, block height}
     const int H = int(shapes[2 * tid]), W = int(shapes[2 * tid + 1]);
@@ -374,7 +374,7 @@ static int launch_gvtiles(const int64_t* shapes, const int64_t* lsi, const void*
     return VNX_ERR_UNSUPPORTED;
   }
   const int n_tiles = (d.Lq + tile_queries - 1) / tile_queries;
-  const int64_t blocks = int64_t(d.B) * d.M * msda_gvtiles_units_bound(d, units_min);
+  const int64_t blocks = ((int64_t(d.B) * msda_gvtiles_units_bound(d, units_min) + 1) & ~int64_t(1)) * d.M;   // even: gv_decode_block
   hipLaunchKernelGGL((rec::msda_bwd_gv_tiles_kernel<TV, TL>), dim3(uint32_t(blocks)), dim3(rec::kThreads),
                      rec::kTilesLdsBytes, stream, shapes, lsi, (const TL*)loc, (const TL*)attn,
                      (const rec::uint2_t*)summaries, (const TV*)grad_out, (TV*)grad_value, d, units_min, tile_shift, n_tiles,

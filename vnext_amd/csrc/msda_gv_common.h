@@ -41,7 +41,7 @@ template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, float4_t v
   uint2_t r;
   r.x = uint32_t(f32_to_bf16_bits(v.x)) | (uint32_t(f32_to_bf16_bits(v.y)) << 16);
   r.y = uint32_t(f32_to_bf16_bits(v.z)) | (uint32_t(f32_to_bf16_bits(v.w)) << 16);
-#ifdef VNX_GV_STORE16_PLAIN      // A/B build (tools/r3_call23.sh)
+#if defined(VNX_GV_STORE16_PLAIN) || (defined(VNX_GV_PAIR16) && !defined(VNX_GV_PAIR16_NT))      // A/B builds (tools/r3_call23.sh, r3_call33.sh)
   *reinterpret_cast<uint2_t*>(p) = r;
 #else
   __builtin_nontemporal_store(r, reinterpret_cast<uint2_t*>(p));
@@ -53,6 +53,33 @@ template <> __device__ __forceinline__ void store4<f16_t>(f16_t* p, float4_t v) 
   r.y = uint32_t(__builtin_bit_cast(uint16_t, _Float16(v.z))) | (uint32_t(__builtin_bit_cast(uint16_t, _Float16(v.w))) << 16);
   __builtin_nontemporal_store(r, reinterpret_cast<uint2_t*>(p));
 }
+
+// Workgroup -> (unit x batch index `rest`, head).  fp32: blockIdx % M picks the head (= the XCD when M == 8), rotated
+// by the batch element (msda_d32.hip).  16-bit values (VNX_GV_PAIR16): a row is 64 B, HALF a cache line, the other half
+// is the next head's row -- written by another XCD each half is a partial-line write (grad_value kernel at decoder-720p:
+// 36.5 us in bf16 against 32.1 in fp32 for half the bytes, no extra traffic by PMC).  So a PAIR of heads shares an XCD
+// (XCDs x and x + M/2 split the units of the pair between them), neighbouring workgroups of an XCD take the two heads of
+// one unit, and the rows are written with plain stores: the two halves meet in that XCD's L2 and leave as one line.
+template <bool PAIR>
+__device__ __forceinline__ void gv_decode_block(uint32_t block, int M, int B, int& rest, int& b, int& m) {
+  const int x = int(block % uint32_t(M)), j = int(block / uint32_t(M));
+  if constexpr (PAIR) {
+    const int half = M >> 1;
+    const int xh = x % half, side = x / half;
+    rest = (j >> 1) * 2 + side;
+    b = rest % B;
+    m = 2 * ((xh + b) % half) + (j & 1);
+  } else {
+    rest = j;
+    b = rest % B;
+    m = (x + b) % M;
+  }
+}
+#ifdef VNX_GV_PAIR16
+constexpr bool kGvPair16 = true;
+#else
+constexpr bool kGvPair16 = false;
+#endif
 
 // The value again, but opaque to the optimiser: what is derived from the result is recomputed where it is used instead of
 // being hoisted out of the loops and then SPILLED (the selection kernel kept `tid | 0x200`, `tid >> 2`, `tid * 4`, ... live
