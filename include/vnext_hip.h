@@ -97,9 +97,13 @@ enum {
 };
 
 /*
- * Bytes of scratch vnx_msda_backward needs for these sizes and flags: 0 for F32 /
- * F64, and for 16-bit values whose levels are promised packed; otherwise an fp32
- * accumulation image of grad_value.
+ * Bytes of scratch vnx_msda_backward needs for these sizes and flags (and the current
+ * kernel variant).  32-channel heads: what the grad_loc kernel hands the grad_value
+ * kernel -- 20 B per sample (records + unit tags) below 1 024 queries, 8 B per (batch,
+ * head, level, 16-query tile) from there on -- plus an fp32 [B, S, M, 32] image of
+ * grad_value for 16-bit values unless the levels are promised packed AND there are
+ * fewer than 1 024 queries (the general path / the query-split levels accumulate with
+ * fp32 atomics).  Other head widths: that image for 16-bit values, else 0.
  */
 size_t vnx_msda_backward_workspace_bytes(int value_dtype, int loc_dtype, int batch,
                                          int spatial_size, int num_heads, int channels,
