@@ -29,6 +29,8 @@ run enc360_M_bf16 --shape enc360 --dtype bf16 --dist M --op both --variants 0 --
 run enc360_M_tile --shape enc360 --dist M --op fwd --variants 700 --inner 8 --reps 7
 run enc360_M_tile2 --shape enc360 --dist M --op fwd --variants 720 --inner 8 --reps 7
 run enc720_M      --shape enc720 --dist M --op both --variants 0 --inner 4 --reps 5
+run enc720_M_B2   --shape enc720 --B 2 --dist M --op both --variants 0 --inner 4 --reps 7
+run enc360_M_fused --shape enc360 --dist M --op fbwd --variants 0 --inner 8 --reps 7
 run enc720_M_B2_bf16 --shape enc720 --dtype bf16 --B 2 --dist M --op both --variants 0 --inner 4 --reps 5
 pmc enc360_M      --shape enc360 --dist M --op both --variants 0
 pmc enc720_M      --shape enc720 --dist M --op both --variants 0
