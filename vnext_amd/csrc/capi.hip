@@ -49,13 +49,13 @@ int msda_forward_d32(int, int, const void*, const int64_t*, const int64_t*, cons
                      const void*, void*, MsdaDims, int variant, hipStream_t);
 int msda_backward_d32(int, int, const void*, const int64_t*, const int64_t*, const void*,
                       const void*, const void*, void*, void*, void*, MsdaDims, int variant,
-                      void* records, void* tile_summary, hipStream_t);
+                      void* records, void* tile_summary, float* tile_copy, hipStream_t);
 int msda_bwd_tile_queries(const MsdaDims& d, int variant);
 bool msda_d32_gvtiles_supported(int vdt, int ldt, const MsdaDims& d);
 size_t msda_gvtiles_summary_bytes(const MsdaDims& d, int tile_queries);
 int msda_backward_gvtiles_d32(int vdt, int ldt, const int64_t*, const int64_t*, const void* loc, const void* attn,
                               const void* summaries, const void* grad_out, void* grad_value, MsdaDims,
-                              int tile_queries, float* split_image, hipStream_t);
+                              int tile_queries, float* split_image, bool compact, hipStream_t);
 bool msda_d32_fused_supported(int vdt, int ldt, const MsdaDims& d);
 int msda_fused_d32(bool backward, int vdt, int ldt, const void* value, const int64_t* shapes, const int64_t* lsi,
                    const void* raw_off, const void* raw_logit, const void* grad_out, void* out_or_grad_off,
@@ -260,8 +260,21 @@ static bool use_tiles(int vdt, int ldt, const MsdaDims& d, int variant) {
 static bool split_image_needed(int vdt, const MsdaDims& d) {
   return (vdt == VNX_BF16 || vdt == VNX_F16) && d.P == 4 && d.Lq >= 1024;
 }
+// Tile path: does the grad_loc kernel leave a copy of the locations / weights laid out for the grad_value kernel
+// ([batch][head][level][query][point], fp32, 12 B per sample)?  The fused backward always does (it has to materialise
+// them anyway: 196.7 -> 194.9 us at encoder-360p against the op's own layout).  The plain backward does not: the 12 B per
+// sample the grad_loc kernel then writes cost more than the grad_value kernel's tidier reads save (encoder-360p 186 vs
+// 175 us, 720p B = 2 337 vs 322 us, B = 5 664 vs 654 us -- although that kernel fetches 2 GB per 720p launch, PMC).
+// Variant 510 forces the copy for A/B runs.
+static bool tile_copy_wanted(const MsdaDims& d, int variant) {
+  (void)d;
+  return variant == 510;
+}
+static size_t tile_copy_bytes(const MsdaDims& d) { return align256(size_t(12) * size_t(d.B) * d.Lq * d.M * d.L * d.P); }
 static size_t fast_path_scratch_bytes(int vdt, int ldt, const MsdaDims& d, int variant) {
-  if (use_tiles(vdt, ldt, d, variant)) return align256(msda_gvtiles_summary_bytes(d, msda_bwd_tile_queries(d, variant)));
+  if (use_tiles(vdt, ldt, d, variant))
+    return align256(msda_gvtiles_summary_bytes(d, msda_bwd_tile_queries(d, variant))) +
+           (tile_copy_wanted(d, variant) ? tile_copy_bytes(d) : 0);
   return align256(msda_gvrec_record_bytes(d));
 }
 
@@ -333,6 +346,9 @@ int vnx_msda_backward(int value_dtype, int loc_dtype, const void* value,
     const size_t rec_bytes = fast_path_scratch_bytes(value_dtype, loc_dtype, d, variant);
     void* records = tiles ? nullptr : workspace;
     void* tile_words = tiles ? workspace : nullptr;
+    float* tile_copy = (tiles && tile_copy_wanted(d, variant))
+                           ? (float*)((char*)workspace + align256(msda_gvtiles_summary_bytes(d, msda_bwd_tile_queries(d, variant))))
+                           : nullptr;
     const bool split16 = split_image_needed(value_dtype, d);
     void* image = (sixteen && (!(flags & VNX_MSDA_LEVELS_PACKED) || split16)) ? (void*)((char*)workspace + rec_bytes) : nullptr;
     float* split_image = split16 ? (float*)image : nullptr;
@@ -344,13 +360,17 @@ int vnx_msda_backward(int value_dtype, int loc_dtype, const void* value,
                            sampling_loc, attn_weight, grad_output,
                            value_dtype == VNX_F32 ? grad_value : (void*)split_image, grad_sampling_loc,
                            grad_attn_weight, d, only_gl ? variant : 100 + (variant < 100 ? variant : 0),
-                           records, tile_words, stream);
+                           records, tile_words, tile_copy, stream);
     if (st != VNX_OK) return st;
     if (!only_gl) {
       if (tiles)
-        st = msda_backward_gvtiles_d32(value_dtype, loc_dtype, spatial_shapes, level_start_index, sampling_loc,
-                                       attn_weight, tile_words, grad_output, grad_value, d,
-                                       msda_bwd_tile_queries(d, variant), split_image, stream);
+        st = tile_copy
+                 ? msda_backward_gvtiles_d32(value_dtype, VNX_F32, spatial_shapes, level_start_index, tile_copy,
+                                             tile_copy + 2 * (int64_t(d.B) * d.Lq * d.M * d.L * d.P), tile_words, grad_output,
+                                             grad_value, d, msda_bwd_tile_queries(d, variant), split_image, true, stream)
+                 : msda_backward_gvtiles_d32(value_dtype, loc_dtype, spatial_shapes, level_start_index, sampling_loc,
+                                             attn_weight, tile_words, grad_output, grad_value, d,
+                                             msda_bwd_tile_queries(d, variant), split_image, false, stream);
       else
         st = msda_backward_gvrec_d32(value_dtype, spatial_shapes, level_start_index, records, grad_output,
                                      grad_value, d, variant, split_image, stream);
@@ -391,7 +411,7 @@ int vnx_msda_backward(int value_dtype, int loc_dtype, const void* value,
   if (variant >= 300 && variant < 400 && msda_d32_bwd_supported(value_dtype, loc_dtype, d))
     st = msda_backward_d32(value_dtype, loc_dtype, value, spatial_shapes, level_start_index,
                            sampling_loc, attn_weight, grad_output, gv_acc, grad_sampling_loc,
-                           grad_attn_weight, d, variant - 300, nullptr, nullptr, stream);
+                           grad_attn_weight, d, variant - 300, nullptr, nullptr, nullptr, stream);
   else
     st = msda_backward_generic(value_dtype, loc_dtype, value, spatial_shapes, level_start_index,
                                sampling_loc, attn_weight, grad_output, gv_acc, grad_sampling_loc,
@@ -529,7 +549,7 @@ int vnx_msda_fused_backward(int value_dtype, int query_dtype, const void* value,
                         tile_attn, stream);
     if (st != VNX_OK) return st;
     st = msda_backward_gvtiles_d32(value_dtype, VNX_F32, spatial_shapes, level_start_index, tile_loc, tile_attn, words,
-                                   grad_output, grad_value, d, msda_bwd_tile_queries(d, 0), split_image, stream);
+                                   grad_output, grad_value, d, msda_bwd_tile_queries(d, 0), split_image, true, stream);
   } else {
     // (1) grad of the Linear outputs (+ reference points) and the sample records; (2) grad_value from the records
     st = msda_fused_d32(true, value_dtype, query_dtype, value, spatial_shapes, level_start_index, sampling_offsets,

@@ -831,15 +831,19 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
       fused_decode<TL>(loc, attn, fa, wi, b, q, l, valid ? int(shapes[2 * l]) : 1, valid ? int(shapes[2 * l + 1]) : 1,
                        d, valid, x, y, a, sx, sy);
       g4.w = a;   // the softmax weight of every sample, in or out of the map (softmax backward, phase 3)
-      if (fa.tile_loc != nullptr && valid) {      // what the tile-fed grad_value kernel decodes again (fp32: the same bits)
-        *reinterpret_cast<float2_t*>(fa.tile_loc + 2 * wi) = float2_t{x, y};
-        fa.tile_attn[wi] = a;
-      }
     }
     if (q < d.Lq) {
       if constexpr (!FUSED) {
         x = to_acc(loc[2 * wi]); y = to_acc(loc[2 * wi + 1]);
         a = to_acc(attn[wi]);
+      }
+      if constexpr (LP_T == 16 && !ATOMICS) {
+        if (fa.tile_loc != nullptr) {      // what the tile-fed grad_value kernel decodes again (fp32: the same bits), laid out
+          // [batch][head][level][query][point]: that kernel walks the queries of one (batch, head, level)
+          const int64_t ci = ((int64_t(b) * d.M + m) * d.L + l) * (int64_t(d.Lq) * d.P) + int64_t(q) * d.P + (p - l * d.P);
+          *reinterpret_cast<float2_t*>(fa.tile_loc + 2 * ci) = float2_t{x, y};
+          fa.tile_attn[ci] = a;
+        }
       }
       const int H = int(shapes[2 * l]), W = int(shapes[2 * l + 1]);
       const int start = int(lsi[l]);
@@ -1146,7 +1150,7 @@ template <typename TV, typename TL, int QPW, int WPB>
 static int launch_bwd_cfg(const void* value, const int64_t* shapes, const int64_t* lsi,
                           const void* loc, const void* attn, const void* grad_out, void* gv,
                           void* grad_loc, void* grad_attn, const MsdaDims& d, bool atomics,
-                          void* records, void* tile_summary, hipStream_t stream) {
+                          void* records, void* tile_summary, float* tile_copy, hipStream_t stream) {
   // records / tile mode: `gv` is not an accumulation image but the fp32 target of the query-split levels' atomics --
   // grad_value itself for fp32 values, the fp32 split image for 16-bit ones (or null) -- whose rows this kernel zeroes
   void* qsplit_zero = (!atomics && (records != nullptr || tile_summary != nullptr)) ? gv : nullptr;
@@ -1173,7 +1177,9 @@ static int launch_bwd_cfg(const void* value, const int64_t* shapes, const int64_
                      (const TL*)attn, (const TV*)grad_out, (float*)gv, (TL*)grad_loc,            \
                      (TL*)grad_attn, d, tiles_per_batch, (uint4_t*)records, (uint32_t*)unit_ids,                \
                      (uint32_t*)tile_summary, units_min,                                                          \
-                     take_stamp_region(kStampGradLoc, blocks), FusedArgs{nullptr, nullptr, 0, 0, (float*)qsplit_zero})
+                     take_stamp_region(kStampGradLoc, blocks),                                                   \
+                     FusedArgs{nullptr, nullptr, 0, 0, (float*)qsplit_zero, tile_copy,                            \
+                               tile_copy ? tile_copy + 2 * (int64_t(d.B) * d.Lq * d.M * d.L * d.P) : nullptr})
   if (!atomics) { if (LP == 16) VNX_LAUNCH(16, false); else VNX_LAUNCH(0, false); }
   else { if (LP == 16) VNX_LAUNCH(16, true); else VNX_LAUNCH(0, true); }
 #undef VNX_LAUNCH
@@ -1184,14 +1190,14 @@ template <typename TV, typename TL>
 static int launch_bwd(const void* value, const int64_t* shapes, const int64_t* lsi,
                       const void* loc, const void* attn, const void* grad_out, void* gv,
                       void* grad_loc, void* grad_attn, const MsdaDims& d, int variant, void* records,
-                      void* tile_summary, hipStream_t stream) {
+                      void* tile_summary, float* tile_copy, hipStream_t stream) {
   // variant 100+v: ablation without the grad_value atomics (timing only, wrong grad_value)
   const bool atomics = variant < 100;
   const FwdCfg c = pick_fwd_cfg(d, atomics ? variant : variant - 100);
 #define VNX_CASE(Q, W)                                                                       \
   if (c.qpw == Q && c.wpb == W)                                                              \
     return launch_bwd_cfg<TV, TL, Q, W>(value, shapes, lsi, loc, attn, grad_out, gv, grad_loc, \
-                                        grad_attn, d, atomics, records, tile_summary, stream);
+                                        grad_attn, d, atomics, records, tile_summary, tile_copy, stream);
   VNX_CASE(8, 4) VNX_CASE(4, 4) VNX_CASE(2, 4) VNX_CASE(1, 4)
   VNX_CASE(8, 1) VNX_CASE(4, 1) VNX_CASE(2, 1) VNX_CASE(1, 1)
   VNX_CASE(4, 2)
@@ -1216,9 +1222,9 @@ bool msda_d32_bwd_supported(int vdt, int ldt, const MsdaDims& d) {
 int msda_backward_d32(int vdt, int ldt, const void* value, const int64_t* shapes,
                       const int64_t* lsi, const void* loc, const void* attn,
                       const void* grad_out, void* gv, void* grad_loc, void* grad_attn, MsdaDims d,
-                      int variant, void* records, void* tile_summary, hipStream_t stream) {
+                      int variant, void* records, void* tile_summary, float* tile_copy, hipStream_t stream) {
   // the 16-bit row limit of the sample records (h0+1, w0+1 packed into one word)
-#define VNX_ARGS value, shapes, lsi, loc, attn, grad_out, gv, grad_loc, grad_attn, d, variant, records, tile_summary, stream
+#define VNX_ARGS value, shapes, lsi, loc, attn, grad_out, gv, grad_loc, grad_attn, d, variant, records, tile_summary, tile_copy, stream
   if (vdt == VNX_F32) return launch_bwd<float, float>(VNX_ARGS);
   if (vdt == VNX_BF16 && ldt == VNX_F32) return launch_bwd<bf16_t, float>(VNX_ARGS);
   if (vdt == VNX_BF16 && ldt == VNX_BF16) return launch_bwd<bf16_t, bf16_t>(VNX_ARGS);

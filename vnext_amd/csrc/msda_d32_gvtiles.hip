@@ -48,7 +48,7 @@ msda_bwd_gv_tiles_kernel(const int64_t* __restrict__ shapes, const int64_t* __re
                          const TL* __restrict__ loc, const TL* __restrict__ attn,
                          const uint2_t* __restrict__ summaries, const TV* __restrict__ grad_out,
                          TV* __restrict__ grad_value, MsdaDims d, int units_min, int tile_shift, int n_tiles,
-                         float* __restrict__ split_image) {
+                         float* __restrict__ split_image, int compact) {
   constexpr int D = 32, P = 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float4_t* grows = reinterpret_cast<float4_t*>(smem);                       // [128][8] grad_out rows
@@ -130,9 +130,14 @@ msda_bwd_gv_tiles_kernel(const int64_t* __restrict__ shapes, const int64_t* __re
   const uint2_t* summ = summaries + ((int64_t(b) * d.M + m) * d.L + lvl) * int64_t(n_tiles);
   // sample (q, head m, level lvl, point k) of this batch element: index  base + q * (M * LP) + k  into attn, twice that
   // into loc; q * M * LP * 2 < 2^32 (msda_d32_gvtiles_supported)
-  const TL* attn_bm = attn + (int64_t(b) * d.Lq * d.M + m) * LP + lvl * P;
-  const TL* loc_bm = loc + 2 * ((int64_t(b) * d.Lq * d.M + m) * LP + lvl * P);
-  const uint32_t s_stride = uint32_t(d.M) * uint32_t(LP);
+  // compact: loc / attn are the grad_loc kernel's copies laid out [batch][head][level][query][point] -- a chunk of 128
+  // queries is 4 KB + 2 KB of consecutive bytes.  In the op's own layout the 32 + 16 bytes of a (query, head, level)
+  // sit in two cache lines of their own per query: 2 GB fetched per 720p B = 5 launch (PMC), the kernel bandwidth-bound.
+  const int64_t s_base = compact ? ((int64_t(b) * d.M + m) * d.L + lvl) * int64_t(d.Lq) * P
+                                 : (int64_t(b) * d.Lq * d.M + m) * LP + lvl * P;
+  const TL* attn_bm = attn + s_base;
+  const TL* loc_bm = loc + 2 * s_base;
+  const uint32_t s_stride = compact ? uint32_t(P) : uint32_t(d.M) * uint32_t(LP);
   const TV* go_head = grad_out + (int64_t(b) * d.Lq * d.M + m) * D;
   const uint32_t q_stride = uint32_t(d.M) * uint32_t(D);
   const float Hf = float(Hl), Wf = float(Wl);
@@ -366,7 +371,7 @@ bool msda_d32_gvtiles_supported(int vdt, int ldt, const MsdaDims& d) {
 template <typename TV, typename TL>
 static int launch_gvtiles(const int64_t* shapes, const int64_t* lsi, const void* loc, const void* attn,
                           const void* summaries, const void* grad_out, void* grad_value, const MsdaDims& d,
-                          int units_min, int tile_queries, float* split_image, hipStream_t stream) {
+                          int units_min, int tile_queries, float* split_image, int compact, hipStream_t stream) {
   int tile_shift = 0;
   while ((1 << tile_shift) < tile_queries) ++tile_shift;
   if ((1 << tile_shift) != tile_queries || tile_queries > rec::kQcMax) {
@@ -378,16 +383,16 @@ static int launch_gvtiles(const int64_t* shapes, const int64_t* lsi, const void*
   hipLaunchKernelGGL((rec::msda_bwd_gv_tiles_kernel<TV, TL>), dim3(uint32_t(blocks)), dim3(rec::kThreads),
                      rec::kTilesLdsBytes, stream, shapes, lsi, (const TL*)loc, (const TL*)attn,
                      (const rec::uint2_t*)summaries, (const TV*)grad_out, (TV*)grad_value, d, units_min, tile_shift, n_tiles,
-                     split_image);
+                     split_image, compact);
   return check_launch("msda_bwd_gv_tiles");
 }
 
 // grad_value from the op's inputs and the tile words; a no-op on the device when the levels are not packed.
 int msda_backward_gvtiles_d32(int vdt, int ldt, const int64_t* shapes, const int64_t* lsi, const void* loc,
                               const void* attn, const void* summaries, const void* grad_out, void* grad_value,
-                              MsdaDims d, int tile_queries, float* split_image, hipStream_t stream) {
+                              MsdaDims d, int tile_queries, float* split_image, bool compact, hipStream_t stream) {
   const int units_min = gv_units_min(d, true);
-#define VNX_ARGS shapes, lsi, loc, attn, summaries, grad_out, grad_value, d, units_min, tile_queries, split_image, stream
+#define VNX_ARGS shapes, lsi, loc, attn, summaries, grad_out, grad_value, d, units_min, tile_queries, split_image, int(compact), stream
   if (vdt == VNX_F32) return launch_gvtiles<float, float>(VNX_ARGS);
   if (vdt == VNX_BF16 && ldt == VNX_F32) return launch_gvtiles<bf16_t, float>(VNX_ARGS);
   if (vdt == VNX_BF16 && ldt == VNX_BF16) return launch_gvtiles<bf16_t, bf16_t>(VNX_ARGS);
