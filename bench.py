@@ -949,6 +949,15 @@ def main():
         line["roofline"]["gather_ceiling_GBs"] = ceil["cold_384MiB"]["GBs"]
         line["roofline"]["gather_ceiling"] = ceil
         line["roofline"]["frac_of_gather_ceiling"] = line["roofline"]["achieved"] / ceil["cold_384MiB"]["GBs"]
+        # what a cold launch of this size cannot beat: one memory latency before the first row arrives + its algorithmic
+        # bytes at the gather rate measured above
+        lat_us = 2.0
+        floor_us = lat_us + bytes_fwd / ceil["cold_384MiB"]["GBs"] / 1e3
+        line["roofline"]["floor_us"] = floor_us
+        line["roofline"]["floor_frac"] = bytes_fwd / floor_us / 1e3 / HBM_PEAK_GBS
+        line["roofline"]["floor_note"] = ("%.1f us of memory latency + algorithmic bytes / the row-gather rate of this run "
+                                          "(%.0f GB/s): the ceiling for a cold call of this size, as a fraction of HBM peak "
+                                          "= floor_frac" % (lat_us, ceil["cold_384MiB"]["GBs"]))
         # HBM bytes per launch cannot be counted from inside this process: they come from the committed
         # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command (profiles/rNN_bench_pmc_hbm.json,
         # corrected as MI355X_MICROARCH.md section HBM says); the rocprofv3 kernel averages ride along
