@@ -222,6 +222,11 @@ __device__ __forceinline__ void fused_decode(const TL* __restrict__ raw_off, con
 #ifndef VNX_K1_BATCH
 #define VNX_K1_BATCH 4
 #endif
+// fp32 rows of the grad_loc kernel as 4 lanes x 32 B (A/B macro: 0 = never, 1 = large-call configurations, 2 = all)
+#ifndef VNX_K1_F32_LPR4_MODE
+#define VNX_K1_F32_LPR4_MODE 0
+#endif
+#define VNX_K1_F32_LPR4(WPB_) (VNX_K1_F32_LPR4_MODE == 2 || (VNX_K1_F32_LPR4_MODE == 1 && (WPB_) > 1))
 #ifndef VNX_K1_BATCH_LARGE
 #define VNX_K1_BATCH_LARGE 2
 #endif
@@ -767,7 +772,7 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
                     uint32_t* __restrict__ sample_units, uint32_t* __restrict__ tile_summary, int units_min,
                     unsigned long long* stamps, FusedArgs fa) {
   static_assert(!FUSED || (LP_T == 16 && !ATOMICS), "the fused prologue is built for L*P == 16, record-fed grad_value");
-  static_assert(LPR == 8 || (LPR == 4 && sizeof(TV) == 2 && LP_T == 16 && !ATOMICS), "4 lanes per row: 16-bit values, L*P == 16");
+  static_assert(LPR == 8 || (LPR == 4 && LP_T == 16 && !ATOMICS), "4 lanes per row: L*P == 16, owner-computes grad_value");
   stamp_begin(stamps);
   constexpr int D = 32;
   constexpr int PG = (64 / LPR) / QPW;
@@ -952,47 +957,82 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
   float4_t* g_res = s_res + qi * (LP + 1) + pg * per_group;
 
   if constexpr (LPR == 4) {
-    // 16-bit rows as 4 lanes x 16 B: 8 channels of grad_out and of every tap per lane, the four dots of a sample
-    // reduced over 4 lanes (two quad permutes) instead of 8
+    // a row as 4 lanes x 8 channels (16-bit values: one 16-B load per tap; fp32: two): the four dots of a sample are
+    // reduced over 4 lanes (two quad permutes) instead of 8, and a wave instruction covers 16 samples.  fp32 (round 3):
+    // this kernel is bound by vector issue on large calls; per 8 samples 8 x 8 lanes cost 4 loads + 12 packed dot
+    // instructions + 8 DPP adds, 16 x 4 lanes cost per 16 samples 8 loads + 20 + 8.
+    constexpr bool k16 = sizeof(TV) == 2;
     float4_t t_lo = {0.f, 0.f, 0.f, 0.f}, t_hi = t_lo;
     if (q < d.Lq) {
-      const uint4_t r = *reinterpret_cast<const uint4_t*>(grad_out + ((int64_t(b) * d.Lq + q) * d.M + m) * D + ch * 8);
-      unpack8<TV>(r, t_lo, t_hi);
+      const TV* gp = grad_out + ((int64_t(b) * d.Lq + q) * d.M + m) * D + ch * 8;
+      if constexpr (k16) {
+        unpack8<TV>(*reinterpret_cast<const uint4_t*>(gp), t_lo, t_hi);
+      } else {
+        t_lo = *reinterpret_cast<const float4_t*>(gp);
+        t_hi = *reinterpret_cast<const float4_t*>(gp + 4);
+      }
     }
     const float2_t ta = {t_lo.x, t_lo.y}, tb = {t_lo.z, t_lo.w}, tc = {t_hi.x, t_hi.y}, td = {t_hi.z, t_hi.w};
-    auto dot8 = [&](const uint4_t raw) {
-      float4_t lo, hi;
-      unpack8<TV>(raw, lo, hi);
+    auto dot8f = [&](const float4_t lo, const float4_t hi) {
       float2_t a2 = ta * float2_t{lo.x, lo.y};
       a2 = tb * float2_t{lo.z, lo.w} + a2;
       a2 = tc * float2_t{hi.x, hi.y} + a2;
       a2 = td * float2_t{hi.z, hi.w} + a2;
       return a2.x + a2.y;
     };
+    auto dot8 = [&](const uint4_t raw) {
+      float4_t lo, hi;
+      unpack8<TV>(raw, lo, hi);
+      return dot8f(lo, hi);
+    };
     constexpr int kPer = LP_T / PG;
-    constexpr int kWant = WPB == 1 ? VNX_K1_BATCH : VNX_K1_BATCH_LARGE;
+    constexpr int kWant = k16 ? (WPB == 1 ? VNX_K1_BATCH : VNX_K1_BATCH_LARGE) : (WPB == 1 ? 2 : 1);   // fp32: 8 registers per tap
     constexpr int kBatch = kPer < kWant ? kPer : kWant;
     static_assert(kPer % kBatch == 0, "whole batches");
     const uint32_t lane_off = uint32_t(ch * kLaneBytes);
 #pragma unroll
     for (int i0 = 0; i0 < kPer; i0 += kBatch) {
       uint4_t o[kBatch];
-      uint4_t raw[kBatch][4];
 #pragma unroll
       for (int j = 0; j < kBatch; ++j) o[j] = g_off[i0 + j];
+      if constexpr (k16) {
+        uint4_t raw[kBatch][4];
 #pragma unroll
-      for (int j = 0; j < kBatch; ++j) {
-        raw[j][0] = __builtin_amdgcn_raw_buffer_load_b128(vsrc, int(o[j].x * 2u + lane_off), 0, 0);
-        raw[j][1] = __builtin_amdgcn_raw_buffer_load_b128(vsrc, int(o[j].y * 2u + lane_off), 0, 0);
-        raw[j][2] = __builtin_amdgcn_raw_buffer_load_b128(vsrc, int(o[j].z * 2u + lane_off), 0, 0);
-        raw[j][3] = __builtin_amdgcn_raw_buffer_load_b128(vsrc, int(o[j].w * 2u + lane_off), 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
+        for (int j = 0; j < kBatch; ++j) {
+          raw[j][0] = __builtin_amdgcn_raw_buffer_load_b128(vsrc, int(o[j].x * 2u + lane_off), 0, 0);
+          raw[j][1] = __builtin_amdgcn_raw_buffer_load_b128(vsrc, int(o[j].y * 2u + lane_off), 0, 0);
+          raw[j][2] = __builtin_amdgcn_raw_buffer_load_b128(vsrc, int(o[j].z * 2u + lane_off), 0, 0);
+          raw[j][3] = __builtin_amdgcn_raw_buffer_load_b128(vsrc, int(o[j].w * 2u + lane_off), 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int j = 0; j < kBatch; ++j) {
-        float4_t dd = {dot8(raw[j][0]), dot8(raw[j][1]), dot8(raw[j][2]), dot8(raw[j][3])};
-        group4_sum4(dd);
-        if (ch == 0) g_res[i0 + j] = dd;
+        for (int j = 0; j < kBatch; ++j) {
+          float4_t dd = {dot8(raw[j][0]), dot8(raw[j][1]), dot8(raw[j][2]), dot8(raw[j][3])};
+          group4_sum4(dd);
+          if (ch == 0) g_res[i0 + j] = dd;
+        }
+      } else {
+        uint4_t lo[kBatch][4], hi[kBatch][4];
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+          const uint32_t ob[4] = {o[j].x * 4u + lane_off, o[j].y * 4u + lane_off, o[j].z * 4u + lane_off, o[j].w * 4u + lane_off};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            lo[j][k] = __builtin_amdgcn_raw_buffer_load_b128(vsrc, int(ob[k]), 0, 0);
+            hi[j][k] = __builtin_amdgcn_raw_buffer_load_b128(vsrc, int(ob[k]), 16, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+          float4_t dd;
+          dd.x = dot8f(__builtin_bit_cast(float4_t, lo[j][0]), __builtin_bit_cast(float4_t, hi[j][0]));
+          dd.y = dot8f(__builtin_bit_cast(float4_t, lo[j][1]), __builtin_bit_cast(float4_t, hi[j][1]));
+          dd.z = dot8f(__builtin_bit_cast(float4_t, lo[j][2]), __builtin_bit_cast(float4_t, hi[j][2]));
+          dd.w = dot8f(__builtin_bit_cast(float4_t, lo[j][3]), __builtin_bit_cast(float4_t, hi[j][3]));
+          group4_sum4(dd);
+          if (ch == 0) g_res[i0 + j] = dd;
+        }
       }
     }
   }
@@ -1170,7 +1210,7 @@ static int launch_bwd_cfg(const void* value, const int64_t* shapes, const int64_
   // grad_value kernel reads them
   void* unit_ids = (records != nullptr && d.P == 4) ? (void*)((char*)records + gv_unit_ids_offset(d)) : nullptr;
   const int units_min = gv_units_min(d, tile_summary != nullptr);
-  constexpr int kLpr = sizeof(TV) == 2 ? 4 : 8;    // 16-bit rows as 4 lanes x 16 B (variant 69 passes through launch_bwd as 169: 8 x 8 B)
+  constexpr int kLpr = (sizeof(TV) == 2 || VNX_K1_F32_LPR4(WPB)) ? 4 : 8;    // 16-bit rows as 4 lanes x 16 B; fp32: VNX_K1_F32_LPR4
 #define VNX_LAUNCH(LPT, AT)                                                                     \
   hipLaunchKernelGGL((msda_bwd_d32_kernel<TV, TL, QPW, WPB, LPT, AT, false, ((LPT) == 16 && !(AT)) ? kLpr : 8>), dim3(uint32_t(blocks)),   \
                      dim3(64 * WPB), lds, stream, (const TV*)value, shapes, lsi, (const TL*)loc, \
@@ -1268,7 +1308,7 @@ static int launch_bwd_fused_cfg(const void* value, const int64_t* shapes, const 
   const size_t lds = size_t(WPB) * 3 * QPW * 17 * 16 + 128;
   void* unit_ids = (records != nullptr && d.P == 4) ? (void*)((char*)records + gv_unit_ids_offset(d)) : nullptr;
   const int units_min = gv_units_min(d, tile_summary != nullptr);
-  constexpr int kLpr = sizeof(TV) == 2 ? 4 : 8;
+  constexpr int kLpr = (sizeof(TV) == 2 || VNX_K1_F32_LPR4(WPB)) ? 4 : 8;
   hipLaunchKernelGGL((msda_bwd_d32_kernel<TV, TL, QPW, WPB, 16, false, true, kLpr>), dim3(uint32_t(blocks)), dim3(64 * WPB),
                      lds, stream, (const TV*)value, shapes, lsi, (const TL*)raw_off, (const TL*)raw_logit,
                      (const TV*)grad_out, (float*)nullptr, (TL*)grad_off, (TL*)grad_logit, d, tiles_per_batch,
