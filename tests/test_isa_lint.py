@@ -1,0 +1,78 @@
+"""ISA lint for the hand-scheduled scalar loads of the mask-head kernels (vnext_amd/csrc/mask_head.hip).
+
+Those kernels issue `s_load_dwordx16 / x8 / x4 / x2` in one asm statement and wait for them (`s_waitcnt lgkmcnt(0)`) in
+another, so that the next group of parameters is in flight while the current one is consumed.  The compiler does not
+know that the destination registers are not valid until the wait: if it copied, moved or spilled one of them in
+between, the kernel would read stale values.  This test compiles the file for gfx950 (no GPU needed) and checks,
+instruction by instruction, that nothing touches the destination of a hand-issued scalar load before the next
+`s_waitcnt lgkmcnt(0)`, that the forward kernels spill nothing at all, and that no kernel uses scratch memory."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "vnext_amd", "csrc", "mask_head.hip")
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+@pytest.fixture(scope="module")
+def asm(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    out = tmp_path_factory.mktemp("isa") / "mask_head.s"
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-S",
+                           "--cuda-device-only", "-o", str(out), SRC], stderr=subprocess.DEVNULL)
+    text = open(out).read()
+    funcs = {}
+    for m in re.finditer(r"^(_ZN3vnx\w*mask_head\w*):[^\n]*\n(.*?)^\.Lfunc_end", text, re.S | re.M):
+        funcs[m.group(1)] = m.group(2)
+    assert len(funcs) >= 3, list(funcs)
+    return text, funcs
+
+
+def sregs(token_text):
+    """scalar registers named in an operand string: s7 -> {7}, s[8:23] -> {8..23}"""
+    regs = set()
+    for a, b in re.findall(r"\bs\[(\d+):(\d+)\]", token_text):
+        regs.update(range(int(a), int(b) + 1))
+    for a in re.findall(r"\bs(\d+)\b", token_text):
+        regs.add(int(a))
+    return regs
+
+
+def test_nothing_touches_a_scalar_load_destination_before_the_wait(asm):
+    _, funcs = asm
+    checked = 0
+    for name, body in funcs.items():
+        pending = set()          # destination registers of scalar loads issued since the last full wait
+        for line in body.splitlines():
+            ins = line.split(";")[0].strip()
+            if not ins or ins.startswith(".") or ins.endswith(":"):
+                continue
+            op, _, rest = ins.partition(" ")
+            if op.startswith("s_load_dword"):
+                dst = rest.split(",")[0]
+                assert not (sregs(rest.split(",", 1)[1]) & pending), (name, ins)      # base / offset still in flight
+                pending |= sregs(dst)
+                checked += 1
+                continue
+            if op == "s_waitcnt":
+                if "lgkmcnt(0)" in rest:
+                    pending.clear()
+                continue
+            if pending and op not in ("s_nop",):
+                assert not (sregs(rest) & pending), f"{name}: `{ins}` touches a scalar load still in flight"
+    assert checked > 50        # the kernels do issue their loads this way
+
+
+def test_forward_kernels_spill_nothing_and_nobody_uses_scratch(asm):
+    text, funcs = asm
+    for name, body in funcs.items():
+        if "bwd" not in name:
+            assert "v_readlane_b32" not in body and "v_writelane_b32" not in body, name
+        assert "scratch_" not in body and "buffer_store_dword" not in body, name
+    for m in re.finditer(r"\.private_segment_fixed_size:\s*(\d+)", text):
+        assert int(m.group(1)) == 0
