@@ -486,6 +486,17 @@ int main(int argc, char** argv) {
                pc(en, .5), pc(en, .9), en.empty() ? 0 : en.back());
         for (int k = 0; k < 8; ++k) printf(" %.1f/%.1f", hm[k] / std::max(hn[k], 1), hx[k]);
         printf("\n");
+        {   // duration by unit index (blockIdx / (M * B): units are numbered from the coarsest level back)
+          double um[32] = {0}, ux[32] = {0}; int un[32] = {0};
+          for (int w = 0; w < 4096; ++w) if (hs[w * 16 + 12] > hs[w * 16]) {
+            const int u = std::min(31, w / (M * B));
+            const double dd = (hs[w * 16 + 12] - hs[w * 16]) * 0.01;
+            um[u] += dd; ux[u] = std::max(ux[u], dd); ++un[u];
+          }
+          printf("    duration by unit (mean/max us):");
+          for (int u = 0; u < 32; ++u) if (un[u]) printf(" %d:%.1f/%.1f", u, um[u] / un[u], ux[u]);
+          printf("\n");
+        }
         {   // phase stamps (diagnostic library builds with -DVNX_SEL_STAMPS fill slots 1..11), light vs heavy workgroups
           const char* nm[13] = {"", "table", "tags", "bar", "compact", "stage", "sort", "apply", "bar", "", "", "rest", "store"};
           for (int heavy = 0; heavy < 2; ++heavy) {
