@@ -10,7 +10,7 @@
 namespace vnx {
 
 static thread_local char t_error[512] = "";
-int g_kernel_variant = 0;
+std::atomic<int> g_kernel_variant{0};   // A/B measurement knob (vnx_set_kernel_variant); every entry point reads it once
 
 void set_error(const char* fmt, ...) {
   va_list ap;
@@ -157,7 +157,7 @@ const char* vnx_status_string(int status) {
 
 const char* vnx_last_error(void) { return t_error; }
 
-void vnx_set_kernel_variant(int variant) { g_kernel_variant = variant; }
+void vnx_set_kernel_variant(int variant) { g_kernel_variant.store(variant, std::memory_order_relaxed); }
 
 // buf: device memory of n_words 64-bit words, ZERO-filled by the caller before every measured run
 // (slots of workgroups that never ran stay {0, 0} and are skipped); nullptr disarms
@@ -183,7 +183,7 @@ int vnx_debug_wall_clock_khz(void) {
   if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess) return 0;
   return khz;
 }
-int vnx_get_kernel_variant(void) { return g_kernel_variant; }
+int vnx_get_kernel_variant(void) { return g_kernel_variant.load(std::memory_order_relaxed); }
 
 // The spatially tiled, LDS-staged forward (msda_d32_tile.hip) is built for the calls whose queries are
 // the pixels of the pyramid -- the encoder's -- which the host can only recognise by Lq == S (the level
@@ -527,7 +527,8 @@ int vnx_msda_fused_backward(int value_dtype, int query_dtype, const void* value,
     set_error("vnx_msda_fused_backward: null pointer argument");
     return VNX_ERR_INVALID_ARGUMENT;
   }
-  const FusedScratch fs = fused_scratch(value_dtype, d, g_kernel_variant);
+  const int variant = g_kernel_variant;
+  const FusedScratch fs = fused_scratch(value_dtype, d, variant);
   const size_t rec_bytes = fs.total;
   const bool split16 = split_image_needed(value_dtype, d);
   const size_t need = rec_bytes + (split16 ? sizeof(float) * size_t(batch) * size_t(spatial_size) * num_heads * 32 : 0);
@@ -558,7 +559,7 @@ int vnx_msda_fused_backward(int value_dtype, int query_dtype, const void* value,
                         nullptr, stream);
     if (st != VNX_OK) return st;
     st = msda_backward_gvrec_d32(value_dtype, spatial_shapes, level_start_index, workspace, grad_output,
-                                 grad_value, d, g_kernel_variant, split_image, stream);
+                                 grad_value, d, variant, split_image, stream);
   }
   if (st != VNX_OK) return st;
   if (split_image)

@@ -7,6 +7,7 @@
 #include <stdint.h>
 
 #include "../../include/vnext_hip.h"
+#include <atomic>
 
 namespace vnx {
 
@@ -77,7 +78,7 @@ __device__ __forceinline__ void stamp_begin(unsigned long long* s) {
 __device__ __forceinline__ void stamp_end(unsigned long long* s) {
   if (s && (threadIdx.x & 63) == 0) atomicMax(s + 2 * size_t(blockIdx.x) + 1, (unsigned long long)wall_clock64());
 }
-extern int g_kernel_variant;
+extern std::atomic<int> g_kernel_variant;
 
 struct MsdaDims {
   int B, S, M, D, L, Lq, P;
