@@ -231,3 +231,22 @@ def test_block_units_with_far_and_border_samples():
     loc[:, ::7] = torch.rand(loc[:, ::7].shape, generator=g) * 1.2 - 0.1       # in and around the map, incl. its edges
     case = (sh, lsi, value, loc, attn, go)
     check(run(case, 0), oracle(case), case)
+
+
+def test_level_wider_than_the_tile_boxes_can_count():
+    """A level side beyond 65 534 pixels: the tile boxes saturate ("or beyond") and stay conservative."""
+    shapes = [(1, 70000), (1, 1100), (1, 64), (1, 8)]
+    case = pixel_queries(shapes, 1, 1100, seed=3, M=8)
+    sh, lsi, value, loc, attn, go = case
+    g = torch.Generator().manual_seed(4)
+    loc = loc.clone()
+    loc[:, ::3, :, 0] = torch.rand(loc[:, ::3, :, 0].shape, generator=g)       # level 0 sampled all along its 70 000 pixels
+    case = (sh, lsi, value, loc, attn, go)
+    # fp32 coordinates x * 70 000 - 0.5 carry 4e-3 px of rounding: compare off the pixel grid with that margin
+    gv, gl, ga = run(case, 0)
+    rv, rl, ra = oracle(case)
+    np.testing.assert_allclose(gv, rv, rtol=0, atol=2e-2 * scale(rv))
+    np.testing.assert_allclose(ga, ra, rtol=0, atol=2e-2 * scale(ra))
+    a, b = run(case, 430), run(case, 0)                                          # the record-fed path computes the same
+    np.testing.assert_allclose(a[0], b[0], rtol=0, atol=1e-5 * scale(b[0]))
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])

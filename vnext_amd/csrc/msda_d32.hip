@@ -867,7 +867,7 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
         o4.z = (bot && lef) ? o00 + uint32_t(W) * pixel_elems : kTapOutsideElem;
         o4.w = (bot && rig) ? o00 + uint32_t(W + 1) * pixel_elems : kTapOutsideElem;
         g4.x = h - hf; g4.y = w - wf; g4.z = a;
-        record = uint4_t{(uint32_t(h0 + 1) << 16) | uint32_t(w0 + 1), __float_as_uint(g4.x),
+        record = uint4_t{gv_pack_corner(h0, w0, H, W), __float_as_uint(g4.x),
                          __float_as_uint(g4.y), __float_as_uint(a)};
         if constexpr (LP_T == 16 && !ATOMICS) {
           if (tile_summary != nullptr) {
@@ -890,7 +890,8 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
         if (sample_units != nullptr) {
           uint32_t uu = 0xffffffffu;
           if (record.x != 0xffffffffu) {
-            const int h0 = int(record.x >> 16) - 1, w0 = int(record.x & 0xffffu) - 1;
+            int h0, w0;
+            gv_unpack_corner(record.x, H, W, h0, w0);
             const bool top = h0 >= 0, bot = h0 + 1 <= H - 1, lef = w0 >= 0, rig = w0 + 1 <= W - 1;
             const int p00 = h0 * W + w0;
             const int lo = (top && lef) ? p00 : (top && rig) ? p00 + 1 : (bot && lef) ? p00 + W : p00 + W + 1;

@@ -180,7 +180,8 @@ msda_bwd_gv_rec_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
     float wt[4] = {0.f, 0.f, 0.f, 0.f};
     uint32_t rank[4] = {0u, 0u, 0u, 0u};
     if (r.x != 0xffffffffu && tid < qc * P) {
-      const int h0 = int(r.x >> 16) - 1, w0 = int(r.x & 0xffffu) - 1;
+      int h0, w0;
+      gv_unpack_corner(r.x, Hl, Wl, h0, w0);
       const float lh = __uint_as_float(r.y), lw = __uint_as_float(r.z), a = __uint_as_float(r.w);
       const float hh = 1.f - lh, hw = 1.f - lw;
       const bool top = h0 >= 0, bot = h0 + 1 <= Hl - 1, lef = w0 >= 0, rig = w0 + 1 <= Wl - 1;
@@ -543,7 +544,8 @@ msda_bwd_gv_sel_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
       float wt[4] = {0.f, 0.f, 0.f, 0.f};
       uint32_t rank[4] = {0u, 0u, 0u, 0u};
       if (r.x != 0xffffffffu) {
-        const int h0 = int(r.x >> 16) - 1, w0 = int(r.x & 0xffffu) - 1;
+        int h0, w0;
+        gv_unpack_corner(r.x, Hl, Wl, h0, w0);
         const float lh = __uint_as_float(r.y), lw = __uint_as_float(r.z), a = __uint_as_float(r.w);
         const float hh = 1.f - lh, hw = 1.f - lw;
         const bool top = h0 >= 0, bot = h0 + 1 <= Hl - 1, lef = w0 >= 0, rig = w0 + 1 <= Wl - 1;

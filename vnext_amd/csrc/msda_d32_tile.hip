@@ -483,6 +483,7 @@ msda_fwd_tile_kernel(const float* __restrict__ value, const int64_t* __restrict_
 bool msda_tile_fwd_supported(int vdt, int ldt, const MsdaDims& d) {
   if (vdt != VNX_F32 || ldt != VNX_F32) return false;
   if (d.D != 32 || d.L != tile::kL || d.P != tile::kP) return false;
+  if (d.S > 32766) return false;      // pixel coordinates travel in 15 / 16-bit fields: no level side can exceed S
   return int64_t(d.S) * d.M * 128 < (int64_t(1) << 31) && int64_t(d.Lq) * d.M * 128 < (int64_t(1) << 31);
 }
 

@@ -145,6 +145,25 @@ struct FusedArgs {
 // empty (units = ceil(n / rows_per_unit)).  (Round 2 had the zeroing phase use the count BEFORE normalisation: with
 // units_min = 5 a 16-pixel level gave 5 there and 4 in the grad_value kernel -- different sides of the query-split
 // threshold, atomics onto rows nobody had zeroed.  Latent at the default units_min = 2)
+// The corner (h0, w0) of a sample's 2 x 2 footprint, h0 in [-1, H - 1], w0 in [-1, W - 1], in one word of the 16-byte
+// sample record (grad_loc kernel -> record-fed grad_value kernel): two 16-bit fields while both sides of the level are
+// below 65 535 pixels, the flat index over a (H + 1) x (W + 1) grid otherwise (one integer division per sample to
+// unpack -- levels that large do not occur in the models, but a 1 x 70 000 level used to come back silently wrong).
+// 0xffffffff = sample outside the map (never produced by either form).
+__device__ __forceinline__ bool gv_corner_is_flat(int H, int W) { return H >= 0xffff || W >= 0xffff; }
+__device__ __forceinline__ uint32_t gv_pack_corner(int h0, int w0, int H, int W) {
+  return gv_corner_is_flat(H, W) ? uint32_t(h0 + 1) * uint32_t(W + 1) + uint32_t(w0 + 1)
+                                 : (uint32_t(h0 + 1) << 16) | uint32_t(w0 + 1);
+}
+__device__ __forceinline__ void gv_unpack_corner(uint32_t v, int H, int W, int& h0, int& w0) {
+  if (gv_corner_is_flat(H, W)) {
+    const uint32_t h1 = v / uint32_t(W + 1);
+    h0 = int(h1) - 1; w0 = int(v - h1 * uint32_t(W + 1)) - 1;
+  } else {
+    h0 = int(v >> 16) - 1; w0 = int(v & 0xffffu) - 1;
+  }
+}
+
 // Rows per unit: 320 for the record-fed kernel (5 rows per 8-lane group, 72 VGPRs, 3 units per CU; 19 units per (batch,
 // head) at 360p = 760 workgroups, one round of the 768 resident), 256 for the tile-fed kernel (4 rows per group: 62 VGPRs
 // and 39 KB of LDS, FOUR units per CU -- encoder-360p backward 190.5 -> 176.8 us, 720p B = 2 341 -> 325 us; at 720p B = 5
