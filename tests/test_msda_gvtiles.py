@@ -250,3 +250,25 @@ def test_level_wider_than_the_tile_boxes_can_count():
     a, b = run(case, 430), run(case, 0)                                          # the record-fed path computes the same
     np.testing.assert_allclose(a[0], b[0], rtol=0, atol=1e-5 * scale(b[0]))
     assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_pyramids_on_both_grad_value_paths(seed):
+    """odd level shapes (single rows / columns, wide-and-flat, levels out of size order) through the rectangle grid"""
+    import random
+    rnd = random.Random(1000 + seed)
+    shapes = []
+    for _ in range(4):
+        kind = rnd.choice(["tiny", "row", "col", "wide", "block", "plain"])
+        h, w = {"tiny": (rnd.randint(1, 3), rnd.randint(1, 3)), "row": (1, rnd.randint(2, 300)), "col": (rnd.randint(2, 120), 1),
+                "wide": (rnd.randint(2, 7), rnd.randint(64, 260)), "block": (rnd.randint(8, 30), rnd.randint(64, 140)),
+                "plain": (rnd.randint(4, 40), rnd.randint(4, 63))}[kind]
+        shapes.append((h, w))
+    S = sum(h * w for h, w in shapes)
+    Lq = max(1024 + rnd.randint(0, 40), min(S, 2600))
+    case = pixel_queries(shapes, rnd.choice([1, 2, 3]), Lq, seed=seed, far=0.1)
+    want = oracle(case)
+    tol = 4e-5 if max(w for _, w in shapes) > 200 else 2e-5         # fp32 pixel coordinates of wide levels (see `line` above)
+    check(run(case, 0), want, case, tol)
+    check(run(case, 430), want, case, tol)
+    check(run(case, 200 + rnd.choice([1, 3, 5])), want, case, tol)
