@@ -172,6 +172,8 @@ def compose64(value, offsets, logits, ref, ref_div, shapes):
     (SMALL, 3, 50, 4, 1, False),         # 4-d references (box-refined decoder layers)
     (SMALL, 6, 1200, 4, 3, False),       # 4-d, shared rows, > 1024 queries (the query-split path of grad_value)
     (S360, 2, 5100, 2, 2, False),        # encoder-360p call of a two-frame clip
+    ([(7, 130), (1, 70), (30, 3), (2, 2)], 2, 1100, 2, 1, True),      # odd levels through the tile-fed grad_value path
+    ([(9, 66), (3, 200), (1, 1), (12, 20)], 3, 1030, 4, 3, False),    # (blocks, flat blocks, a single pixel, bands)
 ])
 def test_fused_backward_against_fp64_autograd_of_an_independent_composition(shapes, B, Lq, ref_dim, ref_div, ref_grad):
     from oracle.msda_torch_fallback import msda_grid_sample
