@@ -272,3 +272,18 @@ def test_random_pyramids_on_both_grad_value_paths(seed):
     check(run(case, 0), want, case, tol)
     check(run(case, 430), want, case, tol)
     check(run(case, 200 + rnd.choice([1, 3, 5])), want, case, tol)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_pyramids_forward_and_decoder_backward(seed):
+    """the same odd pyramids with few queries: forward and the record-fed backward against the oracle"""
+    import random
+    rnd = random.Random(2000 + seed)
+    shapes = [(rnd.randint(1, 30), rnd.randint(1, 200)) for _ in range(4)]
+    case = pixel_queries(shapes, 2, rnd.choice([7, 64, 300, 777]), seed=seed, far=0.2)
+    sh, lsi, value, loc, attn, go = case
+    out = MSDA.ms_deform_attn_forward(value.to(DEV), sh.to(DEV), lsi.to(DEV), loc.to(DEV), attn.to(DEV), 64)
+    torch.cuda.synchronize()
+    want = O.msda_forward(value.double().numpy(), sh.numpy(), lsi.numpy(), loc.double().numpy(), attn.double().numpy(), nthreads=8)
+    np.testing.assert_allclose(out.double().cpu().numpy().reshape(want.shape), want, rtol=0, atol=4e-5 * scale(want))
+    check(run(case, 0), oracle(case), case, 4e-5)
