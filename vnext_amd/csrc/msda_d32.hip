@@ -77,8 +77,8 @@ __device__ __forceinline__ void store_row4<float>(float* p, float4_t v) {
 template <>
 __device__ __forceinline__ void store_row4<bf16_t>(bf16_t* p, float4_t v) {
   uint2_t r;
-  r.x = uint32_t(f32_to_bf16_bits(v.x)) | (uint32_t(f32_to_bf16_bits(v.y)) << 16);
-  r.y = uint32_t(f32_to_bf16_bits(v.z)) | (uint32_t(f32_to_bf16_bits(v.w)) << 16);
+  r.x = f32x2_to_bf16x2(v.x, v.y);
+  r.y = f32x2_to_bf16x2(v.z, v.w);
   __builtin_nontemporal_store(r, reinterpret_cast<uint2_t*>(p));
 }
 __device__ __forceinline__ uint32_t float_to_half_bits(float f) {
@@ -111,10 +111,7 @@ template <typename TV>
 __device__ __forceinline__ uint4_t pack8(float4_t lo, float4_t hi);
 template <>
 __device__ __forceinline__ uint4_t pack8<bf16_t>(float4_t lo, float4_t hi) {
-  return uint4_t{uint32_t(f32_to_bf16_bits(lo.x)) | (uint32_t(f32_to_bf16_bits(lo.y)) << 16),
-                 uint32_t(f32_to_bf16_bits(lo.z)) | (uint32_t(f32_to_bf16_bits(lo.w)) << 16),
-                 uint32_t(f32_to_bf16_bits(hi.x)) | (uint32_t(f32_to_bf16_bits(hi.y)) << 16),
-                 uint32_t(f32_to_bf16_bits(hi.z)) | (uint32_t(f32_to_bf16_bits(hi.w)) << 16)};
+  return uint4_t{f32x2_to_bf16x2(lo.x, lo.y), f32x2_to_bf16x2(lo.z, lo.w), f32x2_to_bf16x2(hi.x, hi.y), f32x2_to_bf16x2(hi.z, hi.w)};
 }
 template <>
 __device__ __forceinline__ uint4_t pack8<f16_t>(float4_t lo, float4_t hi) {

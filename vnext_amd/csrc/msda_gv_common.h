@@ -39,8 +39,8 @@ template <> __device__ __forceinline__ void store4<float>(float* p, float4_t v) 
 }
 template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, float4_t v) {
   uint2_t r;
-  r.x = uint32_t(f32_to_bf16_bits(v.x)) | (uint32_t(f32_to_bf16_bits(v.y)) << 16);
-  r.y = uint32_t(f32_to_bf16_bits(v.z)) | (uint32_t(f32_to_bf16_bits(v.w)) << 16);
+  r.x = f32x2_to_bf16x2(v.x, v.y);
+  r.y = f32x2_to_bf16x2(v.z, v.w);
 #if defined(VNX_GV_STORE16_PLAIN) || (defined(VNX_GV_PAIR16) && !defined(VNX_GV_PAIR16_NT))      // A/B builds (tools/r3_call23.sh, r3_call33.sh)
   *reinterpret_cast<uint2_t*>(p) = r;
 #else

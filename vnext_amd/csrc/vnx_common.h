@@ -26,13 +26,16 @@ __device__ __forceinline__ double to_acc(double x) { return x; }
 __device__ __forceinline__ float to_acc(bf16_t x) { return __uint_as_float(uint32_t(x.bits) << 16); }
 __device__ __forceinline__ float to_acc(f16_t x) { return float(x.v); }
 
-// round-to-nearest-even fp32 -> bf16 (NaN kept quiet)
-__device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return uint16_t((u >> 16) | 0x40u);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return uint16_t(u >> 16);
+// fp32 -> bf16, round to nearest even: gfx950 has the instruction (v_cvt_pk_bf16_f32, two values per issue; the compiler
+// emits it for this vector conversion).  Until round 3 this was integer arithmetic -- ~6 instructions per value, a
+// third more vector instructions in the bf16 grad_value kernel than in the fp32 one (PMC: 14.1 M vs 11.0 M per launch at
+// decoder-720p), which is why 16-bit values were SLOWER there.
+typedef __bf16 vnx_bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float vnx_f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t f32x2_to_bf16x2(float lo, float hi) {       // lo in bits 0..15
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(vnx_f32x2_t{lo, hi}, vnx_bf16x2_t));
 }
+__device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) { return uint16_t(f32x2_to_bf16x2(f, 0.f)); }
 
 template <typename T> __device__ __forceinline__ T from_acc(acc_t<T> x);
 template <> __device__ __forceinline__ float from_acc<float>(float x) { return x; }
