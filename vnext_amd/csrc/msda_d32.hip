@@ -219,6 +219,14 @@ __device__ __forceinline__ void fused_decode(const TL* __restrict__ raw_off, con
 #ifndef VNX_K1_BATCH
 #define VNX_K1_BATCH 4
 #endif
+// tile boxes of the tile-fed grad_value path per WAVE (QPW = 4 queries on large calls) instead of per workgroup (16): a
+// tile's box is 4 + 12 pixels wide instead of 16 + 12, so fewer tiles meet a block (encoder backward, cold: 175.2 -> 169.1 us
+// at 360p, 654.8 -> 625.8 us at 720p B = 5), this kernel loses its LDS step, the grad_value kernel scans four times the
+// words (1 275 per level at 360p: two load rounds instead of one).  VNX_TILE_PER_WAVE=0: the per-workgroup form.
+#ifndef VNX_TILE_PER_WAVE
+#define VNX_TILE_PER_WAVE 1
+#endif
+constexpr bool kTilePerWave = VNX_TILE_PER_WAVE != 0;
 // fp32 rows of the grad_loc kernel as 4 lanes x 32 B (A/B macro: 0 = never, 1 = large-call configurations, 2 = all)
 #ifndef VNX_K1_F32_LPR4_MODE
 #define VNX_K1_F32_LPR4_MODE 0
@@ -917,14 +925,17 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
       tile_kx = pk_min_u16(tile_kx, uint32_t(__shfl_xor(int(tile_kx), 32, 64)));
       tile_ky = pk_min_u16(tile_ky, uint32_t(__shfl_xor(int(tile_ky), 32, 64)));
       if ((lane & 3) == 0 && lane < 16) {
-        if (WPB > 1) s_tile[wave * 4 + (lane >> 2)] = uint2_t{tile_kx, tile_ky};
+        if (kTilePerWave) {      // one box per WAVE (QPW queries): finer selection for the grad_value kernel, no LDS step here
+          const int wt = (tile - b * tiles_per_batch) * WPB + wave, wn = (d.Lq + QPW - 1) / QPW;
+          if (wt < wn) tile_words[((int64_t(b) * d.M + m) * d.L + (lane >> 2)) * wn + wt] = uint2_t{tile_kx, tile_ky};
+        } else if (WPB > 1) s_tile[wave * 4 + (lane >> 2)] = uint2_t{tile_kx, tile_ky};
         else tile_words[((int64_t(b) * d.M + m) * d.L + (lane >> 2)) * tiles_per_batch + (tile - b * tiles_per_batch)] = uint2_t{tile_kx, tile_ky};
       }
     }
   }
   if (WPB > 1) __syncthreads(); else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  if constexpr (LP_T == 16 && !ATOMICS && WPB > 1) {
+  if constexpr (LP_T == 16 && !ATOMICS && WPB > 1 && !kTilePerWave) {
     if (tile_summary != nullptr && threadIdx.x < 4) {
       uint2_t k = s_tile[threadIdx.x];
 #pragma unroll
@@ -1248,7 +1259,7 @@ static int launch_bwd(const void* value, const int64_t* shapes, const int64_t* l
 int msda_bwd_tile_queries(const MsdaDims& d, int variant) {
   // the grad_loc launcher's variant decoding: < 100 as is, 100..199 (grad_loc only, timing) minus 100, others automatic
   const FwdCfg c = pick_fwd_cfg(d, variant < 100 ? variant : (variant < 200 ? variant - 100 : 0));
-  return c.qpw * c.wpb;
+  return kTilePerWave ? c.qpw : c.qpw * c.wpb;
 }
 
 bool msda_d32_bwd_supported(int vdt, int ldt, const MsdaDims& d) {

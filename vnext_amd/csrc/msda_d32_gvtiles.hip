@@ -7,10 +7,11 @@
 // the first tap is applied.  At the decoder shape (300 scattered queries) that selection is what makes a unit cheap;
 // at the encoder shape it is a third of the kernel, and the records are 40 % of the backward's memory traffic.
 //
-// Here selection works on TILES of queries: a workgroup of the grad_loc kernel handles T consecutive queries (T = 16
-// on large calls) of one (batch, head), and consecutive queries of an encoder call are neighbouring pixels whose
-// samples land next to each other.  That workgroup reduces, per level, the bounding box of the pixels its samples'
-// corners touch and leaves TWO 4-byte words per (batch, head, level, tile): 319 word pairs per level at 360p where
+// Here selection works on TILES of queries: a wave of the grad_loc kernel handles T consecutive queries (T = 4
+// on large calls; until late in round 3 the tile was the workgroup's 16) of one (batch, head), and consecutive queries of
+// an encoder call are neighbouring pixels whose samples land next to each other.  That wave reduces, per level, the
+// bounding box of the pixels its samples' corners touch and leaves TWO 4-byte words per (batch, head, level, tile): 1 275
+// word pairs per level at 360p where
 // there were 20 400 tags.  A unit of this kernel -- a rectangle of <= 256 pixels of one level: a band of whole image
 // rows of a narrow level, a block of about 32 x 8 pixels of a wide one (gv_level_grid, vnx_common.h) --
 //   1. reads its level's tile words (one load round per 512 tiles), keeps the tiles whose box meets its rectangle
