@@ -139,9 +139,10 @@ struct FusedArgs {
 #ifndef VNX_QS_MID
 #define VNX_QS_MID 2
 #endif
-// batch_heads = B x M: with fewer than 32 (batch, head) pairs the grid leaves workgroup slots empty (25 units each
-// against 768 slots), and the middle levels are split further: 4 instead of 2 pieces -- encoder backward at B = 2:
-// 123 -> 109 us at 360p, 450 -> 412 us at 720p; at B = 5 (a full grid) 4 pieces measured 1-2 % slower than 2.
+// batch_heads = B x M: with fewer than 32 (batch, head) pairs the grid leaves workgroup slots empty, and the middle
+// levels are split further: 8 pieces instead of 2 (round 2: 4 -- encoder backward at B = 2 123 -> 109 us at 360p, 450 ->
+// 412 us at 720p; round 3, tile-fed path: 8 pieces 322 -> 288 us at 720p B = 2, 234 -> 192 us at B = 1, 360p unchanged; 16
+// pieces 326 us); at B = 5 (a full grid) 4 pieces measured slower than 2 (168.8 -> 191.7 us at 360p, 625 -> 637 us at 720p).
 // The unit split of a level of n pixels, the ONE definition shared by the grad_loc kernel (which zeroes the rows of
 // query-split levels and tags every sample with the units it touches), the grad_value kernels' level tables and the
 // launcher's grid bound: at most rows_max rows per unit (kGvRowsMax / kGvTileRowsMax by grad_value path), at least units_min units, then normalised so that no unit is
@@ -240,7 +241,7 @@ __host__ __device__ inline int gv_query_splits(int row_units, int Lq, int P, boo
   if (!f32 || P != 4 || row_units > 4 || Lq < 1024) return 1;
   const int chunks = (Lq + 127) / 128;
   const int qs = (chunks + 9) / 10;
-  const int mid = batch_heads < 32 ? 2 * VNX_QS_MID : VNX_QS_MID;
+  const int mid = batch_heads < 32 ? 4 * VNX_QS_MID : VNX_QS_MID;
   const int cap = row_units > 2 ? mid : VNX_QS_COARSE;   // middle levels: 3-4 row-units (960 pixels at 360p)
   return qs < 1 ? 1 : (qs > cap ? cap : qs);
 }
