@@ -141,6 +141,12 @@ msda_bwd_gv_tiles_kernel(const int64_t* __restrict__ shapes, const int64_t* __re
   const uint32_t s_stride = compact ? uint32_t(P) : uint32_t(d.M) * uint32_t(LP);
   const TV* go_head = grad_out + (int64_t(b) * d.Lq * d.M + m) * D;
   const uint32_t q_stride = uint32_t(d.M) * uint32_t(D);
+  // byte ranges of this batch element's slices (msda_d32_gvtiles_supported keeps them below 2^31)
+  constexpr uint32_t kOutOfRange = 0x80000000u;
+  const uint32_t n_samp = compact ? uint32_t(d.Lq) * P : uint32_t(d.Lq) * uint32_t(d.M) * uint32_t(LP);   // from s_base on, at most
+  const __amdgpu_buffer_rsrc_t loc_src = uniform_rsrc(loc_bm, n_samp * 2u * uint32_t(sizeof(TL)));
+  const __amdgpu_buffer_rsrc_t attn_src = uniform_rsrc(attn_bm, n_samp * uint32_t(sizeof(TL)));
+  const __amdgpu_buffer_rsrc_t go_src = uniform_rsrc(go_head, uint32_t(d.Lq) * uint32_t(d.M) * uint32_t(D) * uint32_t(sizeof(TV)));
   const float Hf = float(Hl), Wf = float(Wl);
   const int tile_mask = (1 << tile_shift) - 1;
   const int tpc_shift = 7 - tile_shift;              // tiles per chunk = 128 >> tile_shift
@@ -204,19 +210,29 @@ msda_bwd_gv_tiles_kernel(const int64_t* __restrict__ shapes, const int64_t* __re
       const int q = ((win0 + int(hit[ht])) << tile_shift) + (s & tile_mask);
       return q < d.Lq ? q : -1;
     };
+    // Through buffer descriptors with 32-bit byte offsets (a slot without a query reads out of range = zeros, no branch):
+    // the global_load form spent 28 of the chunk's ~200 vector instructions on 64-bit address arithmetic.
     auto prefetch = [&](int c) {
       const int tq = opaque(tid);
       const int q = slot_query(c, tq >> 2);
       nvalid = q >= 0;
-      if (nvalid) {
-        const uint32_t si = __umul24(uint32_t(q), s_stride) + uint32_t(tq & 3);
-        nx = to_acc(loc_bm[2 * si]); ny = to_acc(loc_bm[2 * si + 1]);
-        na = to_acc(attn_bm[si]);
+      const uint32_t si = nvalid ? __umul24(uint32_t(q), s_stride) + uint32_t(tq & 3) : kOutOfRange;
+      if constexpr (sizeof(TL) == 4) {
+        const uint2_t xy = __builtin_bit_cast(uint2_t, __builtin_amdgcn_raw_buffer_load_b64(loc_src, int(si * 8u), 0, 0));
+        nx = __uint_as_float(xy.x); ny = __uint_as_float(xy.y);
+        na = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(attn_src, int(si * 4u), 0, 0));
+      } else {
+        const uint32_t xy = __builtin_amdgcn_raw_buffer_load_b32(loc_src, int(si * 4u), 0, 0);
+        const uint32_t a16 = __builtin_amdgcn_raw_buffer_load_b16(attn_src, int(si * 2u), 0, 0);
+        nx = to_acc(__builtin_bit_cast(TL, uint16_t(xy & 0xffffu))); ny = to_acc(__builtin_bit_cast(TL, uint16_t(xy >> 16)));
+        na = to_acc(__builtin_bit_cast(TL, uint16_t(a16)));
       }
       const int g0 = opaque(tid), g1 = g0 + kThreads;
       const int qa = slot_query(c, g0 >> 3), qb = slot_query(c, g1 >> 3);
-      if (qa >= 0) pg0 = load4<TV>(go_head + __umul24(uint32_t(qa), q_stride) + (g0 & 7) * 4);
-      if (qb >= 0) pg1 = load4<TV>(go_head + __umul24(uint32_t(qb), q_stride) + (g1 & 7) * 4);
+      const uint32_t oa = qa >= 0 ? (__umul24(uint32_t(qa), q_stride) + uint32_t(g0 & 7) * 4u) * uint32_t(sizeof(TV)) : kOutOfRange;
+      const uint32_t ob = qb >= 0 ? (__umul24(uint32_t(qb), q_stride) + uint32_t(g1 & 7) * 4u) * uint32_t(sizeof(TV)) : kOutOfRange;
+      pg0 = load4_buf<TV>(go_src, oa);
+      pg1 = load4_buf<TV>(go_src, ob);
     };
     prefetch(0);
     for (int c = 0; c < n_chunks; ++c, ++gchunk) {
@@ -365,6 +381,8 @@ bool msda_d32_gvtiles_supported(int vdt, int ldt, const MsdaDims& d) {
   // 24-bit stride multiplies: query index, heads x channels and heads x samples below 2^24; element offsets below 2^32
   if (d.Lq >= (1 << 24) || d.M * 32 >= (1 << 24) || d.M * d.L * 4 >= (1 << 24)) return false;
   if (int64_t(d.Lq) * d.M * 32 >= (int64_t(1) << 32) || int64_t(d.Lq) * d.M * d.L * 8 >= (int64_t(1) << 32)) return false;
+  // byte offsets into one batch element's locations (8 B per sample) and grad_out rows: 32-bit buffer offsets below 2^31
+  if (int64_t(d.Lq) * d.M * d.L * d.P * 8 >= (int64_t(1) << 31) || int64_t(d.Lq) * d.M * 32 * 4 >= (int64_t(1) << 31)) return false;
   const int64_t blocks = int64_t(d.B) * d.M * msda_gvtiles_units_bound(d, 16);
   return blocks < (int64_t(1) << 31);
 }

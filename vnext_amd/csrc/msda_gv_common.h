@@ -31,6 +31,27 @@ template <> __device__ __forceinline__ float4_t load4<f16_t>(const f16_t* p) {
   v.w = float(__builtin_bit_cast(_Float16, uint16_t(r.y >> 16)));
   return v;
 }
+// four channels of a row through a buffer descriptor (byte offset; out of range reads zeros)
+template <typename TV> __device__ __forceinline__ float4_t load4_buf(__amdgpu_buffer_rsrc_t src, uint32_t byte_off);
+template <> __device__ __forceinline__ float4_t load4_buf<float>(__amdgpu_buffer_rsrc_t src, uint32_t byte_off) {
+  return __builtin_bit_cast(float4_t, __builtin_amdgcn_raw_buffer_load_b128(src, int(byte_off), 0, 0));
+}
+template <> __device__ __forceinline__ float4_t load4_buf<bf16_t>(__amdgpu_buffer_rsrc_t src, uint32_t byte_off) {
+  const uint2_t r = __builtin_bit_cast(uint2_t, __builtin_amdgcn_raw_buffer_load_b64(src, int(byte_off), 0, 0));
+  float4_t v;
+  v.x = __uint_as_float(r.x << 16); v.y = __uint_as_float(r.x & 0xffff0000u);
+  v.z = __uint_as_float(r.y << 16); v.w = __uint_as_float(r.y & 0xffff0000u);
+  return v;
+}
+template <> __device__ __forceinline__ float4_t load4_buf<f16_t>(__amdgpu_buffer_rsrc_t src, uint32_t byte_off) {
+  const uint2_t r = __builtin_bit_cast(uint2_t, __builtin_amdgcn_raw_buffer_load_b64(src, int(byte_off), 0, 0));
+  float4_t v;
+  v.x = float(__builtin_bit_cast(_Float16, uint16_t(r.x & 0xffffu)));
+  v.y = float(__builtin_bit_cast(_Float16, uint16_t(r.x >> 16)));
+  v.z = float(__builtin_bit_cast(_Float16, uint16_t(r.y & 0xffffu)));
+  v.w = float(__builtin_bit_cast(_Float16, uint16_t(r.y >> 16)));
+  return v;
+}
 template <typename TV> __device__ __forceinline__ void store4(TV* p, float4_t v);
 template <> __device__ __forceinline__ void store4<float>(float* p, float4_t v) {
   // grad_value is written once and read by another kernel much later: `nt` (decoder-360p backward 33.8 -> 31.4 us)
