@@ -273,6 +273,7 @@ msda_fwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int LP = LP_T > 0 ? LP_T : d.L * d.P;
+  const int p_shift = __builtin_ctz(uint32_t(d.P) | 0x10000u);      // log2(P) when P is a power of two (L * P == 16)
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int head_rot = (prefetch_rows >> 16) & 0xf;   // A/B record (variants 61..68): which head runs on which XCD
@@ -349,7 +350,7 @@ msda_fwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
     const int q = q0 + qi;
     uint4_t o4 = {kTapOutside, kTapOutside, kTapOutside, kTapOutside};
     float4_t w4 = {0.f, 0.f, 0.f, 0.f};
-    const int l = p / d.P;
+    const int l = LP_T == 16 ? (p >> p_shift) : p / d.P;       // L * P == 16: P is a power of two
     const int64_t wi = ((int64_t(b) * d.Lq + q) * d.M + m) * LP + p;
     float x = 0.f, y = 0.f, a = 0.f;
     if constexpr (FUSED) {
@@ -397,11 +398,14 @@ msda_fwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
         const float lh = h - hf, lw = w - wf, hh = 1.f - lh, hw = 1.f - lw;
         const bool top = h0 >= 0, bot = h0 + 1 <= H - 1, lef = w0 >= 0, rig = w0 + 1 <= W - 1;
         const uint32_t pb = uint32_t(pixel_bytes);
-        const uint32_t o00 = uint32_t(start + h0 * W + w0) * pb;  // mod 2^32 on purpose
+        // 24-bit multiplies (full rate; v_mul_lo_u32 issues at a quarter of it): level sides and the pixel index stay
+        // below 2^23 (msda_d32_fwd_supported), the low 32 bits of the signed 48-bit product are the value mod 2^32
+        const uint32_t o00 = uint32_t(__mul24(start + __mul24(h0, W) + w0, int(pb)));  // mod 2^32 on purpose
+        const uint32_t row_b = __umul24(uint32_t(W), pb);
         o4.x = (top && lef) ? o00 : kTapOutside;
         o4.y = (top && rig) ? o00 + pb : kTapOutside;
-        o4.z = (bot && lef) ? o00 + uint32_t(W) * pb : kTapOutside;
-        o4.w = (bot && rig) ? o00 + uint32_t(W + 1) * pb : kTapOutside;
+        o4.z = (bot && lef) ? o00 + row_b : kTapOutside;
+        o4.w = (bot && rig) ? o00 + row_b + pb : kTapOutside;
         w4.x = a * (hh * hw); w4.y = a * (hh * lw); w4.z = a * (lh * hw); w4.w = a * (lh * lw);
       }
     }
@@ -638,6 +642,7 @@ bool msda_d32_fwd_supported(int vdt, int ldt, const MsdaDims& d) {
   const int LP = d.L * d.P;
   if (LP > 64) return false;                                    // LDS record budget per wave
   if (int64_t(d.S) * d.M * 32 * elem_size(vdt) >= (int64_t(1) << 31)) return false;  // descriptor range
+  if (d.S >= (1 << 23) || d.M * 128 >= (1 << 23)) return false;                        // 24-bit index multiplies
   return true;
 }
 
@@ -786,6 +791,7 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int LP = LP_T > 0 ? LP_T : d.L * d.P;
+  const int p_shift = __builtin_ctz(uint32_t(d.P) | 0x10000u);      // log2(P) when P is a power of two (L * P == 16)
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int tile = blockIdx.x / d.M;
@@ -832,7 +838,7 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
     const int q = q0 + qi;
     uint4_t o4 = {kTapOutsideElem, kTapOutsideElem, kTapOutsideElem, kTapOutsideElem};
     float4_t g4 = {0.f, 0.f, 0.f, 0.f};
-    const int l = p / d.P;
+    const int l = LP_T == 16 ? (p >> p_shift) : p / d.P;       // L * P == 16: P is a power of two
     const int64_t wi = ((int64_t(b) * d.Lq + q) * d.M + m) * LP + p;
     float x = 0.f, y = 0.f, a = 0.f;
     if constexpr (FUSED) {
@@ -866,11 +872,12 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
         const bool top = h0 >= 0, bot = h0 + 1 <= H - 1, lef = w0 >= 0, rig = w0 + 1 <= W - 1;
         // element (not byte) offsets: the same record addresses `value` (x sizeof(TV))
         // and the fp32 gradient image (x 4)
-        const uint32_t o00 = uint32_t(start + h0 * W + w0) * pixel_elems;  // mod 2^32 on purpose
+        const uint32_t o00 = uint32_t(__mul24(start + __mul24(h0, W) + w0, int(pixel_elems)));  // mod 2^32 on purpose (24-bit multiplies: see the forward)
+        const uint32_t row_e = __umul24(uint32_t(W), pixel_elems);
         o4.x = (top && lef) ? o00 : kTapOutsideElem;
         o4.y = (top && rig) ? o00 + pixel_elems : kTapOutsideElem;
-        o4.z = (bot && lef) ? o00 + uint32_t(W) * pixel_elems : kTapOutsideElem;
-        o4.w = (bot && rig) ? o00 + uint32_t(W + 1) * pixel_elems : kTapOutsideElem;
+        o4.z = (bot && lef) ? o00 + row_e : kTapOutsideElem;
+        o4.w = (bot && rig) ? o00 + row_e + pixel_elems : kTapOutsideElem;
         g4.x = h - hf; g4.y = w - wf; g4.z = a;
         record = uint4_t{gv_pack_corner(h0, w0, H, W), __float_as_uint(g4.x),
                          __float_as_uint(g4.y), __float_as_uint(a)};
@@ -1146,7 +1153,7 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
     const int qi3 = e / LP, p = e - qi3 * LP;
     const int q3 = q0 + qi3;
     if (q3 < d.Lq) {
-      const int l = p / d.P;
+      const int l = LP_T == 16 ? (p >> p_shift) : p / d.P;       // L * P == 16: P is a power of two
       const int64_t wi = ((int64_t(b) * d.Lq + q3) * d.M + m) * LP + p;
       float4_t r = s_res[qi3 * (LP + 1) + p];
       if constexpr (LP_T > 0 && !ATOMICS) {   // the four dots of phase 2 -> (grad_w, grad_h, grad_attn), see there
