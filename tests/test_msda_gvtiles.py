@@ -287,3 +287,25 @@ def test_random_pyramids_forward_and_decoder_backward(seed):
     want = O.msda_forward(value.double().numpy(), sh.numpy(), lsi.numpy(), loc.double().numpy(), attn.double().numpy(), nthreads=8)
     np.testing.assert_allclose(out.double().cpu().numpy().reshape(want.shape), want, rtol=0, atol=4e-5 * scale(want))
     check(run(case, 0), oracle(case), case, 4e-5)
+
+
+@pytest.mark.parametrize("vdt", [torch.float32, torch.bfloat16])
+def test_tile_path_backward_in_a_graph(vdt):
+    """no allocation / synchronisation inside the call (workspace from the caller): the backward of a many-query call
+    (grad_loc kernel, tile-fed grad_value kernel, split-level convert for 16-bit values) replays from a hipGraph"""
+    sh, lsi, value, loc, attn, go = pixel_queries(PYR, 2, 1275, seed=41)
+    args = (value.to(DEV, vdt), sh.to(DEV), lsi.to(DEV), loc.to(DEV), attn.to(DEV), go.to(DEV, vdt), 64)
+    expect = [t.clone() for t in MSDA.ms_deform_attn_backward(*args)]
+    torch.cuda.synchronize()
+    static = [torch.empty_like(t) for t in expect]
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for dst, src in zip(static, MSDA.ms_deform_attn_backward(*args)):
+            dst.copy_(src)
+    for t in static:
+        t.fill_(float("nan"))
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(static[1], expect[1]) and torch.equal(static[2], expect[2])
+    tol = 2e-6 if vdt == torch.float32 else 1e-2
+    assert float((static[0].float() - expect[0].float()).abs().max()) <= tol * float(expect[0].float().abs().max())
