@@ -850,8 +850,13 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
     }
     if (q < d.Lq) {
       if constexpr (!FUSED) {
-        x = to_acc(loc[2 * wi]); y = to_acc(loc[2 * wi + 1]);
-        a = to_acc(attn[wi]);
+        if constexpr (WPB == 1 && sizeof(TL) == 4) {     // small-call configuration: `nt` loads as in the forward (headline
+          x = to_acc(nt_load(loc + 2 * wi)); y = to_acc(nt_load(loc + 2 * wi + 1));      // backward 27.3 -> 27.1 us)
+          a = to_acc(nt_load(attn + wi));
+        } else {
+          x = to_acc(loc[2 * wi]); y = to_acc(loc[2 * wi + 1]);
+          a = to_acc(attn[wi]);
+        }
       }
       if constexpr (LP_T == 16 && !ATOMICS) {
         if (fa.tile_loc != nullptr) {      // what the tile-fed grad_value kernel decodes again (fp32: the same bits), laid out
