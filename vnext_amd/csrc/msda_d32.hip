@@ -1060,6 +1060,7 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
 
   float4_t top = {0.f, 0.f, 0.f, 0.f};
   if constexpr (LPR == 8) {
+    // (`nt` for this row, read once: 27.5-27.8 vs 27.2-27.5 us per headline backward -- not kept)
     if (q < d.Lq) top = load_row4<TV>(grad_out + ((int64_t(b) * d.Lq + q) * d.M + m) * D + ch * 4);
   }
 

@@ -330,7 +330,7 @@ constexpr size_t kSelLdsBytes = size_t(kQcMax) * 128 + size_t(kThreads) * 32 + s
                                 4 * kLevelsMax * 4 + size_t(kWin) * 4 + size_t(kWinQueries) * 2 +
                                 size_t(kSelParts) * 16 + 64;
 
-template <typename TV>
+template <typename TV, bool NT>
 __global__ void __launch_bounds__(kThreads, VNX_SEL_UNITS_PER_CU * kWaves / 4)
 msda_bwd_gv_sel_kernel(const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
                        const uint4_t* __restrict__ records, const uint32_t* __restrict__ unit_ids,
@@ -463,7 +463,10 @@ msda_bwd_gv_sel_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
 #pragma unroll
     for (int r = 0; r < kSelRounds; ++r) {
       const int sidx = r * kThreads + tw;
-      const uint32_t v = sidx < n_w ? my_uids[win0 + sidx] : 0xffffffffu;
+      // NT: tags and records through `nt` loads when the whole grid is resident at once (the headline decoder call: 760
+      // workgroups): every unit reads them at the same moment, once, on its own CU -- headline backward 27.3 -> 26.8 us.  On
+      // grids of several rounds (decoder-720p, B = 10) the later units then miss in L2: 45 -> 52 us; plain loads there.
+      const uint32_t v = sidx < n_w ? (NT ? __builtin_nontemporal_load(my_uids + win0 + sidx) : my_uids[win0 + sidx]) : 0xffffffffu;
       const bool hit = int(v & 0xffffu) <= u_lvl && u_lvl <= int(v >> 16) && v != 0xffffffffu;
       const unsigned long long bh = __ballot(hit);
       const uint32_t quad = uint32_t(bh >> (tw & 60)) & 0xfu;          // my query's four samples
@@ -517,7 +520,7 @@ msda_bwd_gv_sel_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
     auto prefetch = [&](int c) {
       const int i = int(cs[c]) + tid;
       if (i < int(cs[c + 1])) {
-        next = my_recs[win0 + int(sel_id[i])];
+        next = NT ? __builtin_nontemporal_load(my_recs + win0 + int(sel_id[i])) : my_recs[win0 + int(sel_id[i])];
         next_slot = int(sel_qr[i]) - c * kQcMax;
       } else {
         next = none;
@@ -680,9 +683,15 @@ static int launch_gvrec(const int64_t* shapes, const int64_t* lsi, const void* r
   const int64_t blocks = ((int64_t(d.B) * units_bound + 1) & ~int64_t(1)) * d.M;     // (unit, batch) pairs: even (gv_decode_block)
   if (mode == 0 && d.P == 4 && d.L <= rec::kLevelsMax) {
     const uint32_t* unit_ids = reinterpret_cast<const uint32_t*>((const char*)records + gv_unit_ids_offset(d));
-    hipLaunchKernelGGL((rec::msda_bwd_gv_sel_kernel<TV>), dim3(uint32_t(blocks)), dim3(rec::kThreads),
-                       rec::kSelLdsBytes, stream, shapes, lsi, (const rec::uint4_t*)records, unit_ids,
-                       (const TV*)grad_out, (TV*)grad_value, d, units_min, split_image, debug);
+    // one round of resident workgroups (3 per CU x 256 CUs = 768; the bound counts ~1.5x the real units)?
+    if (blocks <= 1200)
+      hipLaunchKernelGGL((rec::msda_bwd_gv_sel_kernel<TV, true>), dim3(uint32_t(blocks)), dim3(rec::kThreads),
+                         rec::kSelLdsBytes, stream, shapes, lsi, (const rec::uint4_t*)records, unit_ids,
+                         (const TV*)grad_out, (TV*)grad_value, d, units_min, split_image, debug);
+    else
+      hipLaunchKernelGGL((rec::msda_bwd_gv_sel_kernel<TV, false>), dim3(uint32_t(blocks)), dim3(rec::kThreads),
+                         rec::kSelLdsBytes, stream, shapes, lsi, (const rec::uint4_t*)records, unit_ids,
+                         (const TV*)grad_out, (TV*)grad_value, d, units_min, split_image, debug);
     return check_launch("msda_bwd_gv_sel");
   }
 #define VNX_LAUNCH(PT, RS)                                                                             \
