@@ -41,8 +41,12 @@ template <typename TV>
 __device__ __forceinline__ float4_t load_tap(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off);
 
 template <>
+#ifndef VNX_TAP_AUX      // cache policy of the fp32 row gathers (A/B: 1 = sc0, 2 = nt, 16 = sc1; 0 = default).  Measured, forward, cold:
+                         // headline 8.6 / 8.9 / 10.9 / 9.0 us for default / sc0 / nt / sc1, encoder-360p 54.2 / 54.3 / 87.4 / 58.3 us
+#define VNX_TAP_AUX 0
+#endif
 __device__ __forceinline__ float4_t load_tap<float>(__amdgpu_buffer_rsrc_t rsrc, uint32_t off) {
-  uint4_t r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, int(off), 0, 0);
+  uint4_t r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, int(off), 0, VNX_TAP_AUX);
   float4_t v;
   v.x = __uint_as_float(r.x); v.y = __uint_as_float(r.y);
   v.z = __uint_as_float(r.z); v.w = __uint_as_float(r.w);
