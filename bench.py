@@ -817,7 +817,8 @@ def main():
     if world > 1:
         import torch.distributed as dist
         from vnext_amd.train import set_rank_affinity
-        affinity = set_rank_affinity(local_rank, world)     # this rank's host threads next to its GPU
+        # the ranks of THIS node share its cores (torchrun's LOCAL_WORLD_SIZE), not the whole job's
+        affinity = set_rank_affinity(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
         dist.init_process_group("nccl", device_id=device)
     n_gpus = world if world > 1 else 1
 
@@ -865,6 +866,13 @@ def main():
     if rank == 0:
         if model_leg is not None:
             line["model_step"] = model_leg
+            # the second half of BASELINE.json's metric ("clips/s at 1/2/4/8 GPU") and what bounds its scaling, as
+            # top-level keys (details stay in `model_step`): whole-job clips/s of the SeqFormer-R50 training step at
+            # this N, and the part of the RCCL gradient all-reduce no overlap with the backward can hide
+            line["clips_per_s"] = model_leg["clips_per_s"]
+            line["clips_per_s_config"] = "SeqFormer-R50 T=5 360p training step, %d clips per GPU, fp32, DDP over RCCL" % model_leg["clips_per_rank"]
+            comm = model_leg.get("ddp_comm")
+            line["exposed_allreduce_ms"] = comm.get("exposed_allreduce_ms") if isinstance(comm, dict) else None
             if world == 1:
                 line["other_configs"] = extra_model_legs(device)
         # ---- per-kernel rooflines, measured live --------------------------------------------
@@ -975,6 +983,13 @@ def main():
         line["fwd_gpoints_per_s"] = points / us_fwd / 1e3
         if not a.no_cases and world == 1:
             line["op_cases"] = op_case_rooflines(op, device)
+            # the same floor as `roofline.floor_us` for the other decoder-shape forwards (B = 10 is the reference's
+            # per-GPU batch: two clips x five frames): one memory latency + the case's bytes at this run's gather rate
+            for key, c in line["op_cases"].items():
+                if key.startswith("decoder_") and c["value_dtype"] == "f32":
+                    fl = lat_us + c["fwd"]["nominal_bytes"] / ceil["cold_384MiB"]["GBs"] / 1e3
+                    c["fwd"]["floor_us"] = fl
+                    c["fwd"]["floor_frac"] = c["fwd"]["nominal_bytes"] / fl / 1e3 / HBM_PEAK_GBS
             line.update({"roofline_" + k: v for k, v in head_rooflines(device).items()})
         if not a.no_cpu and world == 1:     # the CPU leg runs at N = 1 only
             line["cpu_baseline"] = cpu_baseline(B, Lq, res)

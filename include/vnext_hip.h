@@ -100,7 +100,9 @@ enum {
  * Bytes of scratch vnx_msda_backward needs for these sizes and flags (and the current
  * kernel variant).  32-channel heads: what the grad_loc kernel hands the grad_value
  * kernel -- 20 B per sample (records + unit tags) below 1 024 queries, 8 B per (batch,
- * head, level, 16-query tile) from there on -- plus an fp32 [B, S, M, 32] image of
+ * head, level, query tile) from there on, a tile being the queries one wave of the
+ * grad_loc kernel handles (4 on calls of up to 262 144 query rows, 8 beyond) -- size the
+ * scratch with this function, not by hand -- plus an fp32 [B, S, M, 32] image of
  * grad_value for 16-bit values unless the levels are promised packed AND there are
  * fewer than 1 024 queries (the general path / the query-split levels accumulate with
  * fp32 atomics).  Other head widths: that image for 16-bit values, else 0.
@@ -316,13 +318,8 @@ int vnx_add_dropout_layernorm_backward(int dtype, const void* grad_y, const void
                                        void* partial, long long rows, int channels, float p, unsigned long long seed,
                                        const unsigned long long* seed_device, void* hip_stream);
 
-/*
- * Kernel selection override for A/B measurements and tests (process-wide):
- *   0 = automatic (default), 1 = force the generic kernels,
- *   >= 2 = implementation-defined tuned variants.
- */
-void vnx_set_kernel_variant(int variant);
-int vnx_get_kernel_variant(void);
+/* (The kernel-variant override of rounds 1-3 -- a process-wide A/B knob -- is no longer part of this library: it lives in
+ *  the development build only, include/vnext_hip_dev.h.  Every call here selects its kernels from its own arguments.) */
 
 #ifdef __cplusplus
 }

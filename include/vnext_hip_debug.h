@@ -24,10 +24,6 @@ extern "C" {
 void vnx_debug_arm_stamps(void* buf, long long n_words);
 int vnx_debug_stamp_regions(int* kinds, long long* offsets, long long* blocks, int n);
 int vnx_debug_wall_clock_khz(void);
-/* phase stamps of the grad_value kernel (variants 408 / 412) and of the tiled forward (701 / 702): copies
- * n 64-bit words of the kernel's fixed device array to `host`; returns a hipError_t as int */
-int vnx_debug_read_rec_stamps(unsigned long long* host, int n);
-int vnx_debug_read_tile_stamps(unsigned long long* host, int n);
 
 /*
  * Random row gather: the ceiling of the MSDA forward's access pattern on this memory system.  Reads

@@ -22,7 +22,7 @@ def run_bench(*args, env_extra=None):
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize("n", [1, 2])
+@pytest.mark.parametrize("n", [1, 2, 8])
 def test_gpus_flag_starts_that_many_ranks(n):
     line = run_bench("--gpus", str(n), "--backend", "gloo", "--stub-op", "--steps", "3", "--warmup", "1")
     assert line["n_gpus"] == n
@@ -37,3 +37,26 @@ def test_world_size_mismatch_is_refused():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--stub-op"], capture_output=True,
                        text=True, timeout=300, env=env, cwd=ROOT)
     assert p.returncode != 0 and "WORLD_SIZE=2" in (p.stderr + p.stdout)
+
+
+def test_the_drivers_own_eight_rank_command():
+    """The command the driver runs for the scaling record, verbatim (`python -m torch.distributed.run --nnodes=1
+    --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 --steps K --warmup W`), on gloo with the
+    CPU stub op: eight ranks rendezvous, rank 0 prints ONE line with n_gpus = world size = 8 (VERDICT r3 item 9;
+    reference: detectron2/engine/launch.py:67-126)."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "8", "--steps", "4", "--warmup", "1", "--backend", "gloo", "--stub-op"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == line["rccl_world_size"] == 8 and line["steps"] == 4 and line["warmup"] == 1
+    assert line["scaling"] == "weak" and line["config"]["parallelism"].startswith("dp8")

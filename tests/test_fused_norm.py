@@ -149,6 +149,57 @@ def test_captured_training_replays_draw_fresh_masks_and_backward_follows():
 
 
 @pytest.mark.gpu
+def test_a_second_scope_entry_before_the_backward_does_not_change_the_mask_under_it():
+    """the backward used to read the step-seed word as it stood when the BACKWARD ran; a second `step_scope`
+    entry between a forward and its backward (two trunk forwards, one backward) bumped it and the backward silently
+    recomputed another mask.  Every scope entry now leaves a snapshot that its sites' forward and backward both read."""
+    from vnext_amd.ops.fused_norm import step_scope
+    p = 0.25
+    drop, norm = _modules(p)
+    norm = norm.to(DEV)
+    with torch.no_grad():
+        norm.weight.fill_(1.0); norm.bias.zero_()
+    rows = 256
+    g = torch.Generator().manual_seed(9)
+    x = torch.zeros(rows, 256, device=DEV)
+    r = (torch.rand(rows, 256, generator=g) + 0.5).to(DEV)
+    go = torch.randn(rows, 256, generator=g).to(DEV)
+    r1, r2 = r.clone().requires_grad_(True), r.clone().requires_grad_(True)
+    ys = [torch.empty_like(x), torch.empty_like(x)]
+
+    def step():
+        r1.grad = r2.grad = None
+        with step_scope(DEV):
+            y1 = add_dropout_norm(x, r1, drop, norm)
+        with step_scope(DEV):                       # bumps the step seed again before y1's backward has run
+            y2 = add_dropout_norm(x, r2, drop, norm)
+        ((y1 + y2) * go).sum().backward()
+        ys[0].copy_(y1.detach()); ys[1].copy_(y2.detach())
+
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(2):
+            step()                                   # eager warm-up: creates the step seed outside the capture
+    torch.cuda.current_stream().wait_stream(s)
+    r1.grad = r2.grad = None
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step()
+    seen = []
+    for _ in range(2):
+        graph.replay()
+        torch.cuda.synchronize()
+        for y, rr in zip(ys, (r1, r2)):
+            kept = rr.grad != 0                      # the mask the BACKWARD used
+            z = torch.where(kept, r / (1 - p), torch.zeros_like(r))
+            torch.testing.assert_close(y, torch.nn.functional.layer_norm(z, (256,)), rtol=0, atol=3e-5)   # = the forward's
+            seen.append(kept.clone())
+    assert not torch.equal(seen[0], seen[1])         # the two sites of one replay drew different masks
+    assert not torch.equal(seen[0], seen[2])         # and so did the two replays
+
+
+@pytest.mark.gpu
 def test_capture_without_a_step_scope_falls_back_to_the_graph_safe_expression():
     p = 0.25
     drop, norm = _modules(p)

@@ -195,3 +195,35 @@ def test_backward_at_the_training_shape_of_a_360p_clip():
     _close(w.grad[order].double().cpu().numpy(), op, 3e-5)
     one = H.dynamic_mask_head(feats.double().numpy(), pts[order].double().numpy(), params[order].double().numpy(), counts)
     _close(out[order].double().detach().cpu().numpy(), one, 2e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shift", [1, 2, 3])
+def test_backward_accepts_a_4_byte_aligned_grad_feats_pointer(shift):
+    """the zero-fill launch of the backward wrote grad_feats with 16-byte stores on the strength of "it comes
+    from the allocator".  The C ABI takes any caller's pointer: a view with a storage offset is only 4-byte aligned.
+    Through the C ABI with grad_feats `shift` floats into a buffer: same gradients, nothing written outside the view."""
+    from vnext_amd import _lib
+    gen = torch.Generator().manual_seed(31 + shift)
+    counts, H_, W_ = [3, 2], 9, 21
+    n_all = sum(counts)
+    feats = torch.randn(len(counts), 8, H_, W_, generator=gen).cuda()
+    ref = (torch.rand(n_all, 2, generator=gen) * torch.tensor([W_ * 8.0, H_ * 8.0])).cuda()
+    params = (0.3 * torch.randn(n_all, 169, generator=gen)).cuda()
+    gout = torch.randn(n_all, 2 * H_, 2 * W_, generator=gen).cuda()
+    image = torch.repeat_interleave(torch.arange(len(counts), dtype=torch.int32), torch.tensor(counts)).cuda()
+    guard = 7.0
+    buf = torch.full((feats.numel() + 8,), guard, device="cuda:0")
+    gfeats = buf[shift:shift + feats.numel()]
+    assert gfeats.data_ptr() % 16 == 4 * shift
+    gref, gparams = torch.empty_like(ref), torch.empty_like(params)
+    _lib.check(_lib.lib().vnx_dynamic_mask_head_backward(
+        _lib.VNX_F32, feats.data_ptr(), ref.data_ptr(), params.data_ptr(), image.data_ptr(), gout.data_ptr(),
+        gfeats.data_ptr(), gref.data_ptr(), gparams.data_ptr(), len(counts), 8, H_, W_, n_all, 169, 8,
+        torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    of, orf, op = H.dynamic_mask_head_backward(feats.double().cpu().numpy(), ref.double().cpu().numpy(),
+                                               params.double().cpu().numpy(), counts, gout.double().cpu().numpy())
+    _close(gfeats.double().cpu().numpy().reshape(of.shape), of, 2e-5)
+    _close(gparams.double().cpu().numpy(), op, 2e-5)
+    assert bool((buf[:shift] == guard).all()) and bool((buf[shift + feats.numel():] == guard).all())

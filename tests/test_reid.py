@@ -111,10 +111,13 @@ def test_batched_loss_matches_reference_loss_reid():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,k", [(1, 1), (50, 50), (7, 300), (110, 111), (111, 111), (300, 300)])
+@pytest.mark.parametrize("n,k", [(1, 1), (50, 50), (7, 300), (110, 111), (111, 111), (300, 300),
+                                 (6, 2048), (5, 2048), (3, 4096), (2, 4096), (2048, 6)])
 def test_bisoftmax_staged_and_global_forms(n, k):
     """vnx_reid_bisoftmax (tracker.py:232-235: the mean of the row softmax and the column softmax) on both sides of the
-    12 288-element limit below which the matrix is staged in LDS, against float64 softmaxes."""
+    12 288-element limit below which the matrix is staged in LDS, against float64 softmaxes.  The few-rows x full-memory-
+    bank shapes (k = DeviceTracker capacity) pass the element limit but would need more than 64 KiB of dynamic LDS in the
+    staged form (6 x 2 048: 65 584 B): they must take the global-memory form instead of failing to launch."""
     from vnext_amd.heads.reid import bisoftmax
     g = torch.Generator().manual_seed(n * 1000 + k)
     s = 3.0 * torch.randn(n, k, generator=g)

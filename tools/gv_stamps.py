@@ -13,7 +13,7 @@ for _ in range(3):
 torch.cuda.synchronize()
 n = 4096 * 16
 buf = (ctypes.c_ulonglong * n)()
-print("rc", _lib.lib().vnx_debug_read_rec_stamps(buf, n))
+print("rc", _lib.dev_lib().vnx_debug_read_rec_stamps(buf, n))
 a = np.array(buf[:], dtype=np.int64).reshape(-1, 16)
 a = a[a[:, 0] > 0]
 real = a[:, 12] > 0

@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "../include/vnext_hip.h"
+#include "../include/vnext_hip_dev.h"      // links against the development library (libvnext_hip_dev.so): forced variants
 
 #define CK(x)                                                                       \
   do {                                                                              \
@@ -237,10 +238,8 @@ static void run_dma_probe() {
   CK(hipFree(src)); CK(hipFree(dst));
 }
 
-extern "C" int vnx_debug_read_tile_stamps(unsigned long long* host, int n);
 extern "C" void vnx_debug_arm_stamps(void* buf, long long n_words);
 extern "C" int vnx_debug_stamp_regions(int* kinds, long long* offsets, long long* blocks, int n);
-extern "C" int vnx_debug_read_rec_stamps(unsigned long long* host, int n);
 struct Set {
   float *value, *loc, *attn, *go, *out, *gv, *gl, *ga, *off, *logit;
   void* ws;

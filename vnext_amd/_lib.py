@@ -11,6 +11,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libvnext_hip.so")
+# the development build (-DVNX_DEV_VARIANTS + tools/experiments/msda_tile): forced kernel variants for tests and A/B timing
+DEV_LIB_PATH = os.path.join(_HERE, "lib", "libvnext_hip_dev.so")
 
 VNX_F32, VNX_F64, VNX_BF16, VNX_F16 = 0, 1, 2, 3
 VNX_OK = 0
@@ -43,18 +45,21 @@ SIGNATURES = {
     "vnx_add_dropout_layernorm_partial_bytes": (_sz, []),
     "vnx_add_dropout_layernorm_forward": (_i, [_i] + [_vp] * 7 + [_ll, _i, ctypes.c_float, ctypes.c_float, ctypes.c_ulonglong, _vp, _vp]),
     "vnx_add_dropout_layernorm_backward": (_i, [_i] + [_vp] * 9 + [_ll, _i, ctypes.c_float, ctypes.c_ulonglong, _vp, _vp]),
-    "vnx_set_kernel_variant": (None, [_i]),
-    "vnx_get_kernel_variant": (_i, []),
 }
 # measurement aids of include/vnext_hip_debug.h (bench.py, tools/): not part of the drop-in boundary
 DEBUG_SIGNATURES = {
     "vnx_debug_arm_stamps": (None, [_vp, _ll]),
     "vnx_debug_stamp_regions": (_i, [ctypes.POINTER(_i), ctypes.POINTER(_ll), ctypes.POINTER(_ll), _i]),
     "vnx_debug_wall_clock_khz": (_i, []),
-    "vnx_debug_read_rec_stamps": (_i, [ctypes.POINTER(ctypes.c_ulonglong), _i]),
-    "vnx_debug_read_tile_stamps": (_i, [ctypes.POINTER(ctypes.c_ulonglong), _i]),
     "vnx_debug_row_gather_probe": (_i, [_vp, _sz, _vp, _sz, _i, _vp, _vp]),
     "vnx_debug_gvtiles_units": (_i, [_vp, _i, _i, _i, _i, _i, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
+}
+# include/vnext_hip_dev.h: exported by the development library only
+DEV_SIGNATURES = {
+    "vnx_set_kernel_variant": (None, [_i]),
+    "vnx_get_kernel_variant": (_i, []),
+    "vnx_debug_read_rec_stamps": (_i, [ctypes.POINTER(ctypes.c_ulonglong), _i]),
+    "vnx_debug_read_tile_stamps": (_i, [ctypes.POINTER(ctypes.c_ulonglong), _i]),
 }
 
 
@@ -67,33 +72,54 @@ class TrackerConfig(ctypes.Structure):
                                               "match_score_thr", "memo_momentum")]
 
 
-_lib = None
+_lib = None          # the product library
+_dev = None          # the development library, loaded on the first request for a kernel variant
+_active_dev = False  # True while a non-zero kernel variant is set: lib() then hands out the development library
 
 
 class VnextHipError(RuntimeError):
     pass
 
 
-def lib() -> ctypes.CDLL:
-    global _lib
-    if _lib is None:
-        path = os.environ.get("VNX_HIP_LIB") or LIB_PATH    # override: experiment builds (tools/wpe_sweep.py)
-        if not os.path.exists(path):
-            raise VnextHipError(
-                f"{path} is missing: the HIP library is the only implementation of this "
-                "path (no CPU fallback). Build it with `python -m vnext_amd.build`.")
-        # torch ships its own libamdhip64.so.7; import it first so this library binds to
-        # the HIP runtime torch's allocator and streams live in.
-        import torch  # noqa: F401
-        cdll = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
-        for name, (res, args) in {**SIGNATURES, **DEBUG_SIGNATURES}.items():
+def _load(path: str, tables) -> ctypes.CDLL:
+    if not os.path.exists(path):
+        raise VnextHipError(
+            f"{path} is missing: the HIP library is the only implementation of this "
+            "path (no CPU fallback). Build it with `python -m vnext_amd.build`.")
+    # torch ships its own libamdhip64.so.7; import it first so this library binds to
+    # the HIP runtime torch's allocator and streams live in.
+    import torch  # noqa: F401
+    cdll = ctypes.CDLL(path, mode=ctypes.RTLD_LOCAL)
+    for table in tables:
+        for name, (res, args) in table.items():
             fn = getattr(cdll, name)
             fn.restype = res
             fn.argtypes = args
-        if cdll.vnx_abi_version() != ABI_VERSION:
-            raise VnextHipError(f"ABI version {cdll.vnx_abi_version()} != {ABI_VERSION}; rebuild")
-        _lib = cdll
+    if cdll.vnx_abi_version() != ABI_VERSION:
+        raise VnextHipError(f"ABI version {cdll.vnx_abi_version()} != {ABI_VERSION}; rebuild")
+    return cdll
+
+
+def product_lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        path = os.environ.get("VNX_HIP_LIB") or LIB_PATH    # override: experiment builds (tools/wpe_sweep.py)
+        _lib = _load(path, (SIGNATURES, DEBUG_SIGNATURES))
     return _lib
+
+
+def dev_lib() -> ctypes.CDLL:
+    """libvnext_hip_dev.so (include/vnext_hip_dev.h): tests and tools only."""
+    global _dev
+    if _dev is None:
+        _dev = _load(os.environ.get("VNX_HIP_DEV_LIB") or DEV_LIB_PATH, (SIGNATURES, DEBUG_SIGNATURES, DEV_SIGNATURES))
+    return _dev
+
+
+def lib() -> ctypes.CDLL:
+    """The library every op of this package calls: the product -- except while a test or a tool holds a non-zero
+    kernel variant (set_kernel_variant), when it is the development build that has variants at all."""
+    return dev_lib() if _active_dev else product_lib()
 
 
 def check(status: int) -> None:
@@ -110,4 +136,15 @@ def current_stream(tensor) -> int:
 
 
 def set_kernel_variant(v: int) -> None:
-    lib().vnx_set_kernel_variant(int(v))
+    """Tests / tools: route this package's ops through the development library with kernel variant `v` (forced
+    configurations, archived kernels, timing ablations: include/vnext_hip_dev.h); 0 returns to the product library,
+    which has no variants."""
+    global _active_dev
+    v = int(v)
+    if v != 0:
+        dev_lib().vnx_set_kernel_variant(v)
+        _active_dev = True
+    else:
+        if _dev is not None:
+            _dev.vnx_set_kernel_variant(0)
+        _active_dev = False

@@ -6,11 +6,16 @@
 
 #include "vnx_common.h"
 #include "../../include/vnext_hip_debug.h"
+#ifdef VNX_DEV_VARIANTS
+#include "../../include/vnext_hip_dev.h"
+#endif
 
 namespace vnx {
 
 static thread_local char t_error[512] = "";
-std::atomic<int> g_kernel_variant{0};   // A/B measurement knob (vnx_set_kernel_variant); every entry point reads it once
+#ifdef VNX_DEV_VARIANTS
+std::atomic<int> g_kernel_variant{0};   // development build: A/B knob (vnx_set_kernel_variant); every entry point reads it once
+#endif
 
 void set_error(const char* fmt, ...) {
   va_list ap;
@@ -39,11 +44,13 @@ int convert_f32_to(int, const void*, void*, int64_t, const int64_t*, const int64
                    hipStream_t);
 int zero_if_not_packed(const int64_t*, const int64_t*, int, int, void*, size_t, hipStream_t);
 bool msda_d32_fwd_supported(int vdt, int ldt, const MsdaDims& d);
+#ifdef VNX_DEV_VARIANTS      // the LDS-staged forwards: tools/experiments/msda_tile/ (development build only)
 bool msda_tile_fwd_supported(int vdt, int ldt, const MsdaDims& d);
 int msda_forward_tile(const void*, const int64_t*, const int64_t*, const void*, const void*, void*, MsdaDims,
                       const FusedArgs*, int debug, hipStream_t);
 bool msda_tile2_fwd_supported(int vdt, int ldt, const MsdaDims& d);
 int msda_forward_tile2(const void*, const int64_t*, const int64_t*, const void*, const void*, void*, MsdaDims, hipStream_t);
+#endif
 bool msda_d32_bwd_supported(int vdt, int ldt, const MsdaDims& d);
 int msda_forward_d32(int, int, const void*, const int64_t*, const int64_t*, const void*,
                      const void*, void*, MsdaDims, int variant, hipStream_t);
@@ -109,8 +116,7 @@ namespace vnx {
 #ifndef VNX_TILE_UNITS_MIN
 #define VNX_TILE_UNITS_MIN 2
 #endif
-int gv_units_min(const MsdaDims& d, bool tiles) {
-  const int v = g_kernel_variant;
+int gv_units_min(const MsdaDims& d, bool tiles, int v) {
   if (v >= 200 && v < 300) return v - 200 < 1 ? 1 : (v - 200 > 16 ? 16 : v - 200);
   // Tried with per-unit selection: enough units that each expects about one selection window of
   // samples (10 per level at the encoder shape).  Slower on MI355X -- 353 vs 332 us per encoder-shape
@@ -157,7 +163,10 @@ const char* vnx_status_string(int status) {
 
 const char* vnx_last_error(void) { return t_error; }
 
+#ifdef VNX_DEV_VARIANTS
 void vnx_set_kernel_variant(int variant) { g_kernel_variant.store(variant, std::memory_order_relaxed); }
+int vnx_get_kernel_variant(void) { return g_kernel_variant.load(std::memory_order_relaxed); }
+#endif
 
 // buf: device memory of n_words 64-bit words, ZERO-filled by the caller before every measured run
 // (slots of workgroups that never ran stay {0, 0} and are skipped); nullptr disarms
@@ -183,30 +192,18 @@ int vnx_debug_wall_clock_khz(void) {
   if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess) return 0;
   return khz;
 }
-int vnx_get_kernel_variant(void) { return g_kernel_variant.load(std::memory_order_relaxed); }
 
-// The spatially tiled, LDS-staged forward (msda_d32_tile.hip) is built for the calls whose queries are
-// the pixels of the pyramid -- the encoder's -- which the host can only recognise by Lq == S (the level
-// sizes live on the device); the kernel itself checks the rest and stays correct either way.
-// Measured on MI355X against the per-query gather kernel (B = 5, model-like locations, cold): 720p
-// 257-274 vs 266-289 us (it wins, 3-5 %), 360p 70 vs 62 us (it loses: it is bound by VALU issue -- 7 vector
-// instructions per FMA pair once decode, records, staging and bounding boxes are counted -- where the
-// gather kernel is bound by the L1/TA rate), uniform random locations 95 vs 77 us.  So automatic selection
-// took it from 12 288 pixels up (until the change recorded in use_tile_forward).  Variants 700..702 force it (701 / 702:
-// phase stamps), 710 keeps it off.
+// The LDS-staged forwards (north-star row n1; tools/experiments/msda_tile/) were measured over
+// two rounds against the per-query L2-gather kernel -- 64-65 vs 55 us at encoder-360p, within 2 % at 720p -- and are retired
+// from the product build: the development build keeps them reachable (variants 700..702 / 720) with their parity tests.
+#ifdef VNX_DEV_VARIANTS
 static bool use_tile_forward(int vdt, int ldt, const MsdaDims& d, int variant) {
-  if (!msda_tile_fwd_supported(vdt, ldt, d)) return false;
-  // Round 2, late: with two samples in flight instead of four on large calls the gather kernel runs at 8 instead of 5
-  // waves per SIMD and takes 54.9 us at 360p (tiled: 65.5), 88 vs 103 us at 720p B = 2, 252 vs 249 us at 720p B = 5 --
-  // the tiled kernel no longer wins anywhere, so it is never selected automatically.
-  return variant >= 700 && variant <= 702;
+  return variant >= 700 && variant <= 702 && msda_tile_fwd_supported(vdt, ldt, d);
 }
-
-// The second LDS-staged form (msda_d32_tile2.hip): variant 720 forces it, 710 / 730 forbid it.
 static bool use_tile2_forward(int vdt, int ldt, const MsdaDims& d, int variant) {
-  if (!msda_tile2_fwd_supported(vdt, ldt, d)) return false;
-  return variant == 720;
+  return variant == 720 && msda_tile2_fwd_supported(vdt, ldt, d);
 }
+#endif
 
 int vnx_msda_forward(int value_dtype, int loc_dtype, const void* value,
                      const int64_t* spatial_shapes, const int64_t* level_start_index,
@@ -223,12 +220,14 @@ int vnx_msda_forward(int value_dtype, int loc_dtype, const void* value,
     return VNX_ERR_INVALID_ARGUMENT;
   }
   hipStream_t stream = (hipStream_t)hip_stream;
-  const int variant = g_kernel_variant;
+  const int variant = kernel_variant();
+#ifdef VNX_DEV_VARIANTS
   if (use_tile2_forward(value_dtype, loc_dtype, d, variant))
     return msda_forward_tile2(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, output, d, stream);
   if (use_tile_forward(value_dtype, loc_dtype, d, variant))
     return msda_forward_tile(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, output, d, nullptr,
-                             variant >= 700 && variant <= 702 ? variant - 700 : 0, stream);
+                             variant - 700, stream);
+#endif
   if (variant != 1 && msda_d32_fwd_supported(value_dtype, loc_dtype, d))
     return msda_forward_d32(value_dtype, loc_dtype, value, spatial_shapes, level_start_index,
                             sampling_loc, attn_weight, output, d, variant, stream);
@@ -282,7 +281,7 @@ size_t vnx_msda_backward_workspace_bytes(int value_dtype, int loc_dtype, int bat
                                          int spatial_size, int num_heads, int channels,
                                          int num_levels, int num_query, int num_point, int flags) {
   const MsdaDims d{batch, spatial_size, num_heads, channels, num_levels, num_query, num_point};
-  const int variant = g_kernel_variant;
+  const int variant = kernel_variant();
   const bool sixteen = (value_dtype == VNX_BF16 || value_dtype == VNX_F16);
   const size_t image = sixteen ? sizeof(float) * size_t(batch) * size_t(spatial_size) * size_t(num_heads) * size_t(channels) : 0;
   if (!bwd_fast_path(value_dtype, loc_dtype, d, variant)) return image;
@@ -303,7 +302,7 @@ int vnx_msda_backward(int value_dtype, int loc_dtype, const void* value,
                         level_start_index, sampling_loc, attn_weight, d);
   if (st != VNX_OK) return st;
   hipStream_t stream = (hipStream_t)hip_stream;
-  const int variant = g_kernel_variant;
+  const int variant = kernel_variant();
   const size_t n_value = size_t(batch) * size_t(spatial_size) * size_t(num_heads) * size_t(channels);
   const size_t need = vnx_msda_backward_workspace_bytes(value_dtype, loc_dtype, batch, spatial_size,
                                                         num_heads, channels, num_levels, num_query,
@@ -458,11 +457,13 @@ int vnx_msda_fused_forward(int value_dtype, int query_dtype, const void* value, 
     set_error("vnx_msda_fused_forward: null pointer argument");
     return VNX_ERR_INVALID_ARGUMENT;
   }
-  if (use_tile_forward(value_dtype, query_dtype, d, g_kernel_variant)) {
+#ifdef VNX_DEV_VARIANTS
+  if (use_tile_forward(value_dtype, query_dtype, d, kernel_variant())) {
     const FusedArgs fa{reference_points, nullptr, ref_dim, reference_batch_div, nullptr};
     return msda_forward_tile(value, spatial_shapes, level_start_index, sampling_offsets, attention_logits, output, d, &fa, 0,
                              (hipStream_t)hip_stream);
   }
+#endif
   return msda_fused_d32(false, value_dtype, query_dtype, value, spatial_shapes, level_start_index, sampling_offsets,
                         attention_logits, nullptr, output, nullptr, d, nullptr, reference_points, nullptr, ref_dim,
                         reference_batch_div, nullptr, nullptr, nullptr, nullptr, (hipStream_t)hip_stream);
@@ -527,7 +528,7 @@ int vnx_msda_fused_backward(int value_dtype, int query_dtype, const void* value,
     set_error("vnx_msda_fused_backward: null pointer argument");
     return VNX_ERR_INVALID_ARGUMENT;
   }
-  const int variant = g_kernel_variant;
+  const int variant = kernel_variant();
   const FusedScratch fs = fused_scratch(value_dtype, d, variant);
   const size_t rec_bytes = fs.total;
   const bool split16 = split_image_needed(value_dtype, d);

@@ -625,9 +625,15 @@ mask_head_bwd_part(const int block, const float* __restrict__ feats, const float
 __global__ void __launch_bounds__(256)
 zero3_kernel(float* __restrict__ a, size_t na, float* __restrict__ b, size_t nb, float* __restrict__ c, size_t nc) {
   const size_t stride = size_t(gridDim.x) * blockDim.x, t0 = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  const size_t na4 = na / 4;       // grad_feats comes from the allocator: 16-byte aligned
-  for (size_t i = t0; i < na4; i += stride) reinterpret_cast<float4_t*>(a)[i] = float4_t{0.f, 0.f, 0.f, 0.f};
-  for (size_t i = na4 * 4 + t0; i < na; i += stride) a[i] = 0.f;
+  // grad_feats is a caller's pointer: a view with a storage offset is only 4-byte aligned.  A scalar head up to
+  // the first 16-byte boundary, 16-byte stores for the body, a scalar tail.
+  size_t head = (size_t(16) - (reinterpret_cast<uintptr_t>(a) & 15u)) & 15u;
+  head = head / 4 < na ? head / 4 : na;                    // floats before the boundary (the pointer is 4-byte aligned)
+  const size_t na4 = (na - head) / 4;
+  float4_t* a4 = reinterpret_cast<float4_t*>(a + head);
+  for (size_t i = t0; i < head; i += stride) a[i] = 0.f;
+  for (size_t i = t0; i < na4; i += stride) a4[i] = float4_t{0.f, 0.f, 0.f, 0.f};
+  for (size_t i = head + na4 * 4 + t0; i < na; i += stride) a[i] = 0.f;
   for (size_t i = t0; i < nb; i += stride) b[i] = 0.f;
   for (size_t i = t0; i < nc; i += stride) c[i] = 0.f;
 }

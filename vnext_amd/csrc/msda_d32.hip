@@ -1235,7 +1235,7 @@ static int launch_bwd_cfg(const void* value, const int64_t* shapes, const int64_
   // the unit ranges sit behind the records in the workspace (gv_unit_ids_offset); only the P == 4
   // grad_value kernel reads them
   void* unit_ids = (records != nullptr && d.P == 4) ? (void*)((char*)records + gv_unit_ids_offset(d)) : nullptr;
-  const int units_min = gv_units_min(d, tile_summary != nullptr);
+  const int units_min = gv_units_min(d, tile_summary != nullptr, kernel_variant());
   constexpr int kLpr = (sizeof(TV) == 2 || VNX_K1_F32_LPR4(WPB)) ? 4 : 8;    // 16-bit rows as 4 lanes x 16 B; fp32: VNX_K1_F32_LPR4
 #define VNX_LAUNCH(LPT, AT)                                                                     \
   hipLaunchKernelGGL((msda_bwd_d32_kernel<TV, TL, QPW, WPB, LPT, AT, false, ((LPT) == 16 && !(AT)) ? kLpr : 8>), dim3(uint32_t(blocks)),   \
@@ -1333,7 +1333,7 @@ static int launch_bwd_fused_cfg(const void* value, const int64_t* shapes, const 
   }
   const size_t lds = size_t(WPB) * 3 * QPW * 17 * 16 + 128;
   void* unit_ids = (records != nullptr && d.P == 4) ? (void*)((char*)records + gv_unit_ids_offset(d)) : nullptr;
-  const int units_min = gv_units_min(d, tile_summary != nullptr);
+  const int units_min = gv_units_min(d, tile_summary != nullptr, kernel_variant());
   constexpr int kLpr = (sizeof(TV) == 2 || VNX_K1_F32_LPR4(WPB)) ? 4 : 8;
   hipLaunchKernelGGL((msda_bwd_d32_kernel<TV, TL, QPW, WPB, 16, false, true, kLpr>), dim3(uint32_t(blocks)), dim3(64 * WPB),
                      lds, stream, (const TV*)value, shapes, lsi, (const TL*)raw_off, (const TL*)raw_logit,

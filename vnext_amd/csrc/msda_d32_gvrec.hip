@@ -711,7 +711,7 @@ int msda_backward_gvrec_d32(int vdt, const int64_t* shapes, const int64_t* lsi, 
                             hipStream_t stream) {
   // every level is split into at least gv_units_min(d) units (2: 19 units per (b, head) at 360p = 760
   // workgroups <= the 768 resident at 3 per CU -- one round; 4: 960 workgroups, 39.2 vs 37.3 us)
-  const int units_min = gv_units_min(d, false);
+  const int units_min = gv_units_min(d, false, kernel_variant());
   if (vdt == VNX_F32) return launch_gvrec<float>(shapes, lsi, records, grad_out, grad_value, d, units_min, (variant == 408 ? 1 : variant == 412 ? 5 : 0), (variant == 420 ? 1 : variant == 425 ? 3 : 0), split_image, stream);
   if (vdt == VNX_BF16) return launch_gvrec<bf16_t>(shapes, lsi, records, grad_out, grad_value, d, units_min, (variant == 408 ? 1 : variant == 412 ? 5 : 0), (variant == 420 ? 1 : variant == 425 ? 3 : 0), split_image, stream);
   if (vdt == VNX_F16) return launch_gvrec<f16_t>(shapes, lsi, records, grad_out, grad_value, d, units_min, (variant == 408 ? 1 : variant == 412 ? 5 : 0), (variant == 420 ? 1 : variant == 425 ? 3 : 0), split_image, stream);
@@ -751,7 +751,7 @@ split_levels_convert_kernel(const int64_t* __restrict__ shapes, const int64_t* _
 
 int msda_split_levels_convert(int vdt, const int64_t* shapes, const int64_t* lsi, const float* image, void* grad_value,
                               MsdaDims d, bool tiles, hipStream_t stream) {      // tiles: the grad_value path that ran
-  const int units_min = gv_units_min(d, tiles);
+  const int units_min = gv_units_min(d, tiles, kernel_variant());
   const int64_t n4 = int64_t(d.B) * d.S * d.M * 8;
   int64_t blocks = (n4 + 255) / 256;
   if (blocks > 8192) blocks = 8192;
@@ -767,9 +767,11 @@ int msda_split_levels_convert(int vdt, const int64_t* shapes, const int64_t* lsi
   return check_launch("split_levels_convert");
 }
 
-// development aid, not part of the public header
+// development build only (include/vnext_hip_dev.h): the phase stamps variants 408 / 412 leave
+#ifdef VNX_DEV_VARIANTS
 extern "C" int vnx_debug_read_rec_stamps(unsigned long long* host, int n) {
   return int(hipMemcpyFromSymbol(host, HIP_SYMBOL(rec::g_rec_stamps), sizeof(unsigned long long) * size_t(n)));
 }
+#endif
 
 }  // namespace vnx

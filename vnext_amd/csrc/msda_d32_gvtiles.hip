@@ -410,7 +410,7 @@ static int launch_gvtiles(const int64_t* shapes, const int64_t* lsi, const void*
 int msda_backward_gvtiles_d32(int vdt, int ldt, const int64_t* shapes, const int64_t* lsi, const void* loc,
                               const void* attn, const void* summaries, const void* grad_out, void* grad_value,
                               MsdaDims d, int tile_queries, float* split_image, bool compact, hipStream_t stream) {
-  const int units_min = gv_units_min(d, true);
+  const int units_min = gv_units_min(d, true, kernel_variant());
 #define VNX_ARGS shapes, lsi, loc, attn, summaries, grad_out, grad_value, d, units_min, tile_queries, split_image, int(compact), stream
   if (vdt == VNX_F32) return launch_gvtiles<float, float>(VNX_ARGS);
   if (vdt == VNX_BF16 && ldt == VNX_F32) return launch_gvtiles<bf16_t, float>(VNX_ARGS);

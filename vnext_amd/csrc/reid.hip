@@ -88,6 +88,10 @@ constexpr int kBsMax = 4096;
 // form read S from global memory in each of its four passes -- per row two dependent round trips (max, then sum), 13 rows
 // per wave at 50 x 50 on 4 waves: 27.6 us for a 50 x 50 matrix, five times the 300 x 300 similarity before it.
 constexpr int kBsStageMax = 12288;      // elements (48 KiB) staged at most; larger matrices keep the global-memory form
+// The staged form asks for (2 (n + k) + n k) x 4 bytes of dynamic LDS, and without an opt-in a launch may ask for 64 KiB at
+// most: a few rows against the tracker's full memory bank (n = 6, k = 2 048: 65 584 B) passed the element test above and
+// failed to launch.  The choice is made on the BYTES of the whole request.
+constexpr size_t kBsStageLdsMax = 64 * 1024;
 
 template <bool STAGED>
 __global__ void __launch_bounds__(1024)
@@ -190,8 +194,9 @@ extern "C" int vnx_reid_bisoftmax(int dtype, const void* sim, void* out, int n, 
     return VNX_ERR_INVALID_ARGUMENT;
   }
   const int threads = (int64_t(n) * k <= 1024) ? 256 : 1024;
-  if (int64_t(n) * k <= kBsStageMax)
-    hipLaunchKernelGGL(bisoftmax_kernel<true>, dim3(1), dim3(threads), size_t(2 * (n + k) + n * k) * 4,
+  const size_t staged_bytes = (size_t(2) * (size_t(n) + size_t(k)) + size_t(n) * size_t(k)) * 4;
+  if (int64_t(n) * k <= kBsStageMax && staged_bytes <= kBsStageLdsMax)
+    hipLaunchKernelGGL(bisoftmax_kernel<true>, dim3(1), dim3(threads), staged_bytes,
                        (hipStream_t)hip_stream, (const float*)sim, (float*)out, n, k, lds, ldo);
   else
     hipLaunchKernelGGL(bisoftmax_kernel<false>, dim3(1), dim3(threads), size_t(2 * (n + k)) * 4,

@@ -81,16 +81,25 @@ __device__ __forceinline__ void stamp_begin(unsigned long long* s) {
 __device__ __forceinline__ void stamp_end(unsigned long long* s) {
   if (s && (threadIdx.x & 63) == 0) atomicMax(s + 2 * size_t(blockIdx.x) + 1, (unsigned long long)wall_clock64());
 }
+// Kernel variant of this call: 0 = automatic.  The PRODUCT library has no other value -- the forced configurations, the
+// archived kernels and the timing ablations (which return wrong results by construction) exist only in the development
+// build (-DVNX_DEV_VARIANTS, libvnext_hip_dev.so, include/vnext_hip_dev.h), where vnx_set_kernel_variant sets a
+// process-wide value that every entry point reads once.
+#ifdef VNX_DEV_VARIANTS
 extern std::atomic<int> g_kernel_variant;
+inline int kernel_variant() { return g_kernel_variant.load(std::memory_order_relaxed); }
+#else
+constexpr int kernel_variant() { return 0; }
+#endif
 
 struct MsdaDims {
   int B, S, M, D, L, Lq, P;
 };
 
 // grad_value units: every level is split into at least this many.  Shared by the grad_loc kernel
-// (which tags every sample with the units it touches) and the grad_value kernels.  2 (variants
-// 200+x: x).
-int gv_units_min(const MsdaDims& d, bool tiles);
+// (which tags every sample with the units it touches) and the grad_value kernels.  2 (development
+// build, variants 200+x: x).  `variant`: the value the entry point read (kernel_variant()).
+int gv_units_min(const MsdaDims& d, bool tiles, int variant);
 // Backward workspace of the record-fed path: [16-B sample records | 256-B aligned | 4-B unit ranges]
 inline size_t gv_unit_ids_offset(const MsdaDims& d) {
   const size_t n = size_t(d.B) * d.M * d.L * d.Lq * d.P;

@@ -17,8 +17,13 @@ would drop the same elements every step, where the `nn.Dropout` this replaces is
 per replay).  Under capture with p > 0 the kernels therefore also read a per-device STEP SEED from device memory
 (`seed_device` of the C ABI): `step_scope(device)` -- entered by the owner of the captured callable at the top of its
 forward, `_TrainTrunk.forward` here -- bumps that word with a captured `add_`, once per replay; the baked host seeds
-only tell the call sites apart.  The backward of the step reads the same word.  A capture that never entered a
-`step_scope` falls back to the reference expression `norm(x + dropout(r))` (three graph-safe ATen launches).
+only tell the call sites apart.  What the kernels read is not the bumped word itself but a SNAPSHOT of it taken when the
+scope is entered (one captured 8-byte copy per scope entry): the backward of a site reads the snapshot its forward
+read, so a second `step_scope` entry between a forward and its backward -- two trunk forwards before one backward,
+`(loss1 + loss2).backward()`, a second graphed shape key -- cannot change the mask under it.  The step-seed
+word is created eagerly, never inside a capture (its fill would be captured and every replay would reset the seed).  A
+capture that never entered a `step_scope` falls back to the reference expression `norm(x + dropout(r))` (three
+graph-safe ATen launches).
 """
 from __future__ import annotations
 
@@ -29,14 +34,24 @@ from .. import _lib
 CHANNELS = 256
 _calls = 0
 _step_seed = {}          # device -> int64[1] tensor, bumped once per training step inside step_scope()
-_scope_depth = 0
+_scopes = []             # the step_scope objects entered and not yet left (innermost last)
+
+
+def _device_key(device):
+    device = torch.device(device)
+    return (device.type, device.index if device.index is not None else torch.cuda.current_device())
 
 
 def step_seed_tensor(device) -> torch.Tensor:
     device = torch.device(device)
-    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    key = _device_key(device)
     t = _step_seed.get(key)
     if t is None:
+        if device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError(
+                "vnext_amd.ops.fused_norm: the per-device step seed must exist before a hipGraph capture starts (its "
+                "fill would be captured and every replay would reset the seed): run one eager warm-up step, or call "
+                "fused_norm.step_seed_tensor(device) once, before capturing")
         t = _step_seed[key] = torch.full((1,), torch.initial_seed() & 0x7FFFFFFFFFFF, dtype=torch.int64, device=device)
     return t
 
@@ -48,18 +63,30 @@ class step_scope:
 
     def __init__(self, device):
         self.device = torch.device(device)
+        self.snapshot = None     # int64[1]: the step seed as this entry left it; what the sites inside hand to the kernels
 
     def __enter__(self):
-        global _scope_depth
         if self.device.type == "cuda":
-            step_seed_tensor(self.device).add_(0x9E3779B97F4A7C15 & 0x7FFFFFFFFFFF)
-        _scope_depth += 1
+            t = step_seed_tensor(self.device)
+            t.add_(0x9E3779B97F4A7C15 & 0x7FFFFFFFFFFF)
+            # under capture: a captured copy into the graph's private pool, rewritten by every replay; the autograd
+            # contexts of the sites inside keep it alive until their backward has run
+            self.snapshot = t.clone()
+        _scopes.append(self)
         return self
 
     def __exit__(self, *exc):
-        global _scope_depth
-        _scope_depth -= 1
+        _scopes.remove(self)
         return False
+
+
+def _scope_snapshot(device):
+    """The seed snapshot of the innermost open step_scope of this device, or None."""
+    key = _device_key(device)
+    for sc in reversed(_scopes):
+        if sc.snapshot is not None and _device_key(sc.device) == key:
+            return sc.snapshot
+    return None
 
 
 def _next_seed() -> int:
@@ -120,8 +147,8 @@ def add_dropout_norm(x, r, dropout, norm, seed=None):
         return norm(x + dropout(r))
     seed_tensor = None
     if p > 0.0 and torch.cuda.is_current_stream_capturing():
-        if _scope_depth == 0:                    # nobody bumps a step seed in this capture: stay graph-safe
+        seed_tensor = _scope_snapshot(x.device)
+        if seed_tensor is None:                  # nobody bumps a step seed in this capture: stay graph-safe
             return norm(x + dropout(r))
-        seed_tensor = step_seed_tensor(x.device)
     return _AddDropoutLayerNorm.apply(x, r, norm.weight, norm.bias, p, norm.eps, _next_seed() if seed is None else seed,
                                       seed_tensor)
