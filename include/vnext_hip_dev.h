@@ -5,7 +5,7 @@
  * selects its kernels from its own arguments and nothing process-wide can change what it computes.
  *
  * Used by tests/ (parity of every kernel form, not only the automatically selected one), tools/kbench.hip and
- * tools/*.py (A/B timing).
+ * the python tools (A/B timing).
  */
 #ifndef VNEXT_HIP_DEV_H_
 #define VNEXT_HIP_DEV_H_

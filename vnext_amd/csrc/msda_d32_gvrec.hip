@@ -729,23 +729,35 @@ split_levels_convert_kernel(const int64_t* __restrict__ shapes, const int64_t* _
                             const float* __restrict__ image, TV* __restrict__ grad_value, MsdaDims d, int units_min,
                             bool tiles) {
   if (!levels_packed(shapes, lsi, d.L, d.S)) return;
-  // the split levels' pixel ranges, once per workgroup (the first form evaluated the level table per element, with its
-  // loads: 14 us per 360p call for 6 MB of rows)
-  __shared__ int s_lo[rec::kLevelsMax], s_hi[rec::kLevelsMax];
+  // the split levels' pixel ranges, once per workgroup, and the running count of split pixels before each level: the
+  // index space of the pass is ONLY those pixels (round 3 walked all B x S x M x 8 pieces and tested each: 11-14 us per
+  // call for the 6 MB of rows it converts at 360p -- what made the bf16 encoder backward slower than the fp32 one)
+  __shared__ int s_lo[rec::kLevelsMax], s_n[rec::kLevelsMax], s_before[rec::kLevelsMax + 1];
   if (int(threadIdx.x) < d.L) {
     const int l = threadIdx.x;
     const int st = int(lsi[l]), Hc = int(shapes[2 * l]), Wc = int(shapes[2 * l + 1]), n = Hc * Wc;
     const bool split = gv_query_splits(gv_level_units(Hc, Wc, units_min, tiles), d.Lq, d.P, true, d.B * d.M) > 1;
-    s_lo[l] = split ? st : 0; s_hi[l] = split ? st + n : 0;
+    s_lo[l] = st; s_n[l] = split ? n : 0;
   }
   __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int l = 0; l < d.L; ++l) { s_before[l] = run; run += s_n[l]; }
+    s_before[d.L] = run;
+  }
+  __syncthreads();
+  const int split_rows = s_before[d.L];                  // split pixels per batch element
   const int row_pieces = d.M * 8;                        // 16-B pieces per pixel
-  const int64_t n4 = int64_t(d.B) * d.S * row_pieces;    // pieces of 4 channels
+  const int64_t per_batch = int64_t(split_rows) * row_pieces;
+  const int64_t n4 = int64_t(d.B) * per_batch;           // pieces of 4 channels to convert
   for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n4; i += int64_t(gridDim.x) * blockDim.x) {
-    const int s = int((i / row_pieces) % d.S);
-    bool split = false;
-    for (int l = 0; l < d.L; ++l) split = split || (s >= s_lo[l] && s < s_hi[l]);
-    if (split) rec::store4<TV>(grad_value + i * 4, *reinterpret_cast<const rec::float4_t*>(image + i * 4));
+    const int b = int(i / per_batch);
+    const int64_t in_b = i - int64_t(b) * per_batch;
+    const int r = int(in_b / row_pieces), piece = int(in_b - int64_t(r) * row_pieces);
+    int l = 0;
+    while (l + 1 < d.L && r >= s_before[l + 1]) ++l;     // (levels without split pixels have s_before[l + 1] == s_before[l])
+    const int64_t e = ((int64_t(b) * d.S + s_lo[l] + (r - s_before[l])) * row_pieces + piece) * 4;
+    rec::store4<TV>(grad_value + e, *reinterpret_cast<const rec::float4_t*>(image + e));
   }
 }
 

@@ -40,8 +40,10 @@ constexpr int kTileRowsMax = kGvTileRowsMax;      // 256 rows per unit: 4 per 8-
 constexpr int kTileRounds = VNX_TILE_ROUNDS;
 constexpr int kTileWin = kTileRounds * kThreads;  // tile words examined per selection round: 1 024
 constexpr int kTileParts = kTileRounds * kWaves;  // (round, wave) pieces per selection
+constexpr int kTileLevels = 4;                    // the tile words exist for 4 levels x 4 points only (msda_d32.hip, tile mode)
 constexpr size_t kTilesLdsBytes = size_t(kQcMax) * 128 + size_t(kThreads) * 32 + size_t(kTileRowsMax) * 12 + 16 +
-                                  8 * kLevelsMax * 4 + size_t(kTileWin) * 2 + size_t(kTileParts) * 8 + 16;
+                                  8 * kTileLevels * 4 + size_t(kTileWin) * 2 + size_t(kTileParts) * 8 + 16;
+static_assert(kTilesLdsBytes * VNX_TILE_UNITS_PER_CU <= 160 * 1024, "the units that share a CU must fit its LDS");
 
 template <typename TV, typename TL>
 __global__ void __launch_bounds__(kThreads, VNX_TILE_UNITS_PER_CU * kWaves / 4)
@@ -58,7 +60,7 @@ msda_bwd_gv_tiles_kernel(const int64_t* __restrict__ shapes, const int64_t* __re
   uint32_t* offs = cnt2 + 2 * kTileRowsMax;                                      // [rows]
   uint32_t* alloc = offs + kTileRowsMax;                                         // [4]
   int* meta = reinterpret_cast<int*>(alloc + 4);                             // [8*L]
-  uint16_t* hit = reinterpret_cast<uint16_t*>(meta + 8 * kLevelsMax);        // [kTileWin] window-relative tile
+  uint16_t* hit = reinterpret_cast<uint16_t*>(meta + 8 * kTileLevels);       // [kTileWin] window-relative tile
   uint32_t* part_s = reinterpret_cast<uint32_t*>(hit + kTileWin);            // [32] kept tiles per piece
   uint32_t* pre_s = part_s + kTileParts;                                     // [32] exclusive prefixes
   uint32_t* tot = pre_s + kTileParts;                                        // [1] kept tiles of the round
@@ -377,7 +379,7 @@ int msda_gvtiles_units_bound(const MsdaDims& d, int units_min) {
 bool msda_d32_gvtiles_supported(int vdt, int ldt, const MsdaDims& d) {
   if (d.D != 32 || d.P != 4 || vdt == VNX_F64) return false;
   if (vdt == VNX_F32 && ldt != VNX_F32) return false;
-  if (d.L > rec::kLevelsMax) return false;
+  if (d.L != rec::kTileLevels) return false;
   // 24-bit stride multiplies: query index, heads x channels and heads x samples below 2^24; element offsets below 2^32
   if (d.Lq >= (1 << 24) || d.M * 32 >= (1 << 24) || d.M * d.L * 4 >= (1 << 24)) return false;
   if (int64_t(d.Lq) * d.M * 32 >= (int64_t(1) << 32) || int64_t(d.Lq) * d.M * d.L * 8 >= (int64_t(1) << 32)) return false;
