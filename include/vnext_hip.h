@@ -97,15 +97,16 @@ enum {
 };
 
 /*
- * Bytes of scratch vnx_msda_backward needs for these sizes and flags (and the current
- * kernel variant).  32-channel heads: what the grad_loc kernel hands the grad_value
- * kernel -- 20 B per sample (records + unit tags) below 1 024 queries, 8 B per (batch,
- * head, level, query tile) from there on, a tile being the queries one wave of the
- * grad_loc kernel handles (4 on calls of up to 262 144 query rows, 8 beyond) -- size the
- * scratch with this function, not by hand -- plus an fp32 [B, S, M, 32] image of
- * grad_value for 16-bit values unless the levels are promised packed AND there are
- * fewer than 1 024 queries (the general path / the query-split levels accumulate with
- * fp32 atomics).  Other head widths: that image for 16-bit values, else 0.
+ * Bytes of scratch vnx_msda_backward needs for these sizes and flags.  32-channel heads: what the
+ * grad_loc kernel hands the grad_value kernel -- below 1 024 queries 20 B per sample (records + unit
+ * tags); from 1 024 queries up (4 levels x 4 points) 8 B per (batch, head, level, query tile), a tile
+ * being the queries one wave of the grad_loc kernel handles (4 on calls of up to 262 144 query rows, 8
+ * beyond), plus the fp32 partial rows in which the query pieces of the coarse levels meet (at most
+ * 8 x min(S, 4 096) rows of 128 B per (batch, head)) -- size the scratch with this function, not by
+ * hand.  16-bit values additionally need an fp32 [B, S, M, 32] image of grad_value when the levels are
+ * not promised packed (the general path accumulates with fp32 atomics), or on the record-fed path with
+ * >= 1 024 queries (other level / point counts than 4 x 4).  Other head widths: that image for 16-bit
+ * values, else 0.
  */
 size_t vnx_msda_backward_workspace_bytes(int value_dtype, int loc_dtype, int batch,
                                          int spatial_size, int num_heads, int channels,

@@ -1,0 +1,14 @@
+cd $GRAFT_REPO_ROOT
+K=./tools/kbench.bin
+{
+for lib in base p3_1 p3_2; do
+  echo "==== $lib"
+  if [ $lib = base ]; then unset LD_LIBRARY_PATH; else export LD_LIBRARY_PATH=$GRAFT_REPO_ROOT/tools/ab/$lib; fi
+  timeout 120 $K --shape enc360 --dist M --op bwd --variants 0,100 --inner 8 --reps 9 --cold-only --check
+  timeout 120 $K --shape dec360 --dist U --op bwd --variants 0,100 --inner 24 --reps 9 --cold-only --check
+  timeout 120 $K --shape enc720 --dist M --op bwd --variants 0,100 --inner 4 --reps 5 --cold-only
+done
+unset LD_LIBRARY_PATH
+timeout 120 $K --shape enc360 --dist M --dtype bf16 --op bwd --variants 0 --inner 8 --reps 9 --check
+} > gpurun_out/r4c7_kbench.log 2>&1
+grep -v "^shape" gpurun_out/r4c7_kbench.log

@@ -102,6 +102,32 @@ def build_dev(force: bool = False, verbose: bool = False, extra_defines=(), out:
     return build_hip(force=force, verbose=verbose, out=target, defines=(DEV_DEFINE,) + tuple(extra_defines))
 
 
+def build_ab(name: str, defines, files, verbose: bool = False) -> str:
+    """tools/ab/<name>/libvnext_hip_dev.so: the development library with `files` (base names under csrc/) recompiled with
+    extra -D `defines`; every other object is the development build's own (build_dev() first).  An A/B library costs one
+    or two compilations instead of a full rebuild; `LD_LIBRARY_PATH=tools/ab/<name> tools/kbench.bin ...` runs it."""
+    build_dev(verbose=verbose)
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    dev_obj = OBJ_DIR + "_" + DEV_DEFINE
+    out_dir = os.path.join(HERE, "..", "tools", "ab", name)
+    os.makedirs(out_dir, exist_ok=True)
+    objs = []
+    for src in sources(dev=True):
+        base = os.path.basename(src)
+        if base in files:
+            obj = os.path.join(out_dir, base + ".o")
+            cmd = [hipcc] + COMPILE_FLAGS + [f"-D{DEV_DEFINE}"] + [f"-D{d}" for d in defines] + ["-I" + CSRC, "-c", "-o", obj, src]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.check_call(cmd)
+        else:
+            obj = os.path.join(dev_obj, base + ".o")
+        objs.append(obj)
+    target = os.path.join(out_dir, "libvnext_hip_dev.so")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic", "-o", target] + objs)
+    return target
+
+
 def build_kbench(verbose: bool = False) -> str:
     """tools/kbench.bin: the stand-alone timing / cross-check harness (development tool)."""
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"

@@ -60,9 +60,10 @@ int msda_backward_d32(int, int, const void*, const int64_t*, const int64_t*, con
 int msda_bwd_tile_queries(const MsdaDims& d, int variant);
 bool msda_d32_gvtiles_supported(int vdt, int ldt, const MsdaDims& d);
 size_t msda_gvtiles_summary_bytes(const MsdaDims& d, int tile_queries);
+size_t msda_gvtiles_partial_bytes(const MsdaDims& d);
 int msda_backward_gvtiles_d32(int vdt, int ldt, const int64_t*, const int64_t*, const void* loc, const void* attn,
                               const void* summaries, const void* grad_out, void* grad_value, MsdaDims,
-                              int tile_queries, float* split_image, bool compact, hipStream_t);
+                              int tile_queries, float* partials, bool compact, hipStream_t);
 bool msda_d32_fused_supported(int vdt, int ldt, const MsdaDims& d);
 int msda_fused_d32(bool backward, int vdt, int ldt, const void* value, const int64_t* shapes, const int64_t* lsi,
                    const void* raw_off, const void* raw_logit, const void* grad_out, void* out_or_grad_off,
@@ -253,11 +254,13 @@ static bool use_tiles(int vdt, int ldt, const MsdaDims& d, int variant) {
   if (d.P != 4 || d.L * d.P != 16 || !msda_d32_gvtiles_supported(vdt, ldt, d)) return false;
   return variant == 431 || d.Lq >= 1024;
 }
-// 16-bit values with enough queries for the query split of the coarse levels (gv_query_splits): the pieces of such a
-// level meet through fp32 atomics, which need an fp32 target -- the same [B, S, M, 32] fp32 image the general path of
-// unpacked levels uses (the two never run on the same call: one needs packed levels, the other unpacked ones).
-static bool split_image_needed(int vdt, const MsdaDims& d) {
-  return (vdt == VNX_BF16 || vdt == VNX_F16) && d.P == 4 && d.Lq >= 1024;
+// RECORD-fed path with 16-bit values and enough queries for the query split of the coarse levels (gv_query_splits): the
+// pieces of such a level meet through fp32 atomics, which need an fp32 target -- the same [B, S, M, 32] fp32 image the
+// general path of unpacked levels uses (the two never run on the same call: one needs packed levels, the other unpacked
+// ones).  The tile-fed path (every call the models make with >= 1 024 queries) needs none since round 4: its pieces store
+// fp32 partial rows (msda_gvtiles_partial_bytes) and a finishing kernel writes grad_value in its own dtype.
+static bool split_image_needed(int vdt, int ldt, const MsdaDims& d, int variant) {
+  return (vdt == VNX_BF16 || vdt == VNX_F16) && d.P == 4 && d.Lq >= 1024 && !use_tiles(vdt, ldt, d, variant);
 }
 // Tile path: does the grad_loc kernel leave a copy of the locations / weights laid out for the grad_value kernel
 // ([batch][head][level][query][point], fp32, 12 B per sample)?  The fused backward always does (it has to materialise
@@ -270,10 +273,12 @@ static bool tile_copy_wanted(const MsdaDims& d, int variant) {
   return variant == 510;
 }
 static size_t tile_copy_bytes(const MsdaDims& d) { return align256(size_t(12) * size_t(d.B) * d.Lq * d.M * d.L * d.P); }
+// tile path: [tile words | location copy (variant 510 only) | partial rows of the query-split levels' pieces]
+static size_t tiles_partials_offset(const MsdaDims& d, int variant) {
+  return align256(msda_gvtiles_summary_bytes(d, msda_bwd_tile_queries(d, variant))) + (tile_copy_wanted(d, variant) ? tile_copy_bytes(d) : 0);
+}
 static size_t fast_path_scratch_bytes(int vdt, int ldt, const MsdaDims& d, int variant) {
-  if (use_tiles(vdt, ldt, d, variant))
-    return align256(msda_gvtiles_summary_bytes(d, msda_bwd_tile_queries(d, variant))) +
-           (tile_copy_wanted(d, variant) ? tile_copy_bytes(d) : 0);
+  if (use_tiles(vdt, ldt, d, variant)) return tiles_partials_offset(d, variant) + align256(msda_gvtiles_partial_bytes(d));
   return align256(msda_gvrec_record_bytes(d));
 }
 
@@ -287,7 +292,7 @@ size_t vnx_msda_backward_workspace_bytes(int value_dtype, int loc_dtype, int bat
   if (!bwd_fast_path(value_dtype, loc_dtype, d, variant)) return image;
   const size_t records = fast_path_scratch_bytes(value_dtype, loc_dtype, d, variant);
   // packed levels promised: the general path never runs, no fp32 image -- unless the query split needs it
-  return records + (((flags & VNX_MSDA_LEVELS_PACKED) && !split_image_needed(value_dtype, d)) ? 0 : image);
+  return records + (((flags & VNX_MSDA_LEVELS_PACKED) && !split_image_needed(value_dtype, loc_dtype, d, variant)) ? 0 : image);
 }
 
 int vnx_msda_backward(int value_dtype, int loc_dtype, const void* value,
@@ -348,16 +353,17 @@ int vnx_msda_backward(int value_dtype, int loc_dtype, const void* value,
     float* tile_copy = (tiles && tile_copy_wanted(d, variant))
                            ? (float*)((char*)workspace + align256(msda_gvtiles_summary_bytes(d, msda_bwd_tile_queries(d, variant))))
                            : nullptr;
-    const bool split16 = split_image_needed(value_dtype, d);
+    const bool split16 = split_image_needed(value_dtype, loc_dtype, d, variant);
     void* image = (sixteen && (!(flags & VNX_MSDA_LEVELS_PACKED) || split16)) ? (void*)((char*)workspace + rec_bytes) : nullptr;
     float* split_image = split16 ? (float*)image : nullptr;
+    float* partials = tiles ? (float*)((char*)workspace + tiles_partials_offset(d, variant)) : nullptr;
     const bool only_gl = variant >= 100 && variant < 200;  // timing ablations
     const bool only_gv = (variant >= 400 && variant < 430) || (variant > 431 && variant < 500);
-    // records / tile mode: the accumulation-image argument carries fp32 grad_value itself, whose rows of the
-    // query-split levels the kernel zeroes (gv_query_splits)
+    // records mode: the accumulation-image argument carries the fp32 target of the query pieces' atomics (grad_value itself
+    // or the split image), whose rows of the query-split levels the kernel zeroes (gv_query_splits); tile mode: nothing
     st = msda_backward_d32(value_dtype, loc_dtype, value, spatial_shapes, level_start_index,
                            sampling_loc, attn_weight, grad_output,
-                           value_dtype == VNX_F32 ? grad_value : (void*)split_image, grad_sampling_loc,
+                           tiles ? nullptr : (value_dtype == VNX_F32 ? grad_value : (void*)split_image), grad_sampling_loc,
                            grad_attn_weight, d, only_gl ? variant : 100 + (variant < 100 ? variant : 0),
                            records, tile_words, tile_copy, stream);
     if (st != VNX_OK) return st;
@@ -366,10 +372,10 @@ int vnx_msda_backward(int value_dtype, int loc_dtype, const void* value,
         st = tile_copy
                  ? msda_backward_gvtiles_d32(value_dtype, VNX_F32, spatial_shapes, level_start_index, tile_copy,
                                              tile_copy + 2 * (int64_t(d.B) * d.Lq * d.M * d.L * d.P), tile_words, grad_output,
-                                             grad_value, d, msda_bwd_tile_queries(d, variant), split_image, true, stream)
+                                             grad_value, d, msda_bwd_tile_queries(d, variant), partials, true, stream)
                  : msda_backward_gvtiles_d32(value_dtype, loc_dtype, spatial_shapes, level_start_index, sampling_loc,
                                              attn_weight, tile_words, grad_output, grad_value, d,
-                                             msda_bwd_tile_queries(d, variant), split_image, false, stream);
+                                             msda_bwd_tile_queries(d, variant), partials, false, stream);
       else
         st = msda_backward_gvrec_d32(value_dtype, spatial_shapes, level_start_index, records, grad_output,
                                      grad_value, d, variant, split_image, stream);
@@ -473,7 +479,7 @@ int vnx_msda_fused_forward(int value_dtype, int query_dtype, const void* value, 
 // always takes the automatic configuration, hence tile queries of variant 0): [tile words | decoded locations, fp32,
 // 8 B per sample | softmax weights, fp32, 4 B per sample] -- the two tensors the fused prologue otherwise never
 // materialises, 12 B per sample against the records' 16 + 4.
-struct FusedScratch { bool tiles; size_t words, loc, attn, total; };
+struct FusedScratch { bool tiles; size_t words, loc, attn, partials, total; };
 static FusedScratch fused_scratch(int vdt, const MsdaDims& d, int variant) {
   FusedScratch f{};
   f.tiles = use_tiles(vdt, VNX_F32, d, variant);
@@ -482,7 +488,8 @@ static FusedScratch fused_scratch(int vdt, const MsdaDims& d, int variant) {
     f.words = align256(msda_gvtiles_summary_bytes(d, msda_bwd_tile_queries(d, 0)));
     f.loc = align256(samples * 8);
     f.attn = align256(samples * 4);
-    f.total = f.words + f.loc + f.attn;
+    f.partials = align256(msda_gvtiles_partial_bytes(d));      // the query pieces' partial rows, behind the three
+    f.total = f.words + f.loc + f.attn + f.partials;
   } else {
     f.total = align256(msda_gvrec_record_bytes(d));
   }
@@ -492,10 +499,11 @@ static FusedScratch fused_scratch(int vdt, const MsdaDims& d, int variant) {
 size_t vnx_msda_fused_backward_workspace_bytes(int value_dtype, int batch, int spatial_size, int num_heads, int num_levels,
                                                int num_query, int num_point) {
   const MsdaDims d{batch, spatial_size, num_heads, 32, num_levels, num_query, num_point};
-  const size_t image = split_image_needed(value_dtype, d) ? sizeof(float) * size_t(batch) * size_t(spatial_size) * num_heads * 32 : 0;
-  // the larger of the two layouts: the variant may change between this call and the backward (A/B runs)
-  const size_t a = fused_scratch(value_dtype, d, 430).total, b = fused_scratch(value_dtype, d, 0).total;
-  return (a > b ? a : b) + image;
+  // the larger of the two layouts: the variant may change between this call and the backward (A/B runs); the record-fed
+  // one (variant 430) needs the fp32 split image for 16-bit values
+  const size_t image = split_image_needed(value_dtype, VNX_F32, d, 430) ? sizeof(float) * size_t(batch) * size_t(spatial_size) * num_heads * 32 : 0;
+  const size_t a = fused_scratch(value_dtype, d, 430).total + image, b = fused_scratch(value_dtype, d, 0).total;
+  return a > b ? a : b;
 }
 
 int vnx_msda_fused_backward(int value_dtype, int query_dtype, const void* value, const int64_t* spatial_shapes,
@@ -531,27 +539,28 @@ int vnx_msda_fused_backward(int value_dtype, int query_dtype, const void* value,
   const int variant = kernel_variant();
   const FusedScratch fs = fused_scratch(value_dtype, d, variant);
   const size_t rec_bytes = fs.total;
-  const bool split16 = split_image_needed(value_dtype, d);
+  const bool split16 = split_image_needed(value_dtype, VNX_F32, d, variant);
   const size_t need = rec_bytes + (split16 ? sizeof(float) * size_t(batch) * size_t(spatial_size) * num_heads * 32 : 0);
   if (!workspace || workspace_bytes < need) {
     set_error("vnx_msda_fused_backward: workspace of %zu bytes needed (got %zu)", need, workspace_bytes);
     return VNX_ERR_WORKSPACE;
   }
   float* split_image = split16 ? (float*)((char*)workspace + rec_bytes) : nullptr;
-  void* fp32_target = value_dtype == VNX_F32 ? grad_value : (void*)split_image;
+  void* fp32_target = fs.tiles ? nullptr : (value_dtype == VNX_F32 ? grad_value : (void*)split_image);
   if (fs.tiles) {
     // (1) grad of the Linear outputs (+ reference points), one word per (level, tile of queries) and the decoded
     // locations / weights; (2) grad_value from those.  Packed levels are required (no-op on the device otherwise).
     void* words = workspace;
     float* tile_loc = (float*)((char*)workspace + fs.words);
     float* tile_attn = (float*)((char*)workspace + fs.words + fs.loc);
+    float* partials = (float*)((char*)workspace + fs.words + fs.loc + fs.attn);
     st = msda_fused_d32(true, value_dtype, query_dtype, value, spatial_shapes, level_start_index, sampling_offsets,
                         attention_logits, grad_output, grad_sampling_offsets, grad_attention_logits, d, nullptr,
                         reference_points, grad_reference_points, ref_dim, reference_batch_div, fp32_target, words, tile_loc,
                         tile_attn, stream);
     if (st != VNX_OK) return st;
     st = msda_backward_gvtiles_d32(value_dtype, VNX_F32, spatial_shapes, level_start_index, tile_loc, tile_attn, words,
-                                   grad_output, grad_value, d, msda_bwd_tile_queries(d, 0), split_image, true, stream);
+                                   grad_output, grad_value, d, msda_bwd_tile_queries(d, 0), partials, true, stream);
   } else {
     // (1) grad of the Linear outputs (+ reference points) and the sample records; (2) grad_value from the records
     st = msda_fused_d32(true, value_dtype, query_dtype, value, spatial_shapes, level_start_index, sampling_offsets,

@@ -239,6 +239,20 @@ constexpr bool kTilePerWave = VNX_TILE_PER_WAVE != 0;
 #ifndef VNX_K1_BATCH_LARGE
 #define VNX_K1_BATCH_LARGE 2
 #endif
+// Timing ablations of the grad_loc kernel (A/B builds of the development library only; wrong results by construction), a
+// bit mask: 1 = no phase 3 (combination + gradient stores), 2 = no tile boxes, 4 = phase 2 without the 8-lane reductions
+// and result writes (row loads + dots only), 8 = no zeroing of the query-split levels' rows.
+#ifndef VNX_K1_ABL
+#define VNX_K1_ABL 0
+#endif
+// Phase 3's stores: 0 = three plain 4-byte stores per sample (rounds 1-3); 1 = (x, y) as one 8-byte store; 2 = that, and
+// both gradients non-temporal.  Measured (round 4, cold, grad_loc kernel alone / whole backward): encoder-360p 75.5 / 170.7 us
+// (0), 75.6 / 171.2 (1), 64.4 / 165.0 (2); headline 11.4 / 26.6 -> 11.2 / 26.0; encoder-720p B = 5 623 -> 620.  The gradients
+// are read much later, by the caller: streamed past the caches they no longer evict the rows this kernel gathers.  (Round 2
+// tried `nt` on the sample RECORDS as well, which the grad_value kernel reads right away: that lost; boxes and records stay plain.)
+#ifndef VNX_K1_P3
+#define VNX_K1_P3 2
+#endif
 #ifndef VNX_FWD_WPE
 #define VNX_FWD_WPE 0
 #endif
@@ -811,15 +825,18 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
 
   const uint32_t pixel_elems = uint32_t(d.M * D);
 
-  // ---- phase 0: zero the grad_value rows of the query-split levels (gv_query_splits) of this (batch, head):
-  //      the tiles of a batch element share the rows, eight rows per wave and step -----------------------
+  // ---- phase 0 (record-fed grad_value path with >= 1 024 queries only): zero the grad_value rows of the query-split levels
+  //      (gv_query_splits) of this (batch, head), where that path's pieces meet through fp32 atomics: the tiles of a batch
+  //      element share the rows, eight rows per wave and step.  (The tile-fed path -- every encoder call -- has no atomics
+  //      and no zeroing since round 4: its pieces store partial rows, msda_d32_gvtiles.hip; this phase cost 6.7 us of
+  //      the 81-us kernel at encoder-360p.) ---------------------------------------------------------------
   if constexpr (!ATOMICS) {      // (fp32 values: rows of grad_value itself; 16-bit values: rows of the fp32 split image)
-    if (fa.qsplit_zero != nullptr && (sample_units != nullptr || tile_summary != nullptr) && d.Lq >= 1024 &&
+    if (!(VNX_K1_ABL & 8) && fa.qsplit_zero != nullptr && sample_units != nullptr && d.Lq >= 1024 &&
         levels_packed(shapes, lsi, d.L, d.S)) {
       const int t_in_b = tile - b * tiles_per_batch;
       for (int l = 0; l < d.L; ++l) {
         const int Hz = int(shapes[2 * l]), Wz = int(shapes[2 * l + 1]), n = Hz * Wz;
-        if (gv_query_splits(gv_level_units(Hz, Wz, units_min, tile_summary != nullptr), d.Lq, d.P, true, d.B * d.M) > 1) {
+        if (gv_query_splits(gv_level_units(Hz, Wz, units_min, false), d.Lq, d.P, true, d.B * d.M) > 1) {
           float* rows = fa.qsplit_zero + ((int64_t(b) * d.S + int(lsi[l])) * d.M + m) * D;
           for (int r = (t_in_b * WPB + wave) * 8 + (lane >> 3); r < n; r += tiles_per_batch * WPB * 8)
             *reinterpret_cast<float4_t*>(rows + int64_t(r) * d.M * D + (lane & 7) * 4) = float4_t{0.f, 0.f, 0.f, 0.f};
@@ -891,7 +908,7 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
         record = uint4_t{gv_pack_corner(h0, w0, H, W), __float_as_uint(g4.x),
                          __float_as_uint(g4.y), __float_as_uint(a)};
         if constexpr (LP_T == 16 && !ATOMICS) {
-          if (tile_summary != nullptr) {
+          if (!(VNX_K1_ABL & 2) && tile_summary != nullptr) {
             // coordinates saturate at 0xfffe, which the grad_value kernel reads as "or beyond" (a level side of 65 535+)
             const uint32_t x_lo = min(uint32_t(lef ? w0 : w0 + 1), 0xfffeu), x_hi = min(uint32_t(rig ? w0 + 1 : w0), 0xfffeu);
             const uint32_t y_lo = min(uint32_t(top ? h0 : h0 + 1), 0xfffeu), y_hi = min(uint32_t(bot ? h0 + 1 : h0), 0xfffeu);
@@ -930,7 +947,7 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
   uint2_t* s_tile = reinterpret_cast<uint2_t*>(smem + size_t(WPB) * 3 * ent * 16);    // [WPB][4] (tile mode)
   uint2_t* tile_words = reinterpret_cast<uint2_t*>(tile_summary);                       // [b][head][level][tile]
   if constexpr (LP_T == 16 && !ATOMICS) {
-    if (tile_summary != nullptr) {       // uniform.  A lane's samples all have level (lane & 15) >> 2 (P == 4):
+    if (!(VNX_K1_ABL & 2) && tile_summary != nullptr) {       // uniform.  A lane's samples all have level (lane & 15) >> 2 (P == 4):
       // minimum over the 4 points (quad) and over the wave's queries (lane bits 4, 5)
       tile_kx = pk_min_u16(tile_kx, uint32_t(__builtin_amdgcn_update_dpp(int(tile_kx), int(tile_kx), 0xB1, 0xF, 0xF, true)));
       tile_ky = pk_min_u16(tile_ky, uint32_t(__builtin_amdgcn_update_dpp(int(tile_ky), int(tile_ky), 0xB1, 0xF, 0xF, true)));
@@ -1144,6 +1161,10 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
 #pragma unroll
       for (int j = 0; j < kBatch; ++j) {
         const float4_t dd = {dot(v[j][0]), dot(v[j][1]), dot(v[j][2]), dot(v[j][3])};
+        if (VNX_K1_ABL & 4) {
+          if (dd.x + dd.y + dd.z + dd.w == 12345.678f) g_res[i0 + j] = dd;
+          continue;
+        }
         float t0, t1;
         group8_sum4_split(dd, t0, t1);        // lanes 0..3 of the set: (d1, d2); lanes 4..7: (d3, d4)
         if ((ch & 3) == 0) reinterpret_cast<float2_t*>(g_res + i0 + j)[ch >> 2] = float2_t{t0, t1};
@@ -1159,7 +1180,7 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
   __builtin_amdgcn_wave_barrier();
 
   // ---- phase 3 ------------------------------------------------------------------
-  for (int e = lane; e < pairs; e += 64) {
+  for (int e = lane; e < ((VNX_K1_ABL & 1) ? 0 : pairs); e += 64) {
     const int qi3 = e / LP, p = e - qi3 * LP;
     const int q3 = q0 + qi3;
     if (q3 < d.Lq) {
@@ -1178,9 +1199,23 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
       const float Hf = pairs <= 64 ? float(keep_H) : float(int(shapes[2 * l]));
       const float Wf = pairs <= 64 ? float(keep_W) : float(int(shapes[2 * l + 1]));
       if constexpr (!FUSED) {
+#if VNX_K1_P3 >= 1      // A/B: the (x, y) pair of a sample as one 8-byte store (fp32 gradients), 2: both gradients `nt`
+        if constexpr (sizeof(TL) == 4) {
+          const float2_t gxy = {Wf * r.x, Hf * r.y};      // cuh:157-158
+          if (VNX_K1_P3 >= 2) {
+            __builtin_nontemporal_store(gxy, reinterpret_cast<float2_t*>(grad_loc + 2 * wi));
+            __builtin_nontemporal_store(r.z, reinterpret_cast<float*>(grad_attn + wi));
+          } else {
+            *reinterpret_cast<float2_t*>(grad_loc + 2 * wi) = gxy;
+            *reinterpret_cast<float*>(grad_attn + wi) = r.z;      // cuh:156
+          }
+        } else
+#endif
+        {
         store_loc<TL>(grad_loc + 2 * wi, Wf * r.x);       // cuh:157
         store_loc<TL>(grad_loc + 2 * wi + 1, Hf * r.y);   // cuh:158
         store_loc<TL>(grad_attn + wi, r.z);               // cuh:156
+        }
       } else {
         // chain rule through the prologue: d loc / d offset is a per-sample scale, the softmax
         // backward  g_logit = a (g_a - sum_j a_j g_a_j)  is a 16-lane row sum, and 2-d reference
@@ -1219,7 +1254,7 @@ static int launch_bwd_cfg(const void* value, const int64_t* shapes, const int64_
                           void* records, void* tile_summary, float* tile_copy, hipStream_t stream) {
   // records / tile mode: `gv` is not an accumulation image but the fp32 target of the query-split levels' atomics --
   // grad_value itself for fp32 values, the fp32 split image for 16-bit ones (or null) -- whose rows this kernel zeroes
-  void* qsplit_zero = (!atomics && (records != nullptr || tile_summary != nullptr)) ? gv : nullptr;
+  void* qsplit_zero = (!atomics && records != nullptr) ? gv : nullptr;
   if (tile_summary != nullptr && (d.L * d.P != 16 || d.P != 4 || atomics)) {
     set_error("msda_backward: tile mode needs 4 levels x 4 points");
     return VNX_ERR_UNSUPPORTED;

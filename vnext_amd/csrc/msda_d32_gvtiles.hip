@@ -21,8 +21,9 @@
 //      was slow because every unit recomputed ALL samples of its level, not because of these) -- the tiles' grad_out
 //      rows staged in LDS (consecutive queries: the rows of a tile are one strided run), then the same counting sort
 //      by destination row and register accumulation as the record-fed kernel;
-//   3. writes its rows once (or, for the pieces of a query-split level, adds them with fp32 atomics onto rows the
-//      grad_loc kernel zeroed: gv_query_splits, split by tile range here).
+//   3. writes its rows once -- or, for the pieces of a query-split level (gv_query_splits, split by tile range here), stores
+//      them into the piece's slab of fp32 partial rows; gv_split_finish_kernel adds the pieces (no atomics, no zeroing:
+//      gv_partial_rows_bound in vnx_common.h has the measurement that retired the atomics).
 // No records, no tags, no windows.  Levels must be packed (checked on the device).  Reference semantics:
 // ms_deform_im2col_cuda.cuh:87-159 (the scatter this replaces), :253-298 (index decode).
 #include "msda_gv_common.h"
@@ -35,6 +36,12 @@ namespace rec {
 #endif
 #ifndef VNX_TILE_UNITS_PER_CU
 #define VNX_TILE_UNITS_PER_CU 4
+#endif
+// Timing ablations (A/B builds of the development library only; wrong grad_value by construction): 1 = no chunks at all
+// (what set-up + tile selection + the final store cost), 2 = chunks without taps (staging, prefetch and decode only: no
+// rank atomics, no scatter, nothing to apply), 3 = everything but the apply loop.
+#ifndef VNX_GVT_ABL
+#define VNX_GVT_ABL 0
 #endif
 constexpr int kTileRowsMax = kGvTileRowsMax;      // 256 rows per unit: 4 per 8-lane group
 constexpr int kTileRounds = VNX_TILE_ROUNDS;
@@ -51,7 +58,7 @@ msda_bwd_gv_tiles_kernel(const int64_t* __restrict__ shapes, const int64_t* __re
                          const TL* __restrict__ loc, const TL* __restrict__ attn,
                          const uint2_t* __restrict__ summaries, const TV* __restrict__ grad_out,
                          TV* __restrict__ grad_value, MsdaDims d, int units_min, int tile_shift, int n_tiles,
-                         float* __restrict__ split_image, int compact) {
+                         float* __restrict__ partials, int compact) {
   constexpr int D = 32, P = 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float4_t* grows = reinterpret_cast<float4_t*>(smem);                       // [128][8] grad_out rows
@@ -77,7 +84,7 @@ msda_bwd_gv_tiles_kernel(const int64_t* __restrict__ shapes, const int64_t* __re
   if (tid < d.L) {     // level table: {H, W, start, workgroups, query pieces, block width, blocks per row, block height}
     const int H = int(shapes[2 * tid]), W = int(shapes[2 * tid + 1]);
     const GvGrid g = gv_level_grid(H, W, units_min, kTileRowsMax);
-    const int qs = gv_query_splits(g.nbx * g.nby, d.Lq, P, sizeof(TV) == 4 || split_image != nullptr, d.B * d.M);
+    const int qs = gv_query_splits(g.nbx * g.nby, d.Lq, P, true, d.B * d.M);
     int* mt = meta + 8 * tid;
     mt[0] = H; mt[1] = W; mt[2] = int(lsi[tid]); mt[3] = g.nbx * g.nby * qs; mt[4] = qs; mt[5] = g.bw; mt[6] = g.nbx; mt[7] = g.bh;
   }
@@ -88,6 +95,7 @@ msda_bwd_gv_tiles_kernel(const int64_t* __restrict__ shapes, const int64_t* __re
   // this workgroup's unit: pixels [x0, x1) x [y0, y1) of level lvl (local row = (y - y0) * pitch + x - x0, pitch = the
   // level's block width), possibly one of `qsplit` query pieces of it
   int lvl = -1, Hl = 0, Wl = 0, start = 0, qsplit = 1, qpiece = 0, x0 = 0, x1 = 0, y0 = 0, y1 = 0, pitch = 1;
+  int pbase = 0;                               // first partial row of this level's pieces (gv_partial_rows_bound)
   {
     int running = 0;
     bool packed = true;
@@ -115,8 +123,11 @@ msda_bwd_gv_tiles_kernel(const int64_t* __restrict__ shapes, const int64_t* __re
     }
     packed = packed && (running == d.S);
     if (!packed || lvl < 0) return;  // uniform over the workgroup
+    for (int l = 0; l < lvl; ++l)
+      if (meta[8 * l + 4] > 1) pbase += meta[8 * l + 4] * meta[8 * l] * meta[8 * l + 1];
   }
   // uniform over the workgroup, but it came through LDS: scalarise (SGPRs, see opaque())
+  pbase = __builtin_amdgcn_readfirstlane(pbase);
   lvl = __builtin_amdgcn_readfirstlane(lvl);
   Hl = __builtin_amdgcn_readfirstlane(Hl); Wl = __builtin_amdgcn_readfirstlane(Wl); start = __builtin_amdgcn_readfirstlane(start);
   qsplit = __builtin_amdgcn_readfirstlane(qsplit); qpiece = __builtin_amdgcn_readfirstlane(qpiece);
@@ -201,7 +212,7 @@ msda_bwd_gv_tiles_kernel(const int64_t* __restrict__ shapes, const int64_t* __re
     __syncthreads();
 
     // ---- chunks of 128 queries (whole tiles) over the kept tiles ---------------------------------
-    const int n_chunks = ((n_hit << tile_shift) + kQcMax - 1) / kQcMax;
+    const int n_chunks = (VNX_GVT_ABL == 1 || VNX_GVT_ABL == 4 || VNX_GVT_ABL == 5) ? 0 : ((n_hit << tile_shift) + kQcMax - 1) / kQcMax;
     float nx = 0.f, ny = 0.f, na = 0.f;
     bool nvalid = false;
     float4_t pg0 = {0.f, 0.f, 0.f, 0.f}, pg1 = pg0;
@@ -267,6 +278,7 @@ msda_bwd_gv_tiles_kernel(const int64_t* __restrict__ shapes, const int64_t* __re
           wt[0] = a * (hh * hw); wt[1] = a * (hh * lw); wt[2] = a * (lh * hw); wt[3] = a * (lh * lw);
         }
       }
+      if (VNX_GVT_ABL == 2) mask = (wt[0] + wt[1] + wt[2] + wt[3] == 12345.f) ? mask : 0u;
 #pragma unroll
       for (int t = 0; t < 4; ++t)
         if (mask & (1u << t))
@@ -295,6 +307,7 @@ msda_bwd_gv_tiles_kernel(const int64_t* __restrict__ shapes, const int64_t* __re
         rn[k] = row < rows ? cnt[row] : 0u;
         ro[k] = row < rows ? offs[row] : 0u;
         if (row < rows) cnt_next[row] = 0;
+        if (VNX_GVT_ABL == 3) rn[k] = rn[k] == 0x7fffffffu ? 1u : 0u;
       }
       const float4_t* g4 = grows + ch4;
 #pragma unroll
@@ -325,17 +338,17 @@ msda_bwd_gv_tiles_kernel(const int64_t* __restrict__ shapes, const int64_t* __re
   const int grp = te >> 3, ch4 = te & 7;
   const uint32_t inv = (65536u + uint32_t(pitch) - 1u) / uint32_t(pitch);      // row / pitch exactly for row < 256
   const int64_t level_elem = ((int64_t(b) * d.S + start) * d.M + m) * D;
-  if (qsplit > 1) {   // pieces of a query-split level meet through fp32 atomics (rows zeroed by the grad_loc kernel):
-                      // on grad_value itself (fp32) or on the fp32 split image (16-bit values; converted afterwards)
-    float* out32 = (sizeof(TV) == 4 ? reinterpret_cast<float*>(grad_value) : split_image) + level_elem;
+  if (VNX_GVT_ABL == 5) return;                      // (ablation: no final store at all)
+  if (VNX_GVT_ABL == 4 && qsplit > 1) return;        // (ablation: no store of the query pieces' partial rows)
+  if (qsplit > 1) {   // a piece of a query-split level: its rows go to its own slab of fp32 partial rows (plain stores, read
+                      // back right away by gv_split_finish_kernel, which adds the pieces and writes grad_value)
+    float* part = partials + ((int64_t(b) * d.M + m) * gv_partial_rows_bound(d.S, d.L) + pbase + int64_t(qpiece) * (Hl * Wl)) * D;
 #pragma unroll
     for (int k = 0; k < kRpg; ++k) {
       const int row = grp + k * kGroups;
       const int ry = int((uint32_t(row) * inv) >> 16), rx = row - ry * pitch;
-      if (row < rows && rx < x1 - x0) {
-        float* p = out32 + __umul24(uint32_t((y0 + ry) * Wl + x0 + rx), q_stride) + ch4 * 4;
-        atomic_add(p, racc[k].x); atomic_add(p + 1, racc[k].y); atomic_add(p + 2, racc[k].z); atomic_add(p + 3, racc[k].w);
-      }
+      if (row < rows && rx < x1 - x0)
+        *reinterpret_cast<float4_t*>(part + uint32_t((y0 + ry) * Wl + x0 + rx) * uint32_t(D) + ch4 * 4) = racc[k];
     }
     return;
   }
@@ -349,6 +362,50 @@ msda_bwd_gv_tiles_kernel(const int64_t* __restrict__ shapes, const int64_t* __re
   }
 }
 
+
+// The pieces of the query-split levels -> grad_value.  One thread per (batch, head, split pixel, 4 channels): adds the
+// level's qs partial rows in piece order (a fixed order: these rows' sums do not depend on scheduling) and writes the row
+// of grad_value, in its dtype, exactly once.  The level table is the grad_value kernel's (same gv_level_grid /
+// gv_query_splits arguments); nothing to do, on the device, when no level is split or the levels are not packed.
+template <typename TV>
+__global__ void __launch_bounds__(256)
+gv_split_finish_kernel(const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
+                       const float* __restrict__ partials, TV* __restrict__ grad_value, MsdaDims d, int units_min) {
+  constexpr int D = 32, P = 4;
+  if (!levels_packed(shapes, lsi, d.L, d.S)) return;
+  __shared__ int s_start[kTileLevels], s_n[kTileLevels], s_qs[kTileLevels], s_before[kTileLevels + 1], s_base[kTileLevels];
+  if (int(threadIdx.x) < d.L) {
+    const int l = threadIdx.x;
+    const int H = int(shapes[2 * l]), W = int(shapes[2 * l + 1]);
+    const GvGrid g = gv_level_grid(H, W, units_min, kTileRowsMax);
+    const int qs = gv_query_splits(g.nbx * g.nby, d.Lq, P, true, d.B * d.M);
+    s_start[l] = int(lsi[l]); s_qs[l] = qs; s_n[l] = qs > 1 ? H * W : 0;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int before = 0, base = 0;
+    for (int l = 0; l < d.L; ++l) { s_before[l] = before; s_base[l] = base; before += s_n[l]; base += s_qs[l] * s_n[l]; }
+    s_before[d.L] = before;
+  }
+  __syncthreads();
+  const int split_rows = s_before[d.L];                            // split pixels per (batch, head)
+  const int per_bm = split_rows * 8;                               // 16-B pieces per (batch, head): blockIdx.y
+  const int bm = int(blockIdx.y);
+  const int b = bm / d.M, m = bm - b * d.M;
+  const float* slab = partials + int64_t(bm) * gv_partial_rows_bound(d.S, d.L) * D;
+  TV* gv_bm = grad_value + (int64_t(b) * d.S * d.M + m) * D;
+  for (int i = int(blockIdx.x) * int(blockDim.x) + int(threadIdx.x); i < per_bm; i += int(gridDim.x) * int(blockDim.x)) {
+    const int r = i >> 3, ch4 = i & 7;
+    int l = 0;
+    while (l + 1 < d.L && r >= s_before[l + 1]) ++l;               // (unsplit levels: s_before[l + 1] == s_before[l])
+    const int px = r - s_before[l], n_l = s_n[l], qs = s_qs[l];
+    const float* src = slab + (int64_t(s_base[l] + px) * D + ch4 * 4);
+    float4_t acc = *reinterpret_cast<const float4_t*>(src);
+    for (int j = 1; j < qs; ++j) acc += *reinterpret_cast<const float4_t*>(src + int64_t(j) * n_l * D);
+    store4<TV>(gv_bm + int64_t(s_start[l] + px) * d.M * D + ch4 * 4, acc);
+  }
+}
+
 }  // namespace rec
 
 
@@ -356,6 +413,11 @@ msda_bwd_gv_tiles_kernel(const int64_t* __restrict__ shapes, const int64_t* __re
 size_t msda_gvtiles_summary_bytes(const MsdaDims& d, int tile_queries) {
   const size_t n_tiles = (size_t(d.Lq) + tile_queries - 1) / tile_queries;
   return size_t(8) * size_t(d.B) * d.M * d.L * n_tiles;
+}
+
+// bytes of the query pieces' partial rows (fp32), all (batch, head) slabs
+size_t msda_gvtiles_partial_bytes(const MsdaDims& d) {
+  return size_t(d.B) * size_t(d.M) * size_t(gv_partial_rows_bound(d.S, d.L)) * 32 * sizeof(float);
 }
 
 // Workgroups per (batch, head): the host knows S, not the level shapes.  gv_level_grid: a narrow level (W <= 63: bands
@@ -392,7 +454,7 @@ bool msda_d32_gvtiles_supported(int vdt, int ldt, const MsdaDims& d) {
 template <typename TV, typename TL>
 static int launch_gvtiles(const int64_t* shapes, const int64_t* lsi, const void* loc, const void* attn,
                           const void* summaries, const void* grad_out, void* grad_value, const MsdaDims& d,
-                          int units_min, int tile_queries, float* split_image, int compact, hipStream_t stream) {
+                          int units_min, int tile_queries, float* partials, int compact, hipStream_t stream) {
   int tile_shift = 0;
   while ((1 << tile_shift) < tile_queries) ++tile_shift;
   if ((1 << tile_shift) != tile_queries || tile_queries > rec::kQcMax) {
@@ -404,16 +466,30 @@ static int launch_gvtiles(const int64_t* shapes, const int64_t* lsi, const void*
   hipLaunchKernelGGL((rec::msda_bwd_gv_tiles_kernel<TV, TL>), dim3(uint32_t(blocks)), dim3(rec::kThreads),
                      rec::kTilesLdsBytes, stream, shapes, lsi, (const TL*)loc, (const TL*)attn,
                      (const rec::uint2_t*)summaries, (const TV*)grad_out, (TV*)grad_value, d, units_min, tile_shift, n_tiles,
-                     split_image, compact);
-  return check_launch("msda_bwd_gv_tiles");
+                     partials, compact);
+  int st = check_launch("msda_bwd_gv_tiles");
+  if (st != VNX_OK) return st;
+  // the pieces of the query-split levels -> grad_value (sized by the bound on split pixels; idle threads leave at once)
+  // grid: x = a share of the (batch, head)'s split pixels (grid-stride), y = (batch, head)
+  const int64_t px_bound = gv_partial_rows_bound(d.S, d.L) / kGvSplitPiecesMax;
+  int64_t fx = (px_bound * 8 + 255) / 256;
+  fx = fx < 1 ? 1 : (fx > 16 ? 16 : fx);
+  if (int64_t(d.B) * d.M > 65535) {
+    set_error("msda_backward_gvtiles: batch x heads = %lld exceeds the grid limit of the finishing kernel", (long long)(int64_t(d.B) * d.M));
+    return VNX_ERR_UNSUPPORTED;
+  }
+  hipLaunchKernelGGL((rec::gv_split_finish_kernel<TV>), dim3(uint32_t(fx), uint32_t(d.B * d.M)), dim3(256), 0, stream, shapes, lsi,
+                     (const float*)partials, (TV*)grad_value, d, units_min);
+  return check_launch("msda_gv_split_finish");
 }
 
-// grad_value from the op's inputs and the tile words; a no-op on the device when the levels are not packed.
+// grad_value from the op's inputs and the tile words (two launches: the units, then the pieces of the query-split levels);
+// a no-op on the device when the levels are not packed.  partials: msda_gvtiles_partial_bytes(d) bytes of scratch.
 int msda_backward_gvtiles_d32(int vdt, int ldt, const int64_t* shapes, const int64_t* lsi, const void* loc,
                               const void* attn, const void* summaries, const void* grad_out, void* grad_value,
-                              MsdaDims d, int tile_queries, float* split_image, bool compact, hipStream_t stream) {
+                              MsdaDims d, int tile_queries, float* partials, bool compact, hipStream_t stream) {
   const int units_min = gv_units_min(d, true, kernel_variant());
-#define VNX_ARGS shapes, lsi, loc, attn, summaries, grad_out, grad_value, d, units_min, tile_queries, split_image, int(compact), stream
+#define VNX_ARGS shapes, lsi, loc, attn, summaries, grad_out, grad_value, d, units_min, tile_queries, partials, int(compact), stream
   if (vdt == VNX_F32) return launch_gvtiles<float, float>(VNX_ARGS);
   if (vdt == VNX_BF16 && ldt == VNX_F32) return launch_gvtiles<bf16_t, float>(VNX_ARGS);
   if (vdt == VNX_BF16 && ldt == VNX_BF16) return launch_gvtiles<bf16_t, bf16_t>(VNX_ARGS);

@@ -255,6 +255,20 @@ __host__ __device__ inline int gv_query_splits(int row_units, int Lq, int P, boo
   return qs < 1 ? 1 : (qs > cap ? cap : qs);
 }
 
+// Tile-fed grad_value path: the query pieces of a split level do NOT meet through atomics (rounds 2-3 did: 4 M fp32 atomics
+// per T=5 360p encoder call, issued 8 lanes x 16-B stride per row = the slow address pattern of tools/atomic_bench.hip,
+// 80 G dwords/s: 44 us of the 87-us kernel, plus 7 us in the grad_loc kernel to zero the rows first -- found by timing
+// ablations in round 4).  Every piece stores its rows, plain 16-B stores, into its own slab of fp32 PARTIAL rows in the
+// workspace, and a small finishing kernel adds the pieces of each row in a fixed order and writes grad_value once (in its
+// own dtype: the fp32 "split image" + convert pass of 16-bit values is gone too).  Layout per (batch, head): for every
+// split level l in order, qs_l pieces x n_l pixels x 32 floats, starting at row  sum_{l' < l} qs_l' n_l'.
+// A split level has at most 4 units of at most kGvTileRowsMax pixels (gv_query_splits), at most this many pieces:
+constexpr int kGvSplitPiecesMax = VNX_QS_COARSE > 4 * VNX_QS_MID ? VNX_QS_COARSE : 4 * VNX_QS_MID;
+__host__ __device__ inline int64_t gv_partial_rows_bound(int S, int L) {      // partial rows per (batch, head), an upper bound
+  const int64_t px = int64_t(4) * kGvTileRowsMax * L;
+  return (px < S ? px : int64_t(S)) * kGvSplitPiecesMax;
+}
+
 inline int elem_size(int dtype) {
   switch (dtype) {
     case VNX_F32: return 4;
