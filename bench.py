@@ -189,7 +189,8 @@ def count_launches(step):
         return f"unavailable: {type(e).__name__}"
 
 
-def model_step_leg(rank, local_rank, world, device, steps, warmup=3, clips_per_rank=2, bf16=False, count=False):
+def model_step_leg(rank, local_rank, world, device, steps, warmup=3, clips_per_rank=2, bf16=False, count=False,
+                   tuned_gemms=True):
     """clips/s of the SeqFormer-R50 training step (BASELINE config: T=5 synthetic 360p clip, 300
     queries): forward + backward + RCCL gradient all-reduce + clipped AdamW step, two clips per
     rank -- the reference's per-GPU batch (IMS_PER_BATCH 16 on 8 GPUs, configs/base_ytvis.yaml:18) --
@@ -199,7 +200,11 @@ def model_step_leg(rank, local_rank, world, device, steps, warmup=3, clips_per_r
     import torch.distributed as dist
     import vnext_amd.models  # noqa: F401
     from vnext_amd import train as T
+    from vnext_amd import tuning
     from vnext_amd.registry import build_model, get_seqformer_cfg
+    # the Linear / attention GEMMs are plain library GEMMs: take the rocBLAS / hipBLASLt solutions recorded offline for
+    # these shapes on MI355X (vnext_amd/tuning, tuning itself off); tuned_gemms=False = the library's default heuristic
+    gemms = tuning.enable() if tuned_gemms else (tuning.disable() or tuning.status())
     torch.manual_seed(0)
     cfg = get_seqformer_cfg(**{"MODEL.DEVICE": str(device)})
     model = build_model(cfg).train()
@@ -244,7 +249,7 @@ def model_step_leg(rank, local_rank, world, device, steps, warmup=3, clips_per_r
     del ddp, opt, model
     torch.cuda.empty_cache()
     return {"clips_per_s": world * clips_per_rank * steps / dt, "ms_per_step": dt * 1e3 / steps, "steps": steps,
-            "launches_per_step": launches,
+            "launches_per_step": launches, "library_gemms": gemms,
             "clips_per_rank": clips_per_rank, "n_gpus": world, "trainable_params": n_params,
             "grad_allreduce_MB_per_step": round(n_params * 4 / 1e6, 1),
             "ddp_bucket_cap_MB": T.ddp_bucket_mb() if world > 1 else None,
@@ -260,6 +265,8 @@ def extra_model_legs(device):
     import vnext_amd.models  # noqa: F401
     from vnext_amd import train as T
     from vnext_amd.registry import build_model, get_idol_cfg, get_seqformer_cfg
+    from vnext_amd import tuning
+    tuning.enable()
 
     def timed(fn, n):
         torch.cuda.synchronize()
@@ -859,6 +866,11 @@ def main():
             one = model_step_leg(rank, local_rank, world, device, a.model_steps, clips_per_rank=1)
             model_leg["one_clip_per_rank"] = {k: one[k] for k in ("clips_per_s", "ms_per_step")}
             amp = model_step_leg(rank, local_rank, world, device, a.model_steps, bf16=True)
+            plain = model_step_leg(rank, local_rank, world, device, a.model_steps, tuned_gemms=False)
+            model_leg["library_default_gemms"] = {**{k: plain[k] for k in ("clips_per_s", "ms_per_step")},
+                                                  "note": "the same step with TunableOp off: rocBLAS / hipBLASLt default heuristic"}
+            from vnext_amd import tuning
+            tuning.enable()
             model_leg["bf16_autocast"] = {**{k: amp[k] for k in ("clips_per_s", "ms_per_step")},
                                           "note": "same step under torch.autocast(bfloat16): bf16 GEMMs and op value, fp32 "
                                                   "locations / losses; the reference trains in fp32, so this is not the headline"}

@@ -322,6 +322,12 @@ msda_bwd_gv_rec_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
 // decoder backward 27.6 vs 27.9-28.2 us, but the encoder shape LOSES even with the kernel templated back to 128 for
 // large calls (225.5 vs 217.9 us at 360p, 492 vs 452 us at 720p B = 2: the step loop no longer unrolls into the old
 // schedule).  Not kept.
+// Timing ablations of the selection kernel (A/B builds of the development library only; wrong grad_value by construction):
+// 1 = no chunks (set-up + selection + final store), 2 = chunks without taps (no rank atomics / scatter / apply), 3 = no apply,
+// 4 = no selection either (returns after the level table: launch + set-up)
+#ifndef VNX_SEL_ABL
+#define VNX_SEL_ABL 0
+#endif
 constexpr int kWin = 2048;                        // samples per selection window
 constexpr int kWinQueries = kWin / 4;
 constexpr int kSelRounds = kWin / kThreads;       // 4
@@ -414,6 +420,7 @@ msda_bwd_gv_sel_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
   // level land in a unit, so selecting them buys nothing and costs the unit its longest latency chain (tag loads, ballots,
   // scan: 3.4 us of the 12-15 us a coarse unit of the T=5 decoder call takes -- the kernel's critical path).  Such a unit
   // takes every sample of a window in order: identity tables, no loads, no ballots, no scan.
+  if (VNX_SEL_ABL == 4) return;
   const bool dense = __builtin_amdgcn_readfirstlane(lvl_units) <= 2;
   const int rows = r1 - r0;
   constexpr int kRpg = (kRowsMax + kGroups - 1) / kGroups;
@@ -507,7 +514,7 @@ msda_bwd_gv_sel_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
       }
     }
     }   // !dense
-    const int n_chunks = (n_q + kQcMax - 1) / kQcMax;
+    const int n_chunks = VNX_SEL_ABL == 1 ? 0 : (n_q + kQcMax - 1) / kQcMax;
     if (tid == 0) cs[n_chunks] = uint32_t(n_sel);
     __syncthreads();
     if (win0 == 0) VNX_SEL_STAMP(4);
@@ -560,6 +567,7 @@ msda_bwd_gv_sel_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
         row00 = p00 - r0;
         wt[0] = a * (hh * hw); wt[1] = a * (hh * lw); wt[2] = a * (lh * hw); wt[3] = a * (lh * lw);
       }
+      if (VNX_SEL_ABL == 2) mask = (wt[0] + wt[1] + wt[2] + wt[3] == 12345.f) ? mask : 0u;
 #pragma unroll
       for (int t = 0; t < 4; ++t)
         if (mask & (1u << t))
@@ -589,6 +597,7 @@ msda_bwd_gv_sel_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
         rn[k] = row < rows ? cnt[row] : 0u;
         ro[k] = row < rows ? offs[row] : 0u;
         if (row < rows) cnt_next[row] = 0;
+        if (VNX_SEL_ABL == 3) rn[k] = rn[k] == 0x7fffffffu ? 1u : 0u;
       }
       const float4_t* g4 = grows + ch4;
 #pragma unroll

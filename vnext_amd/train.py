@@ -202,6 +202,14 @@ def set_rank_affinity(local_rank: int, local_world: int):
     return {"numa_node": node, "cpus": len(mine)}
 
 
+def enable_tuned_gemms(path=None):
+    """The rocBLAS / hipBLASLt solutions recorded offline for the models' GEMM shapes on MI355X (vnext_amd/tuning):
+    SeqFormer-R50 training step 76.5 -> 66.6 ms.  Call once per process before training / inference; a no-op (with the
+    reason in the returned dict) on other stacks."""
+    from . import tuning
+    return tuning.enable(path)
+
+
 def build_optimizer(model, base_lr=2e-4, backbone_multiplier=0.1, weight_decay=1e-4):
     """AdamW, backbone at base_lr * multiplier (train_net.py:85-113)."""
     backbone, rest = [], []
