@@ -14,7 +14,12 @@ import vnext_amd.models  # noqa: F401,E402
 from vnext_amd import train as T  # noqa: E402
 from vnext_amd.registry import build_model, get_seqformer_cfg  # noqa: E402
 
+from vnext_amd import tuning  # noqa: E402
+
 STEPS = int(os.environ.get("VNX_PROF_STEPS", "6"))
+print("library gemms:", tuning.enable())                      # recorded rocBLAS / hipBLASLt solutions (VNX_TUNED_GEMMS=0: default)
+if os.environ.get("VNX_CUDNN_BENCHMARK", "0") == "1":
+    torch.backends.cudnn.benchmark = True                     # MIOpen: find the convolution algorithms by measurement
 dev = "cuda:0"
 torch.manual_seed(0)
 model = build_model(get_seqformer_cfg(**{"MODEL.DEVICE": dev})).train()
@@ -33,4 +38,8 @@ if delay > 0:
 for _ in range(STEPS):
     T.train_step(model, opt, clips)
 torch.cuda.synchronize()
-print("steps", STEPS)
+t1 = time.time()
+for _ in range(STEPS):
+    T.train_step(model, opt, clips)
+torch.cuda.synchronize()
+print("steps", STEPS, "ms/step %.2f" % ((time.time() - t1) * 1e3 / STEPS))
