@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define VNX_ABI_VERSION 10
+#define VNX_ABI_VERSION 11
 
 /* element types */
 enum {
@@ -306,18 +306,40 @@ int vnx_tracker_frame(const vnx_tracker_config* cfg, void* state, const float* m
  *   `seed`.  A host integer is baked into a captured hipGraph, so every replay of a captured training step would
  *   drop the same elements; a device word the caller bumps once per step (inside the graph) gives each replay fresh
  *   masks.  It must hold the same value when the matching backward runs.
- * Backward: grad_x = d loss / d x, grad_r = d loss / d r (both [rows, 256]), grad_gamma, grad_beta [256] (overwritten, not
- * accumulated; summed in a fixed order).  partial: scratch of vnx_add_dropout_layernorm_partial_bytes() bytes.
+ *   r_bias (may be null; ABI 11): a [256] vector added to every row of r before the dropout -- the bias of the Linear
+ *   that produced r, when that GEMM ran without it -- so that its gradient falls out of this op's backward for free
+ *   (grad_r_bias = column sums of grad_r) instead of costing the caller a reduction launch per Linear.
+ * Backward: grad_x = d loss / d x, grad_r = d loss / d r (both [rows, 256]), grad_gamma, grad_beta [256] and, when
+ * grad_r_bias is not null, grad_r_bias [256] (overwritten, not accumulated; summed in a fixed order).  partial: scratch
+ * of vnx_add_dropout_layernorm_partial_bytes() bytes.
  */
 size_t vnx_add_dropout_layernorm_partial_bytes(void);
-int vnx_add_dropout_layernorm_forward(int dtype, const void* x, const void* r, const void* gamma, const void* beta,
+int vnx_add_dropout_layernorm_forward(int dtype, const void* x, const void* r, const void* r_bias, const void* gamma, const void* beta,
                                       void* y, void* z, void* stats, long long rows, int channels, float p, float eps,
                                       unsigned long long seed, const unsigned long long* seed_device,
                                       void* hip_stream);
 int vnx_add_dropout_layernorm_backward(int dtype, const void* grad_y, const void* z, const void* stats,
                                        const void* gamma, void* grad_x, void* grad_r, void* grad_gamma, void* grad_beta,
-                                       void* partial, long long rows, int channels, float p, unsigned long long seed,
+                                       void* grad_r_bias, void* partial, long long rows, int channels, float p, unsigned long long seed,
                                        const unsigned long long* seed_device, void* hip_stream);
+
+/*
+ * The middle of a transformer FFN, y = dropout(relu(h + bias)), IN PLACE over h [rows, channels] fp32 (channels a multiple
+ * of 4, <= 4 096), and its backward (projects/SeqFormer/seqformer/models/deformable_transformer.py:226-229,330-338:
+ * `self.dropout2(self.activation(self.linear1(src)))` -- relu, dropout and, in the backward, masked_scale,
+ * threshold_backward and linear1's bias-gradient reduction: five ATen launches and 11.5 passes over the hidden tensor;
+ * here two launches + a 32-workgroup reduction and 2 passes).  bias (may be null): added before the ReLU -- run the GEMM
+ * without it.  Dropout as in vnx_add_dropout_layernorm_* (hash of (seed, element), seed_device for captured graphs).
+ * Backward: grad_h = y > 0 ? grad / (1 - p) : 0 -- y, the forward's output, is all it needs (y > 0 <=> the element
+ * passed the ReLU and was kept); grad_h may be the same buffer as grad -- and grad_bias [channels] = the column sums of
+ * grad_h (may be null; partial: scratch of vnx_bias_relu_dropout_partial_bytes(channels) bytes, needed with grad_bias;
+ * fixed summation order).
+ */
+size_t vnx_bias_relu_dropout_partial_bytes(int channels);
+int vnx_bias_relu_dropout_forward(int dtype, void* h, const void* bias, long long rows, int channels, float p,
+                                  unsigned long long seed, const unsigned long long* seed_device, void* hip_stream);
+int vnx_bias_relu_dropout_backward(int dtype, const void* grad, const void* y, void* grad_h, void* grad_bias, void* partial,
+                                   long long rows, int channels, float p, void* hip_stream);
 
 /* (The kernel-variant override of rounds 1-3 -- a process-wide A/B knob -- is no longer part of this library: it lives in
  *  the development build only, include/vnext_hip_dev.h.  Every call here selects its kernels from its own arguments.) */

@@ -16,7 +16,7 @@ DEV_LIB_PATH = os.path.join(_HERE, "lib", "libvnext_hip_dev.so")
 
 VNX_F32, VNX_F64, VNX_BF16, VNX_F16 = 0, 1, 2, 3
 VNX_OK = 0
-ABI_VERSION = 10
+ABI_VERSION = 11
 MSDA_LEVELS_PACKED = 1
 
 _vp, _i, _sz, _ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_longlong
@@ -43,8 +43,11 @@ SIGNATURES = {
     "vnx_tracker_frame_workspace_bytes": (_sz, [_vp, _i, _i]),
     "vnx_tracker_frame": (_i, [_vp] * 6 + [_i] * 3 + [_vp, _vp, _sz, _vp]),
     "vnx_add_dropout_layernorm_partial_bytes": (_sz, []),
-    "vnx_add_dropout_layernorm_forward": (_i, [_i] + [_vp] * 7 + [_ll, _i, ctypes.c_float, ctypes.c_float, ctypes.c_ulonglong, _vp, _vp]),
-    "vnx_add_dropout_layernorm_backward": (_i, [_i] + [_vp] * 9 + [_ll, _i, ctypes.c_float, ctypes.c_ulonglong, _vp, _vp]),
+    "vnx_add_dropout_layernorm_forward": (_i, [_i] + [_vp] * 8 + [_ll, _i, ctypes.c_float, ctypes.c_float, ctypes.c_ulonglong, _vp, _vp]),
+    "vnx_add_dropout_layernorm_backward": (_i, [_i] + [_vp] * 10 + [_ll, _i, ctypes.c_float, ctypes.c_ulonglong, _vp, _vp]),
+    "vnx_bias_relu_dropout_partial_bytes": (_sz, [_i]),
+    "vnx_bias_relu_dropout_forward": (_i, [_i, _vp, _vp, _ll, _i, ctypes.c_float, ctypes.c_ulonglong, _vp, _vp]),
+    "vnx_bias_relu_dropout_backward": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _ll, _i, ctypes.c_float, _vp]),
 }
 # measurement aids of include/vnext_hip_debug.h (bench.py, tools/): not part of the drop-in boundary
 DEBUG_SIGNATURES = {

@@ -23,6 +23,8 @@ typedef float float4_t __attribute__((ext_vector_type(4)));
 constexpr int kAnC = 256;            // channels per row: one float4 per lane
 constexpr int kAnWaves = 4;          // rows per workgroup pass
 constexpr int kAnMaxBlocks = 1024;   // workgroups of the backward = rows of the partial-gradient buffer
+constexpr int kAnParts = 3;          // partial rows per workgroup: gamma, beta, and the bias folded into r (ABI 11)
+static_assert(kAnParts <= kAnWaves, "one wave per partial row");
 
 // murmur3-style mix of (element index, 64-bit seed) -> 32 uniform bits
 __device__ __forceinline__ uint32_t an_hash(uint32_t idx, uint32_t seed_lo, uint32_t seed_hi) {
@@ -67,7 +69,7 @@ __device__ __forceinline__ float4_t an_residual(float4_t x, float4_t r, int64_t 
 }
 
 __global__ void __launch_bounds__(64 * kAnWaves)
-add_dropout_layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ r,
+add_dropout_layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ r_bias,
                                  const float* __restrict__ gamma, const float* __restrict__ beta,
                                  float* __restrict__ y, float* __restrict__ z_out, float* __restrict__ stats,
                                  int64_t rows, uint32_t threshold, float scale, float eps, uint32_t seed_lo,
@@ -78,7 +80,8 @@ add_dropout_layernorm_fwd_kernel(const float* __restrict__ x, const float* __res
   if (threshold != 0u) an_effective_seed(seed_lo, seed_hi, seed_device);
   const int64_t at = row * kAnC + lane * 4;
   const float4_t xv = *reinterpret_cast<const float4_t*>(x + at);
-  const float4_t rv = *reinterpret_cast<const float4_t*>(r + at);
+  float4_t rv = *reinterpret_cast<const float4_t*>(r + at);
+  if (r_bias != nullptr) rv += *reinterpret_cast<const float4_t*>(r_bias + lane * 4);      // r = Linear output WITHOUT its bias
   const float4_t g = *reinterpret_cast<const float4_t*>(gamma + lane * 4);
   const float4_t b = *reinterpret_cast<const float4_t*>(beta + lane * 4);
   const float4_t z = an_residual(xv, rv, row, lane, threshold, scale, seed_lo, seed_hi);
@@ -91,18 +94,19 @@ add_dropout_layernorm_fwd_kernel(const float* __restrict__ x, const float* __res
   if (lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
 }
 
-// grad_x = dz, grad_r = keep * scale * dz, partial[block] = {sum_rows g * xhat, sum_rows g} over this workgroup's rows
+// grad_x = dz, grad_r = keep * scale * dz, partial[block] = {sum_rows g * xhat, sum_rows g, sum_rows grad_r} over this
+// workgroup's rows (the third row is the gradient of the bias folded into r, ABI 11)
 __global__ void __launch_bounds__(64 * kAnWaves)
 add_dropout_layernorm_bwd_kernel(const float* __restrict__ grad_y, const float* __restrict__ z,
                                  const float* __restrict__ stats, const float* __restrict__ gamma,
                                  float* __restrict__ grad_x, float* __restrict__ grad_r, float* __restrict__ partial,
                                  int64_t rows, uint32_t threshold, float scale, uint32_t seed_lo, uint32_t seed_hi,
                                  const unsigned long long* __restrict__ seed_device) {
-  __shared__ float4_t red[2][kAnWaves][64];
+  __shared__ float4_t red[kAnParts][kAnWaves][64];
   if (threshold != 0u) an_effective_seed(seed_lo, seed_hi, seed_device);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float4_t g = *reinterpret_cast<const float4_t*>(gamma + lane * 4);
-  float4_t dg = {0.f, 0.f, 0.f, 0.f}, db = dg;
+  float4_t dg = {0.f, 0.f, 0.f, 0.f}, db = dg, dbias = dg;
   for (int64_t row = int64_t(blockIdx.x) * kAnWaves + wave; row < rows; row += int64_t(gridDim.x) * kAnWaves) {
     const int64_t at = row * kAnC + lane * 4;
     const float4_t gy = *reinterpret_cast<const float4_t*>(grad_y + at);
@@ -125,16 +129,18 @@ add_dropout_layernorm_bwd_kernel(const float* __restrict__ grad_y, const float* 
       dr.z = an_hash(base + 2u, seed_lo, hi) >= threshold ? dz.z * scale : 0.f;
       dr.w = an_hash(base + 3u, seed_lo, hi) >= threshold ? dz.w * scale : 0.f;
     }
+    dbias += dr;
     __builtin_nontemporal_store(dr, reinterpret_cast<float4_t*>(grad_r + at));
   }
   red[0][wave][lane] = dg;
   red[1][wave][lane] = db;
+  red[2][wave][lane] = dbias;
   __syncthreads();
-  if (wave < 2) {      // wave 0 adds the gamma partials of the four waves, wave 1 the beta partials: fixed order
+  if (wave < kAnParts) {      // wave 0 adds the gamma partials of the four waves, wave 1 the beta partials, wave 2 the bias: fixed order
     float4_t s = red[wave][0][lane];
 #pragma unroll
     for (int w = 1; w < kAnWaves; ++w) s += red[wave][w][lane];
-    *reinterpret_cast<float4_t*>(partial + (int64_t(blockIdx.x) * 2 + wave) * kAnC + lane * 4) = s;
+    *reinterpret_cast<float4_t*>(partial + (int64_t(blockIdx.x) * kAnParts + wave) * kAnC + lane * 4) = s;
   }
 }
 
@@ -144,15 +150,17 @@ add_dropout_layernorm_bwd_kernel(const float* __restrict__ grad_y, const float* 
 // (Round 2's form walked all 1 024 partial rows with four chains per column on 4 workgroups: 122 us per call at the
 // encoder's 25 500 rows, seven times the backward kernel it finishes -- 30 calls per training step; rocprofv3,
 // profiles/r03_shapes.)
-constexpr int kPgBlocks = 16, kPgCols = 2 * kAnC / kPgBlocks, kPgSlices = 1024 / kPgCols;     // 16, 32, 32
+constexpr int kPgBlocks = 24, kPgCols = kAnParts * kAnC / kPgBlocks, kPgSlices = 1024 / kPgCols;     // 24, 32, 32
+static_assert(kPgCols * kPgBlocks == kAnParts * kAnC && kPgCols * kPgSlices == 1024, "whole columns, whole slices");
 __global__ void __launch_bounds__(1024)
 layernorm_param_grad_kernel(const float* __restrict__ partial, float* __restrict__ grad_gamma,
-                            float* __restrict__ grad_beta, int blocks) {
+                            float* __restrict__ grad_beta, float* __restrict__ grad_bias, int blocks) {
   __shared__ float red[kPgSlices][kPgCols];
   const int c = threadIdx.x % kPgCols, slice = threadIdx.x / kPgCols;
-  const int col = int(blockIdx.x) * kPgCols + c;                    // 0..511
+  const int col = int(blockIdx.x) * kPgCols + c;                    // 0..767: gamma | beta | bias
   float s = 0.f;
-  for (int b = slice; b < blocks; b += kPgSlices) s += partial[int64_t(b) * 2 * kAnC + col];
+  if (col < 2 * kAnC || grad_bias != nullptr)
+    for (int b = slice; b < blocks; b += kPgSlices) s += partial[int64_t(b) * kAnParts * kAnC + col];
   red[slice][c] = s;
   __syncthreads();
 #pragma unroll
@@ -161,7 +169,9 @@ layernorm_param_grad_kernel(const float* __restrict__ partial, float* __restrict
     __syncthreads();
   }
   if (slice == 0) {
-    if (col < kAnC) grad_gamma[col] = red[0][c]; else grad_beta[col - kAnC] = red[0][c];
+    if (col < kAnC) grad_gamma[col] = red[0][c];
+    else if (col < 2 * kAnC) grad_beta[col - kAnC] = red[0][c];
+    else if (grad_bias != nullptr) grad_bias[col - 2 * kAnC] = red[0][c];
   }
 }
 
@@ -184,9 +194,9 @@ static uint32_t an_threshold(float p) {      // keep iff hash >= threshold:  P(d
 
 using namespace vnx;
 
-extern "C" size_t vnx_add_dropout_layernorm_partial_bytes(void) { return size_t(kAnMaxBlocks) * 2 * kAnC * 4; }
+extern "C" size_t vnx_add_dropout_layernorm_partial_bytes(void) { return size_t(kAnMaxBlocks) * kAnParts * kAnC * 4; }
 
-extern "C" int vnx_add_dropout_layernorm_forward(int dtype, const void* x, const void* r, const void* gamma,
+extern "C" int vnx_add_dropout_layernorm_forward(int dtype, const void* x, const void* r, const void* r_bias, const void* gamma,
                                                  const void* beta, void* y, void* z, void* stats, long long rows,
                                                  int channels, float p, float eps, unsigned long long seed,
                                                  const unsigned long long* seed_device, void* hip_stream) {
@@ -198,15 +208,15 @@ extern "C" int vnx_add_dropout_layernorm_forward(int dtype, const void* x, const
   }
   const int64_t blocks = (rows + kAnWaves - 1) / kAnWaves;
   hipLaunchKernelGGL(add_dropout_layernorm_fwd_kernel, dim3(uint32_t(blocks)), dim3(64 * kAnWaves), 0,
-                     (hipStream_t)hip_stream, (const float*)x, (const float*)r, (const float*)gamma, (const float*)beta,
-                     (float*)y, (float*)z, (float*)stats, int64_t(rows), an_threshold(p), 1.f / (1.f - p), eps,
+                     (hipStream_t)hip_stream, (const float*)x, (const float*)r, (const float*)r_bias, (const float*)gamma,
+                     (const float*)beta, (float*)y, (float*)z, (float*)stats, int64_t(rows), an_threshold(p), 1.f / (1.f - p), eps,
                      uint32_t(seed), uint32_t(seed >> 32), seed_device);
   return check_launch("add_dropout_layernorm_fwd");
 }
 
 extern "C" int vnx_add_dropout_layernorm_backward(int dtype, const void* grad_y, const void* z, const void* stats,
                                                   const void* gamma, void* grad_x, void* grad_r, void* grad_gamma,
-                                                  void* grad_beta, void* partial, long long rows, int channels, float p,
+                                                  void* grad_beta, void* grad_r_bias, void* partial, long long rows, int channels, float p,
                                                   unsigned long long seed, const unsigned long long* seed_device,
                                                   void* hip_stream) {
   if (int st = an_check("vnx_add_dropout_layernorm_backward", dtype, rows, channels, p)) return st;
@@ -229,6 +239,6 @@ extern "C" int vnx_add_dropout_layernorm_backward(int dtype, const void* grad_y,
     blocks = 0;
   }
   hipLaunchKernelGGL(layernorm_param_grad_kernel, dim3(kPgBlocks), dim3(1024), 0, stream, (const float*)partial,
-                     (float*)grad_gamma, (float*)grad_beta, blocks);
+                     (float*)grad_gamma, (float*)grad_beta, (float*)grad_r_bias, blocks);
   return check_launch("add_dropout_layernorm_bwd");
 }

@@ -19,6 +19,7 @@ from torch import nn
 from torch.nn.init import constant_, normal_, xavier_uniform_
 
 from ..ops.functions import level_tensors
+from ..ops.fused_ffn import ffn_block
 from ..ops.fused_norm import add_dropout_norm
 from ..ops.modules import MSDeformAttnIDOL
 from .seqformer_transformer import DeformableTransformerEncoder as _ClipEncoder
@@ -42,8 +43,8 @@ class DeformableTransformerEncoderLayer(nn.Module):
         q = src if pos is None else src + pos
         src2 = self.self_attn(q, reference_points, src, spatial_shapes, level_start_index, padding_mask)[0]
         src = add_dropout_norm(src, src2, self.dropout1, self.norm1)
-        src2 = self.linear2(self.dropout2(self.activation(self.linear1(src))))
-        return add_dropout_norm(src, src2, self.dropout3, self.norm2)
+        # norm2(src + dropout3(linear2(dropout2(activation(linear1(src)))))) -- vnext_amd/ops/fused_ffn.py
+        return ffn_block(src, self.linear1, self.activation, self.dropout2, self.linear2, self.dropout3, self.norm2)
 
 
 class DeformableTransformerEncoder(nn.Module):
@@ -87,8 +88,7 @@ class DeformableTransformerDecoderLayer(nn.Module):
         tgt2, loc, w = self.cross_attn(tgt if query_pos is None else tgt + query_pos, reference_points, src,
                                        src_spatial_shapes, level_start_index, src_padding_mask)
         tgt = add_dropout_norm(tgt, tgt2, self.dropout1, self.norm1)
-        tgt2 = self.linear2(self.dropout3(self.activation(self.linear1(tgt))))
-        return add_dropout_norm(tgt, tgt2, self.dropout4, self.norm3), loc, w
+        return ffn_block(tgt, self.linear1, self.activation, self.dropout3, self.linear2, self.dropout4, self.norm3), loc, w
 
 
 class DeformableTransformerDecoder(nn.Module):

@@ -20,6 +20,7 @@ from torch import nn
 from torch.nn.init import constant_, normal_, xavier_uniform_
 
 from ..ops.functions import level_tensors
+from ..ops.fused_ffn import ffn_block
 from ..ops.fused_norm import add_dropout_norm
 from ..ops.modules import MSDeformAttnSeqFormer
 
@@ -65,8 +66,8 @@ class DeformableTransformerEncoderLayer(nn.Module):
         return tensor if pos is None else tensor + pos
 
     def forward_ffn(self, src):
-        src2 = self.linear2(self.dropout2(self.activation(self.linear1(src))))
-        return add_dropout_norm(src, src2, self.dropout3, self.norm2)
+        # src2 = linear2(dropout2(activation(linear1(src)))); norm2(src + dropout3(src2)) -- vnext_amd/ops/fused_ffn.py
+        return ffn_block(src, self.linear1, self.activation, self.dropout2, self.linear2, self.dropout3, self.norm2)
 
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None):
         src2 = self.self_attn(self.with_pos_embed(src, pos), None, reference_points, src, spatial_shapes,
@@ -140,12 +141,11 @@ class DeformableTransformerDecoderLayer(nn.Module):
         return tensor if pos is None else tensor + pos
 
     def forward_ffn(self, tgt):
-        tgt2 = self.linear2(self.dropout3(self.activation(self.linear1(tgt))))
-        return add_dropout_norm(tgt, tgt2, self.dropout4, self.norm3)
+        return ffn_block(tgt, self.linear1, self.activation, self.dropout3, self.linear2, self.dropout4, self.norm3)
 
     def forward_ffn_box(self, tgt):
-        tgt2 = self.linear2_box(self.dropout3_box(self.activation_box(self.linear1_box(tgt))))
-        return add_dropout_norm(tgt, tgt2, self.dropout4_box, self.norm3_box)
+        return ffn_block(tgt, self.linear1_box, self.activation_box, self.dropout3_box, self.linear2_box,
+                         self.dropout4_box, self.norm3_box)
 
     def forward(self, tgt, tgt_box, query_pos, reference_points, src, src_spatial_shapes, level_start_index,
                 src_padding_mask=None):

@@ -97,7 +97,7 @@ def _next_seed() -> int:
 
 class _AddDropoutLayerNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, r, gamma, beta, p, eps, seed, seed_tensor):
+    def forward(ctx, x, r, gamma, beta, p, eps, seed, seed_tensor, r_bias=None):
         lib = _lib.lib()
         x, r = x.contiguous(), r.contiguous()
         rows = x.numel() // CHANNELS
@@ -105,11 +105,12 @@ class _AddDropoutLayerNorm(torch.autograd.Function):
         stats = torch.empty(rows, 2, dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
             _lib.check(lib.vnx_add_dropout_layernorm_forward(
-                _lib.VNX_F32, x.data_ptr(), r.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), z.data_ptr(),
+                _lib.VNX_F32, x.data_ptr(), r.data_ptr(), r_bias.data_ptr() if r_bias is not None else None,
+                gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), z.data_ptr(),
                 stats.data_ptr(), rows, CHANNELS, float(p), float(eps), int(seed),
                 seed_tensor.data_ptr() if seed_tensor is not None else None, _lib.current_stream(x)))
         ctx.save_for_backward(z, stats, gamma)
-        ctx.p, ctx.seed, ctx.seed_tensor = float(p), int(seed), seed_tensor
+        ctx.p, ctx.seed, ctx.seed_tensor, ctx.has_bias = float(p), int(seed), seed_tensor, r_bias is not None
         return y
 
     @staticmethod
@@ -121,14 +122,16 @@ class _AddDropoutLayerNorm(torch.autograd.Function):
         rows = z.numel() // CHANNELS
         grad_x, grad_r = torch.empty_like(z), torch.empty_like(z)
         grad_gamma, grad_beta = torch.empty_like(gamma), torch.empty_like(gamma)
+        grad_bias = torch.empty_like(gamma) if ctx.has_bias else None      # the folded Linear bias: column sums of grad_r
         partial = torch.empty(lib.vnx_add_dropout_layernorm_partial_bytes(), dtype=torch.uint8, device=z.device)
         with torch.cuda.device(z.device):
             _lib.check(lib.vnx_add_dropout_layernorm_backward(
                 _lib.VNX_F32, grad_y.data_ptr(), z.data_ptr(), stats.data_ptr(), gamma.data_ptr(), grad_x.data_ptr(),
-                grad_r.data_ptr(), grad_gamma.data_ptr(), grad_beta.data_ptr(), partial.data_ptr(), rows, CHANNELS,
+                grad_r.data_ptr(), grad_gamma.data_ptr(), grad_beta.data_ptr(),
+                grad_bias.data_ptr() if grad_bias is not None else None, partial.data_ptr(), rows, CHANNELS,
                 ctx.p, ctx.seed, ctx.seed_tensor.data_ptr() if ctx.seed_tensor is not None else None,
                 _lib.current_stream(z)))
-        return grad_x, grad_r, grad_gamma, grad_beta, None, None, None, None
+        return grad_x, grad_r, grad_gamma, grad_beta, None, None, None, None, grad_bias
 
 
 def fused_applies(x, r, norm) -> bool:
@@ -138,17 +141,29 @@ def fused_applies(x, r, norm) -> bool:
             and not torch.is_autocast_enabled())
 
 
-def add_dropout_norm(x, r, dropout, norm, seed=None):
-    """`norm(x + dropout(r))` for an nn.Dropout and an nn.LayerNorm (see the module docstring)."""
-    if not fused_applies(x, r, norm):
-        return norm(x + dropout(r))
+def dropout_site(x, dropout):
+    """(p, seed_tensor, ok) for a fused dropout site on x's device: p = the module's drop probability (0 in eval mode);
+    under hipGraph capture with p > 0 the seed snapshot of the enclosing step_scope, and ok = False when there is none
+    (the caller must then fall back to the graph-safe nn.Dropout)."""
     p = dropout.p if dropout.training else 0.0
     if p >= 1.0:
-        return norm(x + dropout(r))
-    seed_tensor = None
+        return p, None, False
     if p > 0.0 and torch.cuda.is_current_stream_capturing():
-        seed_tensor = _scope_snapshot(x.device)
-        if seed_tensor is None:                  # nobody bumps a step seed in this capture: stay graph-safe
-            return norm(x + dropout(r))
+        snap = _scope_snapshot(x.device)
+        return p, snap, snap is not None
+    return p, None, True
+
+
+def add_dropout_norm(x, r, dropout, norm, seed=None, r_bias=None):
+    """`norm(x + dropout(r))` for an nn.Dropout and an nn.LayerNorm (see the module docstring).  r_bias: the bias of the
+    Linear that produced r, when the caller ran that GEMM without it (`norm(x + dropout(r + r_bias))`): its gradient then
+    comes out of this op's backward instead of a separate reduction launch."""
+    def reference():
+        return norm(x + dropout(r if r_bias is None else r + r_bias))
+    if not fused_applies(x, r, norm) or (r_bias is not None and (r_bias.dtype != torch.float32 or r_bias.numel() != CHANNELS)):
+        return reference()
+    p, seed_tensor, ok = dropout_site(x, dropout)
+    if not ok:
+        return reference()
     return _AddDropoutLayerNorm.apply(x, r, norm.weight, norm.bias, p, norm.eps, _next_seed() if seed is None else seed,
-                                      seed_tensor)
+                                      seed_tensor, r_bias.contiguous() if r_bias is not None else None)
