@@ -324,22 +324,28 @@ int vnx_add_dropout_layernorm_backward(int dtype, const void* grad_y, const void
                                        const unsigned long long* seed_device, void* hip_stream);
 
 /*
- * The middle of a transformer FFN, y = dropout(relu(h + bias)), IN PLACE over h [rows, channels] fp32 (channels a multiple
- * of 4, <= 4 096), and its backward (projects/SeqFormer/seqformer/models/deformable_transformer.py:226-229,330-338:
- * `self.dropout2(self.activation(self.linear1(src)))` -- relu, dropout and, in the backward, masked_scale,
- * threshold_backward and linear1's bias-gradient reduction: five ATen launches and 11.5 passes over the hidden tensor;
- * here two launches + a 32-workgroup reduction and 2 passes).  bias (may be null): added before the ReLU -- run the GEMM
- * without it.  Dropout as in vnx_add_dropout_layernorm_* (hash of (seed, element), seed_device for captured graphs).
- * Backward: grad_h = y > 0 ? grad / (1 - p) : 0 -- y, the forward's output, is all it needs (y > 0 <=> the element
- * passed the ReLU and was kept); grad_h may be the same buffer as grad -- and grad_bias [channels] = the column sums of
- * grad_h (may be null; partial: scratch of vnx_bias_relu_dropout_partial_bytes(channels) bytes, needed with grad_bias;
- * fixed summation order).
+ * Bias / activation epilogues of a library GEMM that ran WITHOUT its bias, IN PLACE over h [rows, channels] fp32
+ * (channels a multiple of 4, <= 4 096), with the bias gradient produced by the backward pass itself:
+ *   relu != 0: y = dropout(relu(h + bias)) -- the middle of a transformer FFN
+ *     (projects/SeqFormer/seqformer/models/deformable_transformer.py:226-229,330-338: relu, dropout and, in the backward,
+ *     masked_scale, threshold_backward and linear1's bias-gradient reduction: five ATen launches and 11.5 passes over the
+ *     hidden tensor; here two launches + a small reduction and 2 + 3 passes);
+ *   relu == 0 (p must be 0): y = h + bias.
+ *   row_zero (may be null): one byte per row; rows with a non-zero byte are written as zeros -- the padding mask of
+ *     `value = value_proj(x).masked_fill(mask[..., None], 0)` (projects/SeqFormer/seqformer/models/ops/modules/ms_deform_attn.py:94-96),
+ *     which ATen runs as a copy + a fill forward and again backward, plus the bias reduction.
+ * bias may be null.  Dropout as in vnx_add_dropout_layernorm_* (hash of (seed, element), seed_device for captured graphs).
+ * Backward: grad_h = grad where the row is kept (and, with the ReLU, where y > 0, times 1 / (1 - p): y > 0 <=> the
+ * element passed the ReLU and was kept, so y -- the forward's output -- is all it needs; y = null when relu == 0);
+ * grad_h may be the same buffer as grad.  grad_bias [channels] = the column sums of grad_h (may be null; partial: scratch
+ * of vnx_bias_relu_dropout_partial_bytes(channels) bytes, needed with grad_bias; fixed summation order).
  */
 size_t vnx_bias_relu_dropout_partial_bytes(int channels);
-int vnx_bias_relu_dropout_forward(int dtype, void* h, const void* bias, long long rows, int channels, float p,
-                                  unsigned long long seed, const unsigned long long* seed_device, void* hip_stream);
-int vnx_bias_relu_dropout_backward(int dtype, const void* grad, const void* y, void* grad_h, void* grad_bias, void* partial,
-                                   long long rows, int channels, float p, void* hip_stream);
+int vnx_bias_relu_dropout_forward(int dtype, void* h, const void* bias, const unsigned char* row_zero, long long rows,
+                                  int channels, int relu, float p, unsigned long long seed,
+                                  const unsigned long long* seed_device, void* hip_stream);
+int vnx_bias_relu_dropout_backward(int dtype, const void* grad, const void* y, const unsigned char* row_zero, void* grad_h,
+                                   void* grad_bias, void* partial, long long rows, int channels, float p, void* hip_stream);
 
 /* (The kernel-variant override of rounds 1-3 -- a process-wide A/B knob -- is no longer part of this library: it lives in
  *  the development build only, include/vnext_hip_dev.h.  Every call here selects its kernels from its own arguments.) */

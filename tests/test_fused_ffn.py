@@ -6,7 +6,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from vnext_amd.ops.fused_ffn import _BiasReluDropout, ffn_block, fused_applies
+from vnext_amd.ops.fused_ffn import _BiasReluDropout, ffn_block, fused_applies, linear_masked
 from vnext_amd.ops.fused_norm import add_dropout_norm
 
 DEV = "cuda:0"
@@ -156,3 +156,38 @@ def test_training_mode_block_drops_at_both_sites_and_stays_finite():
         m.eval()
     base = ffn_block(x, l1, F.relu, d_mid, l2, d_out, norm)
     assert float((y1 - base).abs().mean()) < 0.5
+
+
+def test_linear_masked_on_cpu_is_the_expression():
+    lin = torch.nn.Linear(256, 256)
+    x = torch.randn(2, 3, 50, 256)
+    mask = torch.rand(2, 3, 50) < 0.2
+    assert torch.equal(linear_masked(x, lin, mask), lin(x).masked_fill(mask[..., None], 0.0))
+    assert torch.equal(linear_masked(x, lin, None), lin(x))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 5, 5100), (3, 77)])
+def test_linear_masked_forward_and_gradients(shape):
+    """value = value_proj(x).masked_fill(mask[..., None], 0) (ms_deform_attn.py:94-96): forward, grad_x, grad_W and the
+    bias gradient that comes out of the masking pass, against fp64 autograd through the expression itself."""
+    torch.manual_seed(1)
+    lin = torch.nn.Linear(256, 256).to(DEV)
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(*shape, 256, generator=g).to(DEV).requires_grad_(True)
+    mask = (torch.rand(*shape, generator=g) < 0.15).to(DEV)
+    mask[..., -3:] = True                                   # a padded tail, as the 384-row frames of a 360p clip have
+    y = linear_masked(x, lin, mask)
+    assert bool((y[mask] == 0).all())
+    go = torch.randn(*shape, 256, generator=g).to(DEV)
+    y.backward(go)
+    ld = torch.nn.Linear(256, 256).to(DEV).double()
+    ld.load_state_dict({k: v.double() for k, v in lin.state_dict().items()})
+    xd = x.detach().double().requires_grad_(True)
+    want = ld(xd).masked_fill(mask[..., None], 0.0)
+    want.backward(go.double())
+    torch.testing.assert_close(y.double(), want, rtol=0, atol=3e-6 * float(want.detach().abs().max()))
+    for got, ref in ((x.grad, xd.grad), (lin.weight.grad, ld.weight.grad), (lin.bias.grad, ld.bias.grad)):
+        torch.testing.assert_close(got.double(), ref, rtol=0, atol=2e-5 * float(ref.abs().max()))
+    with torch.no_grad():                                    # inference: same values, nothing recorded
+        torch.testing.assert_close(linear_masked(x.detach(), lin, mask), y.detach(), rtol=0, atol=0)

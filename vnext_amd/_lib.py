@@ -46,8 +46,8 @@ SIGNATURES = {
     "vnx_add_dropout_layernorm_forward": (_i, [_i] + [_vp] * 8 + [_ll, _i, ctypes.c_float, ctypes.c_float, ctypes.c_ulonglong, _vp, _vp]),
     "vnx_add_dropout_layernorm_backward": (_i, [_i] + [_vp] * 10 + [_ll, _i, ctypes.c_float, ctypes.c_ulonglong, _vp, _vp]),
     "vnx_bias_relu_dropout_partial_bytes": (_sz, [_i]),
-    "vnx_bias_relu_dropout_forward": (_i, [_i, _vp, _vp, _ll, _i, ctypes.c_float, ctypes.c_ulonglong, _vp, _vp]),
-    "vnx_bias_relu_dropout_backward": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _ll, _i, ctypes.c_float, _vp]),
+    "vnx_bias_relu_dropout_forward": (_i, [_i, _vp, _vp, _vp, _ll, _i, _i, ctypes.c_float, ctypes.c_ulonglong, _vp, _vp]),
+    "vnx_bias_relu_dropout_backward": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, ctypes.c_float, _vp]),
 }
 # measurement aids of include/vnext_hip_debug.h (bench.py, tools/): not part of the drop-in boundary
 DEBUG_SIGNATURES = {

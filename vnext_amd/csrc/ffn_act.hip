@@ -43,17 +43,21 @@ __device__ __forceinline__ void fa_effective_seed(uint32_t& lo, uint32_t& hi, co
 // in place over h [rows, cols]; thread = 4 consecutive columns (blockIdx.x * 256 + threadIdx.x), rows blockIdx.y,
 // blockIdx.y + gridDim.y, ...: no division anywhere, the bias quad is loaded once per thread
 __global__ void __launch_bounds__(256)
-bias_relu_dropout_fwd_kernel(float* __restrict__ h, const float* __restrict__ bias, int64_t rows, int cols4,
-                             uint32_t threshold, float scale, uint32_t seed_lo, uint32_t seed_hi,
-                             const unsigned long long* __restrict__ seed_device) {
+bias_relu_dropout_fwd_kernel(float* __restrict__ h, const float* __restrict__ bias, const uint8_t* __restrict__ row_zero,
+                             int64_t rows, int cols4, int relu, uint32_t threshold, float scale, uint32_t seed_lo,
+                             uint32_t seed_hi, const unsigned long long* __restrict__ seed_device) {
   const int c4 = int(blockIdx.x) * 256 + int(threadIdx.x);
   if (c4 >= cols4) return;
   if (threshold != 0u) fa_effective_seed(seed_lo, seed_hi, seed_device);
   const ffn_f4 b = bias != nullptr ? *reinterpret_cast<const ffn_f4*>(bias + c4 * 4) : ffn_f4{0.f, 0.f, 0.f, 0.f};
   for (int64_t row = blockIdx.y; row < rows; row += gridDim.y) {
     const int64_t i = row * cols4 + c4;                                // float4 index
+    if (row_zero != nullptr && row_zero[row]) {                        // a padding row: zeros, whatever h holds (masked_fill)
+      *reinterpret_cast<ffn_f4*>(h + i * 4) = ffn_f4{0.f, 0.f, 0.f, 0.f};
+      continue;
+    }
     ffn_f4 v = *reinterpret_cast<const ffn_f4*>(h + i * 4) + b;
-    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
     if (threshold != 0u) {
       const uint32_t base = uint32_t(i) * 4u;                          // element index mod 2^32 ...
       const uint32_t hi = seed_hi ^ uint32_t(uint64_t(i) >> 30);       // ... and what lies above it
@@ -70,18 +74,21 @@ bias_relu_dropout_fwd_kernel(float* __restrict__ h, const float* __restrict__ bi
 // columns 4t..4t+3, a workgroup (cols / 4 threads) walks the rows blockIdx.x, blockIdx.x + gridDim.x, ...;
 // partial[blockIdx.x][cols] = this workgroup's column sums
 __global__ void __launch_bounds__(1024)
-bias_relu_dropout_bwd_kernel(const float* g, const float* __restrict__ y, float* out, float* __restrict__ partial,
-                             int64_t rows, int cols, float scale) {
+bias_relu_dropout_bwd_kernel(const float* g, const float* __restrict__ y, const uint8_t* __restrict__ row_zero, float* out,
+                             float* __restrict__ partial, int64_t rows, int cols, float scale) {
   const int c = int(threadIdx.x) * 4;
   ffn_f4 acc = {0.f, 0.f, 0.f, 0.f};
   for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
     const int64_t at = row * cols + c;
-    const ffn_f4 yv = *reinterpret_cast<const ffn_f4*>(y + at);
     ffn_f4 gv = *reinterpret_cast<const ffn_f4*>(g + at);
-    gv.x = yv.x > 0.f ? gv.x * scale : 0.f;
-    gv.y = yv.y > 0.f ? gv.y * scale : 0.f;
-    gv.z = yv.z > 0.f ? gv.z * scale : 0.f;
-    gv.w = yv.w > 0.f ? gv.w * scale : 0.f;
+    if (row_zero != nullptr && row_zero[row]) gv = ffn_f4{0.f, 0.f, 0.f, 0.f};
+    if (y != nullptr) {                         // ReLU (+ dropout): y > 0 <=> passed and kept
+      const ffn_f4 yv = *reinterpret_cast<const ffn_f4*>(y + at);
+      gv.x = yv.x > 0.f ? gv.x * scale : 0.f;
+      gv.y = yv.y > 0.f ? gv.y * scale : 0.f;
+      gv.z = yv.z > 0.f ? gv.z * scale : 0.f;
+      gv.w = yv.w > 0.f ? gv.w * scale : 0.f;
+    }
     acc += gv;
     *reinterpret_cast<ffn_f4*>(out + at) = gv;
   }
@@ -137,10 +144,14 @@ extern "C" size_t vnx_bias_relu_dropout_partial_bytes(int channels) {
   return size_t(kFaMaxBlocks) * size_t(channels > 0 ? channels : 0) * sizeof(float);
 }
 
-extern "C" int vnx_bias_relu_dropout_forward(int dtype, void* h, const void* bias, long long rows, int channels, float p,
-                                             unsigned long long seed, const unsigned long long* seed_device,
-                                             void* hip_stream) {
+extern "C" int vnx_bias_relu_dropout_forward(int dtype, void* h, const void* bias, const unsigned char* row_zero, long long rows,
+                                             int channels, int relu, float p, unsigned long long seed,
+                                             const unsigned long long* seed_device, void* hip_stream) {
   if (int st = fa_check("vnx_bias_relu_dropout_forward", dtype, rows, channels, p)) return st;
+  if (!relu && p > 0.f) {
+    set_error("vnx_bias_relu_dropout_forward: dropout without the ReLU is not built (the backward reads the mask off y > 0)");
+    return VNX_ERR_UNSUPPORTED;
+  }
   if (rows == 0) return VNX_OK;
   if (!h) {
     set_error("vnx_bias_relu_dropout_forward: null pointer argument");
@@ -149,13 +160,14 @@ extern "C" int vnx_bias_relu_dropout_forward(int dtype, void* h, const void* bia
   const int cols4 = channels / 4;
   const dim3 grid(uint32_t((cols4 + 255) / 256), uint32_t(std::min<int64_t>(rows, 16384)));
   hipLaunchKernelGGL(bias_relu_dropout_fwd_kernel, grid, dim3(256), 0, (hipStream_t)hip_stream, (float*)h,
-                     (const float*)bias, int64_t(rows), channels / 4, fa_threshold(p), 1.f / (1.f - p), uint32_t(seed),
-                     uint32_t(seed >> 32), seed_device);
+                     (const float*)bias, (const uint8_t*)row_zero, int64_t(rows), channels / 4, relu, fa_threshold(p),
+                     1.f / (1.f - p), uint32_t(seed), uint32_t(seed >> 32), seed_device);
   return check_launch("bias_relu_dropout_fwd");
 }
 
-extern "C" int vnx_bias_relu_dropout_backward(int dtype, const void* grad, const void* y, void* grad_h, void* grad_bias,
-                                              void* partial, long long rows, int channels, float p, void* hip_stream) {
+extern "C" int vnx_bias_relu_dropout_backward(int dtype, const void* grad, const void* y, const unsigned char* row_zero,
+                                              void* grad_h, void* grad_bias, void* partial, long long rows, int channels,
+                                              float p, void* hip_stream) {
   if (int st = fa_check("vnx_bias_relu_dropout_backward", dtype, rows, channels, p)) return st;
   if (grad_bias && !partial) {
     set_error("vnx_bias_relu_dropout_backward: grad_bias needs the partial scratch (vnx_bias_relu_dropout_partial_bytes)");
@@ -164,13 +176,13 @@ extern "C" int vnx_bias_relu_dropout_backward(int dtype, const void* grad, const
   hipStream_t stream = (hipStream_t)hip_stream;
   int blocks = int(std::min<int64_t>(kFaMaxBlocks, rows));
   if (rows > 0) {
-    if (!grad || !y || !grad_h) {
+    if (!grad || !grad_h || (!y && p > 0.f)) {      // y == null: the forward ran without the ReLU
       set_error("vnx_bias_relu_dropout_backward: null pointer argument");
       return VNX_ERR_INVALID_ARGUMENT;
     }
     hipLaunchKernelGGL(bias_relu_dropout_bwd_kernel, dim3(uint32_t(blocks)), dim3(channels / 4), 0, stream, (const float*)grad,
-                       (const float*)y, (float*)grad_h, grad_bias ? (float*)partial : (float*)nullptr, int64_t(rows), channels,
-                       1.f / (1.f - p));
+                       (const float*)y, (const uint8_t*)row_zero, (float*)grad_h, grad_bias ? (float*)partial : (float*)nullptr,
+                       int64_t(rows), channels, 1.f / (1.f - p));
   } else {
     blocks = 0;
   }

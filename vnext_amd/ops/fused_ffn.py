@@ -27,6 +27,8 @@ reference expression, evaluated by torch.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -35,43 +37,73 @@ from . import fused_norm
 from .fused_norm import add_dropout_norm, dropout_site
 
 MAX_CHANNELS = 4096
+# A/B switches (tools/time_fusions.py; VNX_FUSED_FFN=0 / VNX_FUSED_MASKED_LINEAR=0 in the environment): off = the reference
+# expressions, evaluated by torch
+ENABLE_FFN = os.environ.get("VNX_FUSED_FFN", "1") != "0"
+ENABLE_MASKED_LINEAR = os.environ.get("VNX_FUSED_MASKED_LINEAR", "1") != "0"
 
 
 class _BiasReluDropout(torch.autograd.Function):
-    """a = dropout(relu(h + bias)) in place over h (h is the GEMM's fresh output: nobody else holds it); backward:
-    grad_h (a new tensor: autograd's gradient buffers are not ours to overwrite) and grad_bias, in one pass."""
+    """a = dropout(relu(h + bias)) (relu=True) or h + bias (relu=False, p = 0), rows flagged in row_zero written as zeros,
+    in place over h (h is the GEMM's fresh output: nobody else holds it); backward: grad_h (a new tensor: autograd's
+    gradient buffers are not ours to overwrite) and grad_bias, in one pass."""
 
     @staticmethod
-    def forward(ctx, h, bias, p, seed, seed_tensor):
+    def forward(ctx, h, bias, p, seed, seed_tensor, relu=True, row_zero=None):
         lib = _lib.lib()
-        assert h.is_contiguous()
+        assert h.is_contiguous() and (relu or p == 0.0)
         rows, cols = h.numel() // h.shape[-1], h.shape[-1]
         with torch.cuda.device(h.device):
             _lib.check(lib.vnx_bias_relu_dropout_forward(
-                _lib.VNX_F32, h.data_ptr(), bias.data_ptr() if bias is not None else None, rows, cols, float(p), int(seed),
+                _lib.VNX_F32, h.data_ptr(), bias.data_ptr() if bias is not None else None,
+                row_zero.data_ptr() if row_zero is not None else None, rows, cols, int(bool(relu)), float(p), int(seed),
                 seed_tensor.data_ptr() if seed_tensor is not None else None, _lib.current_stream(h)))
         ctx.mark_dirty(h)
-        ctx.save_for_backward(h)
-        ctx.p, ctx.has_bias = float(p), bias is not None
+        ctx.save_for_backward(*((h,) if relu else ()), *((row_zero,) if row_zero is not None else ()))
+        ctx.p, ctx.has_bias, ctx.relu, ctx.masked = float(p), bias is not None, bool(relu), row_zero is not None
+        ctx.cols = cols
         return h
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, grad):
         lib = _lib.lib()
-        (y,) = ctx.saved_tensors
+        saved = list(ctx.saved_tensors)
+        y = saved.pop(0) if ctx.relu else None
+        row_zero = saved.pop(0) if ctx.masked else None
         grad = grad.contiguous()
         grad_h = torch.empty_like(grad)
-        rows, cols = y.numel() // y.shape[-1], y.shape[-1]
-        grad_bias = torch.empty(cols, dtype=torch.float32, device=y.device) if ctx.has_bias else None
-        partial = torch.empty(lib.vnx_bias_relu_dropout_partial_bytes(cols), dtype=torch.uint8, device=y.device) \
+        cols = ctx.cols
+        rows = grad.numel() // cols
+        grad_bias = torch.empty(cols, dtype=torch.float32, device=grad.device) if ctx.has_bias else None
+        partial = torch.empty(lib.vnx_bias_relu_dropout_partial_bytes(cols), dtype=torch.uint8, device=grad.device) \
             if ctx.has_bias else None
-        with torch.cuda.device(y.device):
+        with torch.cuda.device(grad.device):
             _lib.check(lib.vnx_bias_relu_dropout_backward(
-                _lib.VNX_F32, grad.data_ptr(), y.data_ptr(), grad_h.data_ptr(),
+                _lib.VNX_F32, grad.data_ptr(), y.data_ptr() if y is not None else None,
+                row_zero.data_ptr() if row_zero is not None else None, grad_h.data_ptr(),
                 grad_bias.data_ptr() if grad_bias is not None else None,
-                partial.data_ptr() if partial is not None else None, rows, cols, ctx.p, _lib.current_stream(y)))
-        return grad_h, grad_bias, None, None, None
+                partial.data_ptr() if partial is not None else None, rows, cols, ctx.p, _lib.current_stream(grad)))
+        return grad_h, grad_bias, None, None, None, None, None
+
+
+def linear_masked(x, linear, row_mask):
+    """`linear(x).masked_fill(row_mask[..., None], 0)` -- the value projection of MSDeformAttn with its padding mask
+    (projects/SeqFormer/seqformer/models/ops/modules/ms_deform_attn.py:94-96) -- as one GEMM without bias + ONE in-place
+    pass (bias add, padding rows zeroed); the backward zeroes the padding rows of the gradient and sums linear's bias
+    gradient in the same pass.  ATen: GEMM, copy + fill, and copy + fill + a reduction launch backward.  row_mask: bool
+    [..., rows] or None.  Falls back to the expression itself where the kernels do not apply."""
+    def reference():
+        out = linear(x)
+        return out if row_mask is None else out.masked_fill(row_mask[..., None], float(0))
+    ok = (x.is_cuda and x.dtype == torch.float32 and linear.weight.dtype == torch.float32 and linear.bias is not None
+          and not torch.is_autocast_enabled() and linear.out_features % 4 == 0 and linear.out_features <= MAX_CHANNELS
+          and (row_mask is None or (row_mask.dtype == torch.bool and row_mask.shape == x.shape[:-1])))
+    if not ok or row_mask is None or not ENABLE_MASKED_LINEAR:       # without a mask the GEMM's own bias epilogue is the cheaper form
+        return reference()
+    h = F.linear(x, linear.weight)
+    rz = row_mask.contiguous().view(torch.uint8) if row_mask is not None else None
+    return _BiasReluDropout.apply(h, linear.bias, 0.0, 0, None, False, rz)
 
 
 def fused_applies(x, linear1, linear2, norm, activation) -> bool:
@@ -88,7 +120,7 @@ def ffn_block(x, linear1, activation, dropout_mid, linear2, dropout_out, norm):
     """`norm(x + dropout_out(linear2(dropout_mid(activation(linear1(x))))))` (see the module docstring)."""
     def reference():
         return add_dropout_norm(x, linear2(dropout_mid(activation(linear1(x)))), dropout_out, norm)
-    if not fused_applies(x, linear1, linear2, norm, activation):
+    if not ENABLE_FFN or not fused_applies(x, linear1, linear2, norm, activation):
         return reference()
     p_mid, seed_mid, ok = dropout_site(x, dropout_mid)
     if not ok:

@@ -92,7 +92,8 @@ def _scope_snapshot(device):
 def _next_seed() -> int:
     global _calls
     _calls += 1
-    return (torch.initial_seed() * 0x9E3779B97F4A7C15 + _calls * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+    # 63 bits: torch.profiler(record_shapes=True) converts Function.apply's integer arguments to int64
+    return (torch.initial_seed() * 0x9E3779B97F4A7C15 + _calls * 0xD1B54A32D192ED03) & 0x7FFFFFFFFFFFFFFF
 
 
 class _AddDropoutLayerNorm(torch.autograd.Function):

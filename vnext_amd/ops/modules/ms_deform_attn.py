@@ -27,6 +27,7 @@ from torch import nn
 from torch.nn.init import constant_, xavier_uniform_
 
 from ... import msda_ext
+from ..fused_ffn import linear_masked
 from ..functions import MSDeformAttnFunction, MSDeformAttnFusedFunction, check_flattened_length
 
 
@@ -104,10 +105,9 @@ class _MSDeformAttnBase(nn.Module):
 
     # -- shared pieces ------------------------------------------------------------------------
     def _project_value(self, input_flatten, input_padding_mask):
-        value = self.value_proj(input_flatten)
-        if input_padding_mask is not None:
-            value = value.masked_fill(input_padding_mask[..., None], float(0))
-        return value
+        # value = self.value_proj(input_flatten); value.masked_fill(input_padding_mask[..., None], 0)  (SeqFormer :94-96):
+        # one GEMM + one in-place pass on the GPU (vnext_amd/ops/fused_ffn.py), the expression itself elsewhere
+        return linear_masked(input_flatten, self.value_proj, input_padding_mask)
 
     def _offsets_and_weights(self, query):
         lead = query.shape[:-1]
