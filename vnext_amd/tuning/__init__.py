@@ -9,7 +9,8 @@ the tuned solution takes 197 -- and the training step of SeqFormer-R50 (two clip
 library default, nothing is ever timed at run time.  TunableOp itself refuses the file when the PyTorch / ROCm / hipBLASLt
 / rocBLAS versions or the GPU architecture differ from the ones it was recorded with (the `Validator` rows).
 
-Only fp32 entries are recorded: the bf16 tuning pass faulted inside a hipBLASLt candidate on this stack (round 4).
+Only fp32 entries are recorded: the bf16 tuning pass took a GPU memory-access fault inside a library candidate on this
+stack, with and without the hipBLASLt candidates (two attempts, round 4).
 """
 from __future__ import annotations
 
