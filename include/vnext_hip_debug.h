@@ -39,9 +39,11 @@ int vnx_debug_row_gather_probe(const void* rows, size_t n_rows, const uint32_t* 
  * msda_d32_gvtiles.hip): the launcher sizes the grid from the pixel count alone, the kernel derives the units from the
  * level shapes on the device -- the sum of the latter must never pass the former, or a unit's rows would be lost.
  * host_shapes: [levels][2] = (H, W) in HOST memory.  Writes the workgroups per (batch, head) the kernel will use and
- * the launcher's bound; 0 on success.  No GPU needed (tests/test_units_bound.py). */
+ * the launcher's bound, and (either may be null) the fp32 partial rows per (batch, head) the query pieces of the split
+ * levels store and the slab size the workspace reserves for them (gv_partial_rows_bound: a piece past its slab would
+ * write into the next (batch, head)'s); 0 on success.  No GPU needed (tests/test_units_bound.py). */
 int vnx_debug_gvtiles_units(const int64_t* host_shapes, int levels, int num_query, int batch, int heads, int units_min,
-                            int* units_used, int* units_bound);
+                            int* units_used, int* units_bound, long long* partial_rows_used, long long* partial_rows_bound);
 
 #ifdef __cplusplus
 }

@@ -13,8 +13,13 @@ from vnext_amd import _lib
 def used_and_bound(shapes, Lq, B, M, units_min=2):
     arr = np.asarray(shapes, dtype=np.int64)
     used, bound = ctypes.c_int(), ctypes.c_int()
-    rc = _lib.lib().vnx_debug_gvtiles_units(arr.ctypes.data, len(shapes), Lq, B, M, units_min, ctypes.byref(used), ctypes.byref(bound))
+    rows, rows_bound = ctypes.c_longlong(), ctypes.c_longlong()
+    rc = _lib.lib().vnx_debug_gvtiles_units(arr.ctypes.data, len(shapes), Lq, B, M, units_min, ctypes.byref(used), ctypes.byref(bound),
+                                            ctypes.byref(rows), ctypes.byref(rows_bound))
     assert rc == 0
+    # round 4: the query pieces of the split levels store fp32 partial rows into a slab per (batch, head) whose size the host
+    # derives from S and L alone (gv_partial_rows_bound): a piece past its slab would write into the next (batch, head)'s
+    assert 0 <= rows.value <= rows_bound.value, (shapes, Lq, B, units_min, rows.value, rows_bound.value)
     return used.value, bound.value
 
 
@@ -41,3 +46,15 @@ def test_random_pyramids_never_pass_the_bound(seed):
         um = rnd.choice([1, 2, 3, 16])
         used, bound = used_and_bound(shapes, Lq, B, M, um)
         assert used <= bound, (shapes, Lq, B, um, used, bound)
+
+
+def test_degenerate_levels_keep_their_partial_rows_inside_the_slab():
+    """flat, one-row, one-pixel and equal-sized levels, with every query count around the split threshold"""
+    cases = [[(1, 1)] * 4, [(1, 1024)] * 4, [(1024, 1)] * 4, [(16, 64)] * 4, [(8, 128), (4, 256), (2, 512), (1, 1024)],
+             [(3, 300), (300, 3), (1, 70000), (7, 7)], [(32, 32), (31, 33), (1, 1), (2, 1000)]]
+    for shapes in cases:
+        S = sum(h * w for h, w in shapes)
+        for Lq in (1023, 1024, S, 5 * S + 7, 1 << 20):
+            for B, M in ((1, 1), (1, 8), (4, 8), (64, 8)):
+                for um in (1, 2, 16):
+                    used_and_bound(shapes, Lq, B, M, um)

@@ -583,19 +583,24 @@ int vnx_msda_fused_backward(int value_dtype, int query_dtype, const void* value,
 // ---- unit grid of the tile-fed grad_value kernel, seen from the host (include/vnext_hip_debug.h) -----------
 namespace vnx { int msda_gvtiles_units_bound(const MsdaDims& d, int units_min); }
 extern "C" int vnx_debug_gvtiles_units(const int64_t* host_shapes, int levels, int num_query, int batch, int heads,
-                                       int units_min, int* units_used, int* units_bound) {
+                                       int units_min, int* units_used, int* units_bound, long long* partial_rows_used,
+                                       long long* partial_rows_bound) {
   if (!host_shapes || levels <= 0 || !units_used || !units_bound) return VNX_ERR_INVALID_ARGUMENT;
-  int64_t S = 0;
+  int64_t S = 0, rows = 0;
   int used = 0;
   for (int l = 0; l < levels; ++l) {
     const int H = int(host_shapes[2 * l]), W = int(host_shapes[2 * l + 1]);
     S += int64_t(H) * W;
     const int units = gv_level_units(H, W, units_min, true);
-    used += units * gv_query_splits(units, num_query, 4, true, batch * heads);     // the kernel's level table, fp32 case
+    const int qs = gv_query_splits(units, num_query, 4, true, batch * heads);      // the kernel's level table
+    used += units * qs;
+    if (qs > 1) rows += int64_t(qs) * H * W;      // the partial rows the level's query pieces store (gv_partial_rows_bound)
   }
   const MsdaDims d{batch, int(S), heads, 32, levels, num_query, 4};
   *units_used = used;
   *units_bound = vnx::msda_gvtiles_units_bound(d, units_min);
+  if (partial_rows_used) *partial_rows_used = rows;
+  if (partial_rows_bound) *partial_rows_bound = gv_partial_rows_bound(int(S), levels);
   return VNX_OK;
 }
 
