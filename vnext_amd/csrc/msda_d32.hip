@@ -1229,9 +1229,17 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
           const TL* rf = static_cast<const TL*>(fa.reference) + ((int64_t(b / fa.ref_div) * d.Lq + q3) * d.L + l) * 4;
           sx = to_acc(rf[2]) * 0.5f / float(d.P); sy = to_acc(rf[3]) * 0.5f / float(d.P);
         }
+#if VNX_K1_P3 >= 2 && !defined(VNX_K1_P3F_PLAIN)      // as in the unfused branch: one 8-byte store per (x, y), both gradients `nt`
+        if constexpr (sizeof(TL) == 4) {
+          __builtin_nontemporal_store(float2_t{gx * sx, gy * sy}, reinterpret_cast<float2_t*>(grad_loc + 2 * wi));
+          __builtin_nontemporal_store(a * (r.z - dot), reinterpret_cast<float*>(grad_attn + wi));
+        } else
+#endif
+        {
         store_loc<TL>(grad_loc + 2 * wi, gx * sx);
         store_loc<TL>(grad_loc + 2 * wi + 1, gy * sy);
         store_loc<TL>(grad_attn + wi, a * (r.z - dot));
+        }
         if (fa.grad_reference != nullptr) {
           float rx = gx, ry = gy;
           for (int k = 1; k < d.P; k <<= 1) { rx += __shfl_xor(rx, k, 16); ry += __shfl_xor(ry, k, 16); }
