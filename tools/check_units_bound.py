@@ -4,7 +4,7 @@ a level of H x W pixels is cut by gv_level_grid (vnx_common.h; restated here wit
 import numpy as np
 
 
-def units(H, W, um, rows_max=256, minw=64, bw0=32):
+def units(H, W, um, rows_max=256, minw=32, bw0=32):
     W = W.astype(np.int64)
     narrow = W < minw
     target = np.where(H >= rows_max // bw0, bw0, rows_max // max(H, 1))

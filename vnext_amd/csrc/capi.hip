@@ -114,8 +114,15 @@ static int check_common(const char* fn, int vdt, int ldt, const void* value,
 using namespace vnx;
 
 namespace vnx {
+// Units per level at least, tile-fed path.  1 since round 4: a level that fits one unit (<= 256 pixels: the coarsest level of
+// both pyramids, and the 240-pixel level of 360p) is ONE rectangle cut into query pieces, not two half-rectangles that each
+// scan and decode every tile of the level -- with the pieces meeting in partial rows instead of atomics the second row-unit
+// buys nothing and costs the level's reads twice: encoder backward 166.5 -> 163.2 us at 360p, 622 -> 611 us at 720p B = 5
+// (720p B = 2: 271.4 / 272.1, unchanged).  (Round 3 measured 2 against 1 as 175.2 vs 176.4 us: then the pieces flushed
+// through atomics.)  Also re-measured on the partial-row scheme: a piece per 5 chunks instead of 10 190 us, per 20 chunks
+// 194 us (360p) / 265.6 us (720p B = 2, - 6); 4 pieces for the middle levels 171 / 293 us.
 #ifndef VNX_TILE_UNITS_MIN
-#define VNX_TILE_UNITS_MIN 2
+#define VNX_TILE_UNITS_MIN 1
 #endif
 int gv_units_min(const MsdaDims& d, bool tiles, int v) {
   if (v >= 200 && v < 300) return v - 200 < 1 ? 1 : (v - 200 > 16 ? 16 : v - 200);
@@ -600,7 +607,7 @@ extern "C" int vnx_debug_gvtiles_units(const int64_t* host_shapes, int levels, i
   *units_used = used;
   *units_bound = vnx::msda_gvtiles_units_bound(d, units_min);
   if (partial_rows_used) *partial_rows_used = rows;
-  if (partial_rows_bound) *partial_rows_bound = gv_partial_rows_bound(int(S), levels);
+  if (partial_rows_bound) *partial_rows_bound = gv_partial_rows_bound(int(S), levels, batch * heads);
   return VNX_OK;
 }
 

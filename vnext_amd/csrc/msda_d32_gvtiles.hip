@@ -342,7 +342,7 @@ msda_bwd_gv_tiles_kernel(const int64_t* __restrict__ shapes, const int64_t* __re
   if (VNX_GVT_ABL == 4 && qsplit > 1) return;        // (ablation: no store of the query pieces' partial rows)
   if (qsplit > 1) {   // a piece of a query-split level: its rows go to its own slab of fp32 partial rows (plain stores, read
                       // back right away by gv_split_finish_kernel, which adds the pieces and writes grad_value)
-    float* part = partials + ((int64_t(b) * d.M + m) * gv_partial_rows_bound(d.S, d.L) + pbase + int64_t(qpiece) * (Hl * Wl)) * D;
+    float* part = partials + ((int64_t(b) * d.M + m) * gv_partial_rows_bound(d.S, d.L, d.B * d.M) + pbase + int64_t(qpiece) * (Hl * Wl)) * D;
 #pragma unroll
     for (int k = 0; k < kRpg; ++k) {
       const int row = grp + k * kGroups;
@@ -392,7 +392,7 @@ gv_split_finish_kernel(const int64_t* __restrict__ shapes, const int64_t* __rest
   const int per_bm = split_rows * 8;                               // 16-B pieces per (batch, head): blockIdx.y
   const int bm = int(blockIdx.y);
   const int b = bm / d.M, m = bm - b * d.M;
-  const float* slab = partials + int64_t(bm) * gv_partial_rows_bound(d.S, d.L) * D;
+  const float* slab = partials + int64_t(bm) * gv_partial_rows_bound(d.S, d.L, d.B * d.M) * D;
   TV* gv_bm = grad_value + (int64_t(b) * d.S * d.M + m) * D;
   for (int i = int(blockIdx.x) * int(blockDim.x) + int(threadIdx.x); i < per_bm; i += int(gridDim.x) * int(blockDim.x)) {
     const int r = i >> 3, ch4 = i & 7;
@@ -417,7 +417,7 @@ size_t msda_gvtiles_summary_bytes(const MsdaDims& d, int tile_queries) {
 
 // bytes of the query pieces' partial rows (fp32), all (batch, head) slabs
 size_t msda_gvtiles_partial_bytes(const MsdaDims& d) {
-  return size_t(d.B) * size_t(d.M) * size_t(gv_partial_rows_bound(d.S, d.L)) * 32 * sizeof(float);
+  return size_t(d.B) * size_t(d.M) * size_t(gv_partial_rows_bound(d.S, d.L, d.B * d.M)) * 32 * sizeof(float);
 }
 
 // Workgroups per (batch, head): the host knows S, not the level shapes.  gv_level_grid: a narrow level (W <= 63: bands
@@ -471,7 +471,7 @@ static int launch_gvtiles(const int64_t* shapes, const int64_t* lsi, const void*
   if (st != VNX_OK) return st;
   // the pieces of the query-split levels -> grad_value (sized by the bound on split pixels; idle threads leave at once)
   // grid: x = a share of the (batch, head)'s split pixels (grid-stride), y = (batch, head)
-  const int64_t px_bound = gv_partial_rows_bound(d.S, d.L) / kGvSplitPiecesMax;
+  const int64_t px_bound = gv_partial_rows_bound(d.S, d.L, d.B * d.M) / gv_split_pieces_max(d.B * d.M);
   int64_t fx = (px_bound * 8 + 255) / 256;
   fx = fx < 1 ? 1 : (fx > 16 ? 16 : fx);
   if (int64_t(d.B) * d.M > 65535) {

@@ -143,10 +143,16 @@ struct FusedArgs {
 // L2-bypassing atomics cost each piece 12-25 us, and the backward went from 32 to 49 us.
 // fp32 grad_value and 4 points per level only (the selection kernel); 1 = no split.
 #ifndef VNX_QS_COARSE
-#define VNX_QS_COARSE 8
+#define VNX_QS_COARSE 4         // query pieces of a coarse level (<= 2 row-units) at most, from 32 (batch, head) pairs up
+#endif
+#ifndef VNX_QS_COARSE_SMALL
+#define VNX_QS_COARSE_SMALL 16  // ... with fewer pairs (the grid does not fill the chip: more, shorter pieces)
 #endif
 #ifndef VNX_QS_MID
 #define VNX_QS_MID 2
+#endif
+#ifndef VNX_QS_CHUNKS
+#define VNX_QS_CHUNKS 10      // a piece is given about this many chunks of 128 queries
 #endif
 // batch_heads = B x M: with fewer than 32 (batch, head) pairs the grid leaves workgroup slots empty, and the middle
 // levels are split further: 8 pieces instead of 2 (round 2: 4 -- encoder backward at B = 2 123 -> 109 us at 360p, 450 ->
@@ -197,16 +203,19 @@ __host__ __device__ inline GvSplit gv_level_split(int n, int units_min, int rows
 }
 
 // Units of the tile-fed grad_value kernel (msda_d32_gvtiles.hip): RECTANGLES of a level, at most rows_max pixels each.
-// A narrow level (W < 64) is cut into bands of whole image rows; a wider one also into columns of about 32 pixels --
+// A narrow level (W < 32) is cut into bands of whole image rows; a wider one also into columns of about 32 pixels --
 // blocks of 32 x 8: a band of a 160-pixel-wide level would be 1.6 image rows thin while samples reach +-6 rows, i.e.
 // 8.5 bands' worth of query tiles would hit every band of the 720p level 0 where a block sees 4.7.  Measured (encoder
-// backward, B = 5, cold): blocks from 128 pixels of width up 732 -> 691 us at 720p, from 64 pixels up 651 us (the 80-pixel
-// level 1 is hit mostly by the tiles of the finer level 0, which are only 8 of ITS pixels wide) and 176.7 -> 174.6 us at
-// 360p; block width 16 instead of 32: 699 us.  Very flat levels (H < 8) get wider blocks so that the unit count stays
-// ~ n / rows_max.  At least units_min units per level when it has the rows.
+// backward, B = 5, cold): round 3 -- blocks from 128 pixels of width up 732 -> 691 us at 720p, from 64 pixels up 651 us and
+// 176.7 -> 174.6 us at 360p; block width 16 instead of 32: 699 us.  Round 4 (pieces meeting in partial rows): blocks from
+// 32 pixels of width up -- the 40-pixel levels (24 x 40 at 360p, 23 x 40 at 720p) become four 20 x 12 blocks instead of four
+// 40 x 6 bands -- 163.5 -> 153.4 us at 360p, 611 -> 594 us at 720p B = 5, 272.7 -> 266.7 us at B = 2; from 16 pixels up:
+// the same (a 20-pixel level fits one unit either way); block width 24: 154.8 / 590 / 262.5 us, 16: 162 / 617 / 412 us.
+// Very flat levels (H < 8) get wider blocks so that the unit count stays ~ n / rows_max.  At least units_min units per
+// level when it has the rows.
 // Unit u of a level: block (u % nbx, u / nbx), pixels [bx * bw, ..) x [by * bh, ..), clipped to the level.
 #ifndef VNX_GV_BLOCK_MINW
-#define VNX_GV_BLOCK_MINW 64
+#define VNX_GV_BLOCK_MINW 32
 #endif
 #ifndef VNX_GV_BLOCK_W
 #define VNX_GV_BLOCK_W 32
@@ -249,9 +258,12 @@ __host__ __device__ inline int gv_level_units(int H, int W, int units_min, bool 
 __host__ __device__ inline int gv_query_splits(int row_units, int Lq, int P, bool f32, int batch_heads) {
   if (!f32 || P != 4 || row_units > 4 || Lq < 1024) return 1;
   const int chunks = (Lq + 127) / 128;
-  const int qs = (chunks + 9) / 10;
+  const int qs = (chunks + VNX_QS_CHUNKS - 1) / VNX_QS_CHUNKS;
+  // round 4, pieces meeting in partial rows (no atomics): coarse cap 8 -> 4 from 32 pairs up (encoder-720p B = 5 611 -> 600 us;
+  // 360p has 4 pieces either way), 8 -> 16 below (720p B = 2 272.7 -> 263.9 us; 16 at B = 5: 628 us, 4 at B = 2: 332 us)
   const int mid = batch_heads < 32 ? 4 * VNX_QS_MID : VNX_QS_MID;
-  const int cap = row_units > 2 ? mid : VNX_QS_COARSE;   // middle levels: 3-4 row-units (960 pixels at 360p)
+  const int coarse = batch_heads < 32 ? VNX_QS_COARSE_SMALL : VNX_QS_COARSE;
+  const int cap = row_units > 2 ? mid : coarse;          // middle levels: 3-4 row-units (960 pixels at 360p)
   return qs < 1 ? 1 : (qs > cap ? cap : qs);
 }
 
@@ -263,10 +275,14 @@ __host__ __device__ inline int gv_query_splits(int row_units, int Lq, int P, boo
 // own dtype: the fp32 "split image" + convert pass of 16-bit values is gone too).  Layout per (batch, head): for every
 // split level l in order, qs_l pieces x n_l pixels x 32 floats, starting at row  sum_{l' < l} qs_l' n_l'.
 // A split level has at most 4 units of at most kGvTileRowsMax pixels (gv_query_splits), at most this many pieces:
-constexpr int kGvSplitPiecesMax = VNX_QS_COARSE > 4 * VNX_QS_MID ? VNX_QS_COARSE : 4 * VNX_QS_MID;
-__host__ __device__ inline int64_t gv_partial_rows_bound(int S, int L) {      // partial rows per (batch, head), an upper bound
+__host__ __device__ inline int gv_split_pieces_max(int batch_heads) {          // = the caps of gv_query_splits
+  const int mid = batch_heads < 32 ? 4 * VNX_QS_MID : VNX_QS_MID;
+  const int coarse = batch_heads < 32 ? VNX_QS_COARSE_SMALL : VNX_QS_COARSE;
+  return mid > coarse ? mid : coarse;
+}
+__host__ __device__ inline int64_t gv_partial_rows_bound(int S, int L, int batch_heads) {      // partial rows per (batch, head), an upper bound
   const int64_t px = int64_t(4) * kGvTileRowsMax * L;
-  return (px < S ? px : int64_t(S)) * kGvSplitPiecesMax;
+  return (px < S ? px : int64_t(S)) * gv_split_pieces_max(batch_heads);
 }
 
 inline int elem_size(int dtype) {
