@@ -78,7 +78,10 @@ def test_kernel_matches_reference_outputs(name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("H_,W_,n", [(48, 80, 300), (92, 160, 37), (1, 130, 3), (17, 1, 2), (33, 47, 5), (7, 95, 4), (5, 31, 3), (6, 64, 3)])
+@pytest.mark.parametrize("H_,W_,n", [(48, 80, 300), (92, 160, 37), (1, 130, 3), (17, 1, 2), (33, 47, 5), (7, 95, 4), (5, 31, 3), (6, 64, 3),
+                                     # the runs kernel's edges: rows wider than a chunk (the kept logits overlap their new
+                                     # place), many rows per register, one row per run (n = 1), one run per instance (n = 2 100)
+                                     (3, 400, 2), (2, 500, 3), (300, 3, 2), (48, 80, 1), (48, 80, 2100)])
 def test_kernel_at_frame_sizes(H_, W_, n):
     """360p / 720p frame sizes (BASELINE configs): a sample of instances against the oracle,
     and linearity in the last layer's bias (adds a constant to every logit)."""
@@ -103,6 +106,36 @@ def test_kernel_at_frame_sizes(H_, W_, n):
                                   params[0, j:j + 1].double().numpy(), [1])
         scale = max(1e-6, float(np.abs(one).max()))
         np.testing.assert_allclose(out[0, j].double().cpu().numpy(), one[0], rtol=0, atol=2e-5 * scale)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H_,W_,n", [(48, 80, 40), (92, 160, 9), (5, 31, 3), (3, 400, 2), (300, 3, 2), (11, 64, 700)])
+def test_single_frame_call_every_instance_and_forced_run_counts(H_, W_, n):
+    """One frame per call (the inference path: the kernel is told so and skips the instance -> frame lookup): every
+    instance against the oracle; and the development build's forced configurations -- one run per instance, several, one
+    row per run, the strip kernel of rounds 1 - 3 -- give the same bits (the arithmetic of a pixel is the same sequence
+    of operations however the frame is cut)."""
+    from vnext_amd import _lib
+    from vnext_amd.heads import dynamic_mask_with_coords
+    gen = torch.Generator().manual_seed(H_ * 31 + W_)
+    feats = torch.randn(1, 8, H_, W_, generator=gen)
+    ref = torch.rand(1, n, 2, generator=gen) * torch.tensor([W_ * 8.0, H_ * 8.0])
+    params = 0.3 * torch.randn(1, n, 169, generator=gen)
+    with torch.no_grad():
+        out = dynamic_mask_with_coords(feats.cuda(), ref.cuda(), params.cuda(), [n], 8)
+    torch.cuda.synchronize()
+    for j in range(0, n, max(1, n // 12)):
+        one = H.dynamic_mask_head(feats.double().numpy(), ref[0, j:j + 1].double().numpy(), params[0, j:j + 1].double().numpy(), [1])
+        scale = max(1e-6, float(np.abs(one).max()))
+        np.testing.assert_allclose(out[0, j].double().cpu().numpy(), one[0], rtol=0, atol=2e-5 * scale)
+    try:
+        for v in (701, 702, 703, 707, 798, 799):
+            _lib.set_kernel_variant(v)
+            with torch.no_grad():
+                other = dynamic_mask_with_coords(feats.cuda(), ref.cuda(), params.cuda(), [n], 8)
+            assert torch.equal(other, out), v
+    finally:
+        _lib.set_kernel_variant(0)
 
 
 def _grads_on_gpu(feats, ref, params, counts, gout):

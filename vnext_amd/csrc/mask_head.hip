@@ -29,15 +29,18 @@ constexpr int kMhChannels = 8;    // mask feature channels (hidden_dim / 32)
 constexpr int kMhHidden = 8;      // dynamic_mask_channels
 constexpr int kMhParams = (kMhChannels + 2) * kMhHidden + kMhHidden * kMhHidden + kMhHidden + kMhHidden + kMhHidden + 1;
 constexpr int kMhStripW = 63;     // stored columns per wave (64 lanes - 1 halo lane)
+#ifdef VNX_DEV_VARIANTS
 #ifndef VNX_MH_ROWS
 #define VNX_MH_ROWS 5
 #endif
-constexpr int kMhStripH = VNX_MH_ROWS;   // stored rows per wave (+1 halo row, all held in registers)
+constexpr int kMhStripH = VNX_MH_ROWS;   // strip kernel: stored rows per wave (+1 halo row, all held in registers)
+#endif
 static_assert(kMhParams == 169, "parameter vector layout");
 
 typedef float float2_t __attribute__((ext_vector_type(2)));
 typedef float float4_t __attribute__((ext_vector_type(4)));
 typedef uint32_t sgpr2_t __attribute__((ext_vector_type(2)));
+typedef unsigned int store2_t __attribute__((__vector_size__(2 * sizeof(unsigned int))));
 typedef uint32_t sgpr4_t __attribute__((ext_vector_type(4)));
 typedef uint32_t sgpr8_t __attribute__((ext_vector_type(8)));
 typedef uint32_t sgpr16_t __attribute__((ext_vector_type(16)));
@@ -57,6 +60,167 @@ __device__ __forceinline__ void pk_fma_bcast(float2_t& d, uint64_t w_pair, float
   else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(d) : "s"(w_pair), "v"(x));
 }
 
+// d = w * x + c: the first FMA of an accumulator takes the bias from a register pair shared by all row pairs of an
+// output channel -- one move per channel instead of one per (channel, row pair): 51 -> 17 moves per wave.
+__device__ __forceinline__ float2_t pk_fma_first(uint64_t w_pair, float2_t x, float2_t c) {
+  float2_t d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(d) : "s"(w_pair), "v"(x), "v"(c));
+  return d;
+}
+
+// ReLU of a row pair.  asm: `__builtin_elementwise_max(a, 0)` on a value that comes out of an asm statement makes hipcc
+// canonicalise it first (v_max_f32 x, x, x before v_max_f32 x, 0, x) -- 96 of a wave's 868 vector instructions.
+__device__ __forceinline__ float2_t relu2(float2_t a) {
+  float2_t r;
+  asm("v_max_f32 %0, 0, %1" : "=v"(r.x) : "v"(a.x));
+  asm("v_max_f32 %0, 0, %1" : "=v"(r.y) : "v"(a.y));
+  return r;
+}
+
+// The three layers (10 -> 8, ReLU, 8 -> 8, ReLU, 8 -> 1) of a wave's pixels.  x0[p][i] = input channel i (relative x, relative
+// y, the 8 features) of register pair p; logit[2p], logit[2p + 1] = the pair's outputs.  P = the instance's 169 parameters.
+//
+// The parameters are wave-uniform: scalar loads, SGPR operands of the packed FMAs (v_pk_fma_f32 takes one SGPR pair and
+// broadcasts either half with op_sel).  What decides the speed is HOW MANY of them are live: left to itself hipcc hoists
+// all eleven s_load_dwordx16 to the top, 169 values meet ~100 SGPRs, and the rest lives in VGPR lanes -- 655 v_readlane +
+// 371 v_writelane beside 432 v_pk_fma_f32 per wave (27 us per 360p frame at 300 instances).  Here the parameters arrive
+// in groups of two output channels (asm s_load, at most two groups in flight, waited for by hand), so none of them ever
+// leaves the scalar file: 14.6 us.  Other forms measured on MI355X (tools/time_heads.py): the parameters parked across the
+// lanes of three VGPRs and read back pair by pair with v_readlane where consumed (no scalar loads inside the layers, 169
+// more instructions per wave) 15.4 us; LDS broadcast reads 31.6 us.
+// after_layer1(): called once the inputs have been consumed (the runs kernel issues its next feature loads there).
+template <int RP, typename Mid>
+__device__ __forceinline__ void mask_logits(const float* P, const float2_t (&x0)[RP][kMhChannels + 2], float (&logit)[2 * RP],
+                                            Mid&& after_layer1) {
+  constexpr int W0 = 0, W1 = 80, W2 = 144, B0 = 152, B1 = 160, B2 = 168;
+  // a group of parameters in the scalar file: 20 (or 16) weights of two output channels + their two biases
+  struct Group { sgpr16_t w; sgpr4_t w2; sgpr2_t b; };
+  auto fetch20 = [&](Group& g, int w_at, int b_at) {   // 20 consecutive weights, 2 consecutive biases
+    asm volatile("s_load_dwordx16 %0, %3, %4\n\ts_load_dwordx4 %1, %3, %5\n\ts_load_dwordx2 %2, %3, %6"
+                 : "=&s"(g.w), "=&s"(g.w2), "=&s"(g.b)
+                 : "s"(P), "n"(w_at * 4), "n"(w_at * 4 + 64), "n"(b_at * 4)
+                 : "memory");
+  };
+  auto fetch16 = [&](Group& g, int w_at, int b_at) {   // 16 consecutive weights, 2 consecutive biases
+    asm volatile("s_load_dwordx16 %0, %2, %3\n\ts_load_dwordx2 %1, %2, %4"
+                 : "=&s"(g.w), "=&s"(g.b)
+                 : "s"(P), "n"(w_at * 4), "n"(b_at * 4)
+                 : "memory");
+  };
+  auto landed = [&](Group& g) {   // everything issued so far is in its registers (the loads are invisible to hipcc's own counting)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(g.w), "+s"(g.w2), "+s"(g.b)::"memory");
+  };
+  auto wpair = [](const Group& g, int k) -> uint64_t {   // weights 2k, 2k + 1 of the group as one SGPR pair
+    return k < 8 ? (uint64_t(g.w[2 * k + 1]) << 32) | g.w[2 * k] : (uint64_t(g.w2[2 * (k - 8) + 1]) << 32) | g.w2[2 * (k - 8)];
+  };
+
+  float2_t x1[RP][kMhHidden];
+  {
+    Group ga, gb;
+    ga.w2 = sgpr4_t{0u, 0u, 0u, 0u}; gb.w2 = ga.w2;
+#define VNX_L1(G, o0)                                                                                          \
+    {   /* the group's two output channels together: 2 x RP independent accumulators -- a v_pk_fma_f32 that reads the */ \
+        /* result of one less than four instructions before it costs a wait state (hipcc fills in s_nop)            */ \
+      float2_t a[2][RP];                                                                                         \
+      float2_t bias2[2];                                                                                         \
+      _Pragma("unroll") for (int oo = 0; oo < 2; ++oo) {                                                         \
+        const float bias = __uint_as_float(G.b[oo]);                                                             \
+        bias2[oo] = float2_t{bias, bias};                                                                        \
+      }                                                                                                          \
+      _Pragma("unroll") for (int i = 0; i < kMhChannels + 2; i += 2) {                                           \
+        _Pragma("unroll") for (int oo = 0; oo < 2; ++oo) {                                                       \
+          const uint64_t w2 = wpair(G, (oo * (kMhChannels + 2) + i) / 2);                                        \
+          _Pragma("unroll") for (int p = 0; p < RP; ++p) {                                                       \
+            if (i == 0) a[oo][p] = pk_fma_first(w2, x0[p][i], bias2[oo]);                                        \
+            else pk_fma_bcast<false>(a[oo][p], w2, x0[p][i]);                                                    \
+          }                                                                                                      \
+        }                                                                                                        \
+        _Pragma("unroll") for (int oo = 0; oo < 2; ++oo) {                                                       \
+          const uint64_t w2 = wpair(G, (oo * (kMhChannels + 2) + i) / 2);                                        \
+          _Pragma("unroll") for (int p = 0; p < RP; ++p) pk_fma_bcast<true>(a[oo][p], w2, x0[p][i + 1]);         \
+        }                                                                                                        \
+      }                                                                                                          \
+      _Pragma("unroll") for (int oo = 0; oo < 2; ++oo) {                                                         \
+        _Pragma("unroll") for (int p = 0; p < RP; ++p) x1[p][(o0) + oo] = relu2(a[oo][p]);                       \
+      }                                                                                                          \
+    }
+    // (sched_barrier: without it the machine scheduler sinks every FMA block below the last fetch -- the asm
+    //  statements only order each other -- and all 169 values are live at once again)
+#define VNX_FENCE __builtin_amdgcn_sched_barrier(0);
+    fetch20(ga, W0, B0);
+    landed(ga); fetch20(gb, W0 + 20, B0 + 2); VNX_FENCE
+    VNX_L1(ga, 0) VNX_FENCE
+    landed(gb); fetch20(ga, W0 + 40, B0 + 4); VNX_FENCE
+    VNX_L1(gb, 2) VNX_FENCE
+    landed(ga); fetch20(gb, W0 + 60, B0 + 6); VNX_FENCE
+    VNX_L1(ga, 4) VNX_FENCE
+    landed(gb); VNX_FENCE
+    VNX_L1(gb, 6) VNX_FENCE
+#undef VNX_L1
+  }
+  after_layer1();
+  __builtin_amdgcn_sched_barrier(0);
+  // Layer two, with layer three accumulated as its channels appear (logit = b3 + sum_k w3[k] relu(x2[k]) in the order
+  // k = 0 .. 7 either way): only two channels of x2 are ever live, which leaves the registers of the inputs free for the
+  // loads issued in after_layer1().
+  {
+    Group ga, gb;
+    ga.w2 = sgpr4_t{0u, 0u, 0u, 0u}; gb.w2 = ga.w2;
+    sgpr8_t w3; uint32_t b3;
+    float2_t l3[RP];
+#define VNX_L2(G, o0)                                                                                          \
+    {                                                                                                            \
+      float2_t a[2][RP];                                                                                         \
+      float2_t bias2[2];                                                                                         \
+      _Pragma("unroll") for (int oo = 0; oo < 2; ++oo) {                                                         \
+        const float bias = __uint_as_float(G.b[oo]);                                                             \
+        bias2[oo] = float2_t{bias, bias};                                                                        \
+      }                                                                                                          \
+      _Pragma("unroll") for (int i = 0; i < kMhHidden; i += 2) {                                                 \
+        _Pragma("unroll") for (int oo = 0; oo < 2; ++oo) {                                                       \
+          const uint64_t w2 = wpair(G, (oo * kMhHidden + i) / 2);                                                \
+          _Pragma("unroll") for (int p = 0; p < RP; ++p) {                                                       \
+            if (i == 0) a[oo][p] = pk_fma_first(w2, x1[p][i], bias2[oo]);                                        \
+            else pk_fma_bcast<false>(a[oo][p], w2, x1[p][i]);                                                    \
+          }                                                                                                      \
+        }                                                                                                        \
+        _Pragma("unroll") for (int oo = 0; oo < 2; ++oo) {                                                       \
+          const uint64_t w2 = wpair(G, (oo * kMhHidden + i) / 2);                                                \
+          _Pragma("unroll") for (int p = 0; p < RP; ++p) pk_fma_bcast<true>(a[oo][p], w2, x1[p][i + 1]);         \
+        }                                                                                                        \
+      }                                                                                                          \
+      const uint64_t w3pair = (uint64_t(w3[(o0) + 1]) << 32) | w3[(o0)];                                         \
+      _Pragma("unroll") for (int p = 0; p < RP; ++p) {                                                           \
+        const float2_t xa = relu2(a[0][p]);                                                                      \
+        if ((o0) == 0) l3[p] = pk_fma_first(w3pair, xa, bias3);                                                  \
+        else pk_fma_bcast<false>(l3[p], w3pair, xa);                                                             \
+      }                                                                                                          \
+      _Pragma("unroll") for (int p = 0; p < RP; ++p) pk_fma_bcast<true>(l3[p], w3pair, relu2(a[1][p]));          \
+    }
+#define VNX_FENCE __builtin_amdgcn_sched_barrier(0);
+    fetch16(ga, W1, B1);
+    // the last layer's 8 weights + bias (W2 .. B2 are NOT contiguous: 144..151 and 168)
+    asm volatile("s_load_dwordx8 %0, %2, %3\n\ts_load_dword %1, %2, %4" : "=&s"(w3), "=&s"(b3) : "s"(P), "n"(W2 * 4), "n"(B2 * 4) : "memory");
+    landed(ga);
+    asm volatile("" : "+s"(w3), "+s"(b3)::"memory");      // (landed() waited for everything issued)
+    fetch16(gb, W1 + 16, B1 + 2); VNX_FENCE
+    const float bias3f = __uint_as_float(b3);
+    const float2_t bias3 = {bias3f, bias3f};
+    VNX_L2(ga, 0) VNX_FENCE
+    landed(gb); fetch16(ga, W1 + 32, B1 + 4); VNX_FENCE
+    VNX_L2(gb, 2) VNX_FENCE
+    landed(ga); fetch16(gb, W1 + 48, B1 + 6); VNX_FENCE
+    VNX_L2(ga, 4) VNX_FENCE
+    landed(gb); VNX_FENCE
+    VNX_L2(gb, 6) VNX_FENCE
+#undef VNX_L2
+#undef VNX_FENCE
+#pragma unroll
+    for (int p = 0; p < RP; ++p) { logit[2 * p] = l3[p].x; logit[2 * p + 1] = l3[p].y; }
+  }
+}
+
+#ifdef VNX_DEV_VARIANTS     // the strip kernel of rounds 1 - 3: A/B reference of the development build (variant 799)
 // HALVES = 1: the wave is one strip of 63 columns (+ halo lane 0).  HALVES = 2: two strips of 31 columns
 // (+ halo lanes 0 and 32) stacked vertically -- lanes 32..63 take the kMhStripH rows below those of lanes
 // 0..31.  The launcher picks whichever wastes fewer lanes on the frame's width: at 80 columns (360p) one
@@ -81,20 +245,7 @@ dynamic_mask_head_kernel(const float* __restrict__ feats, const float* __restric
   const int xc = x < 0 ? 0 : (x > W - 1 ? W - 1 : x);
   const int y0 = (sy * HALVES + half_id) * kMhStripH;
 
-  // The instance's 169 parameters are wave-uniform: scalar loads, SGPR operands of the packed FMAs
-  // (v_pk_fma_f32 takes one SGPR pair and broadcasts either half with op_sel).  What decides the speed is
-  // HOW MANY of them are live: left to itself hipcc hoists all eleven s_load_dwordx16 to the top of the
-  // kernel, 169 values meet ~100 SGPRs, and the rest lives in VGPR lanes -- 655 v_readlane + 371
-  // v_writelane beside 432 v_pk_fma_f32 per wave (27 us per 360p frame at 300 instances).  Here the
-  // parameters arrive in groups of two output channels (asm s_load, at most two groups in flight, waited
-  // for by hand), so none of them ever leaves the scalar file: 14.6 us.  Other forms measured on MI355X
-  // (tools/time_heads.py): the parameters parked across the lanes of three VGPRs and read back pair by pair
-  // with v_readlane where consumed (no scalar loads inside the layers, 169 more instructions per wave) 15.4 us;
-  // LDS broadcast reads 31.6 us.  PMC of this form: 868 vector instructions per wave (440 packed FMAs, 192
-  // v_max -- gfx950 has no packed max --, the rest bias moves, addresses and the up-sampling), VALU busy 48 %
-  // of the kernel at ~1.9 GHz; the output write (18.4 MB) would take 3 us.
   const float* P = params + int64_t(j) * kMhParams;
-  constexpr int W0 = 0, W1 = 80, W2 = 144, B0 = 152, B1 = 160, B2 = 168;
   const float refx = ref[2 * j], refy = ref[2 * j + 1];
   const int img = inst_image[j];
   // the frame's 8 feature planes through one buffer descriptor: per-lane offset = the pixel, scalar offset =
@@ -131,107 +282,8 @@ dynamic_mask_head_kernel(const float* __restrict__ feats, const float* __restric
 #pragma unroll
     for (int i = 0; i < kMhChannels + 2; ++i) x0[p][i] = float2_t{v[0][i], v[1][i]};
   }
-  const float2_t zero2 = {0.f, 0.f};
-
-  // a group of parameters in the scalar file: 20 (or 16) weights of two output channels + their two biases
-  struct Group { sgpr16_t w; sgpr4_t w2; sgpr2_t b; };
-  auto fetch20 = [&](Group& g, int w_at, int b_at) {   // 20 consecutive weights, 2 consecutive biases
-    asm volatile("s_load_dwordx16 %0, %3, %4\n\ts_load_dwordx4 %1, %3, %5\n\ts_load_dwordx2 %2, %3, %6"
-                 : "=&s"(g.w), "=&s"(g.w2), "=&s"(g.b)
-                 : "s"(P), "n"(w_at * 4), "n"(w_at * 4 + 64), "n"(b_at * 4)
-                 : "memory");
-  };
-  auto fetch16 = [&](Group& g, int w_at, int b_at) {   // 16 consecutive weights, 2 consecutive biases
-    asm volatile("s_load_dwordx16 %0, %2, %3\n\ts_load_dwordx2 %1, %2, %4"
-                 : "=&s"(g.w), "=&s"(g.b)
-                 : "s"(P), "n"(w_at * 4), "n"(b_at * 4)
-                 : "memory");
-  };
-  auto landed = [&](Group& g) {   // everything issued so far is in its registers (the loads are invisible to hipcc's own counting)
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(g.w), "+s"(g.w2), "+s"(g.b)::"memory");
-  };
-  auto wpair = [](const Group& g, int k) -> uint64_t {   // weights 2k, 2k + 1 of the group as one SGPR pair
-    return k < 8 ? (uint64_t(g.w[2 * k + 1]) << 32) | g.w[2 * k] : (uint64_t(g.w2[2 * (k - 8) + 1]) << 32) | g.w2[2 * (k - 8)];
-  };
-
-  float2_t x1[RP][kMhHidden];
-  {
-    Group ga, gb;
-    ga.w2 = sgpr4_t{0u, 0u, 0u, 0u}; gb.w2 = ga.w2;
-#define VNX_L1(G, o0)                                                                                          \
-    _Pragma("unroll") for (int oo = 0; oo < 2; ++oo) {   /* weight outer, row pairs inner: a broadcast weight */   \
-      const float bias = __uint_as_float(G.b[oo]);         /* is used three times at once and never kept          */   \
-      float2_t a[RP];                                                                                            \
-      _Pragma("unroll") for (int p = 0; p < RP; ++p) a[p] = float2_t{bias, bias};                                \
-      _Pragma("unroll") for (int i = 0; i < kMhChannels + 2; i += 2) {                                           \
-        const uint64_t w2 = wpair(G, (oo * (kMhChannels + 2) + i) / 2);                                          \
-        _Pragma("unroll") for (int p = 0; p < RP; ++p) pk_fma_bcast<false>(a[p], w2, x0[p][i]);                  \
-        _Pragma("unroll") for (int p = 0; p < RP; ++p) pk_fma_bcast<true>(a[p], w2, x0[p][i + 1]);               \
-      }                                                                                                          \
-      _Pragma("unroll") for (int p = 0; p < RP; ++p) x1[p][(o0) + oo] = __builtin_elementwise_max(a[p], zero2);  \
-    }
-    // (sched_barrier: without it the machine scheduler sinks every FMA block below the last fetch -- the asm
-    //  statements only order each other -- and all 169 values are live at once again)
-#define VNX_FENCE __builtin_amdgcn_sched_barrier(0);
-    fetch20(ga, W0, B0);
-    landed(ga); fetch20(gb, W0 + 20, B0 + 2); VNX_FENCE
-    VNX_L1(ga, 0) VNX_FENCE
-    landed(gb); fetch20(ga, W0 + 40, B0 + 4); VNX_FENCE
-    VNX_L1(gb, 2) VNX_FENCE
-    landed(ga); fetch20(gb, W0 + 60, B0 + 6); VNX_FENCE
-    VNX_L1(ga, 4) VNX_FENCE
-    landed(gb); VNX_FENCE
-    VNX_L1(gb, 6) VNX_FENCE
-#undef VNX_L1
-  }
-  float2_t x2[RP][kMhHidden];
   float logit[R1];
-  {
-    Group ga, gb;
-    ga.w2 = sgpr4_t{0u, 0u, 0u, 0u}; gb.w2 = ga.w2;
-#define VNX_L2(G, o0)                                                                                          \
-    _Pragma("unroll") for (int oo = 0; oo < 2; ++oo) {                                                           \
-      const float bias = __uint_as_float(G.b[oo]);                                                               \
-      float2_t a[RP];                                                                                            \
-      _Pragma("unroll") for (int p = 0; p < RP; ++p) a[p] = float2_t{bias, bias};                                \
-      _Pragma("unroll") for (int i = 0; i < kMhHidden; i += 2) {                                                 \
-        const uint64_t w2 = wpair(G, (oo * kMhHidden + i) / 2);                                                  \
-        _Pragma("unroll") for (int p = 0; p < RP; ++p) pk_fma_bcast<false>(a[p], w2, x1[p][i]);                  \
-        _Pragma("unroll") for (int p = 0; p < RP; ++p) pk_fma_bcast<true>(a[p], w2, x1[p][i + 1]);               \
-      }                                                                                                          \
-      _Pragma("unroll") for (int p = 0; p < RP; ++p) x2[p][(o0) + oo] = __builtin_elementwise_max(a[p], zero2);  \
-    }
-    fetch16(ga, W1, B1);
-    landed(ga); fetch16(gb, W1 + 16, B1 + 2); VNX_FENCE
-    VNX_L2(ga, 0) VNX_FENCE
-    landed(gb); fetch16(ga, W1 + 32, B1 + 4); VNX_FENCE
-    VNX_L2(gb, 2) VNX_FENCE
-    landed(ga); fetch16(gb, W1 + 48, B1 + 6); VNX_FENCE
-    VNX_L2(ga, 4) VNX_FENCE
-    landed(gb);
-    // the last layer's 8 weights + bias (W2 .. B2 are NOT contiguous: 144..151 and 168)
-    sgpr8_t w3; uint32_t b3;
-    asm volatile("s_load_dwordx8 %0, %2, %3\n\ts_load_dword %1, %2, %4" : "=&s"(w3), "=&s"(b3) : "s"(P), "n"(W2 * 4), "n"(B2 * 4) : "memory");
-    VNX_FENCE
-    VNX_L2(gb, 6) VNX_FENCE
-#undef VNX_L2
-#undef VNX_FENCE
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(w3), "+s"(b3)::"memory");
-    const float bias = __uint_as_float(b3);
-    float2_t a[RP];
-#pragma unroll
-    for (int p = 0; p < RP; ++p) a[p] = float2_t{bias, bias};
-#pragma unroll
-    for (int i = 0; i < kMhHidden; i += 2) {
-      const uint64_t w2 = (uint64_t(w3[i + 1]) << 32) | w3[i];
-#pragma unroll
-      for (int p = 0; p < RP; ++p) pk_fma_bcast<false>(a[p], w2, x2[p][i]);
-#pragma unroll
-      for (int p = 0; p < RP; ++p) pk_fma_bcast<true>(a[p], w2, x2[p][i + 1]);
-    }
-#pragma unroll
-    for (int p = 0; p < RP; ++p) { logit[2 * p] = a[p].x; logit[2 * p + 1] = a[p].y; }
-  }
+  mask_logits<RP>(P, x0, logit, [] {});
   // Stores: a lane owns 2 x 2 outputs, 8 bytes in each of two rows.  (Measured, round 2: without the stores
   // the kernel takes 10.5 of its 14.6 us at 360p; pairing neighbouring lanes by column parity so that each
   // writes one dwordx4 instead of two dwordx2 -- 4 shuffles per row -- gave 14.65 us, no gain: the cost is
@@ -252,6 +304,213 @@ dynamic_mask_head_kernel(const float* __restrict__ feats, const float* __restric
   }
 }
 
+
+#endif  // VNX_DEV_VARIANTS
+
+// ------------------------------------------------------------------------------ forward, row-major runs
+// The strip kernel above spends lanes and rows on geometry: at W = 80 three 31-column half-strips use 80 of 93 lanes, one
+// row in six is a halo, the last strip row of a 48-row frame is 8 of 10 rows -- 69 % of the computed pixels are stored.
+// Here a wave takes a RUN of whole image rows of one instance in row-major order: register r of a chunk holds pixels
+// f .. f + 63 of the flattened H x W frame -- every lane a pixel whatever W is, every feature load 256 contiguous bytes --
+// and walks down its run in chunks of up to three register pairs.  The x2 up-sampling needs the logits of the pixel to
+// the left and of the row above: the wave keeps the logits of its chunk, preceded by the last `halo` (>= W + 1) of the
+// chunk before, in its own piece of LDS (a wave's LDS operations execute in order: no barrier) and reads the three
+// neighbours at f - 1, f - W, f - W - 1 from there.  A run that does not start at the top of the frame computes the row
+// above it first: W pixels of halo per run instead of one row in six.
+// Everything around the layers is kept off the vector ALU where the hardware offers another place for it (the layers
+// themselves run at the VALU's issue rate; with 49 further vector instructions per register the rest was as long again):
+//   * LDS addresses are the lane's offset + an immediate; what depends on x, y is a select between per-wave constants;
+//   * feature loads: the frame's eight planes are one descriptor, the pixel in the vector offset (+ an immediate per
+//     register), the plane in the scalar offset (the range check takes it off the buffer's size): a pixel past the frame
+//     reads the next plane or, in the last one, zero -- nothing is clamped, nothing past the tensor is touched;
+//   * stores: the descriptor covers exactly the run's own output rows, offsets are relative to them -- the halo's lanes
+//     come out negative, the lanes past the run's end beyond the range, and the hardware drops both.
+template <int kDummy>
+__global__ void __launch_bounds__(256)
+dynamic_mask_head_runs_kernel(const float* __restrict__ feats, const float* __restrict__ ref,
+                              const float* __restrict__ params, const int* __restrict__ inst_image,
+                              float* __restrict__ out, int H, int W, int n_inst, int stride, int runs, int halo) {
+  extern __shared__ float mh_lds[];
+  const int lane = threadIdx.x & 63;
+  const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t wave_id = blockIdx.x * 4u + uint32_t(wave_in_block);     // the launcher keeps this below 2^31
+  const int j = int(wave_id / uint32_t(runs));  // instance
+  if (j >= n_inst) return;
+  const int k = int(wave_id) - j * runs;
+  const int ya = (k * H) / runs, yb = ((k + 1) * H) / runs;               // the run's rows [ya, yb)
+  if (ya >= yb) return;
+  const int f0 = ya * W, f1 = yb * W;                                     // its pixels
+  const int start = ya > 0 ? f0 - W : 0;                                  // first computed pixel: the row above the run
+  const int total = f1 - start;
+
+  const float* P = params + int64_t(j) * kMhParams;
+  const float refx = ref[2 * j], refy = ref[2 * j + 1];
+  // one frame in the call (inference: 300 instances of one frame): every instance belongs to it, and the features need
+  // not wait for a trip to memory to learn that (the launcher passes no index array)
+  const int img = inst_image ? inst_image[j] : 0;
+  // (requesting the instance's 676 parameter bytes here, beside the frame index, so that the layers' own scalar loads hit
+  //  the cache: 9.9 against 9.7 us at 360p, 6.6 against 6.1 us at the training shape -- not kept)
+  const uint32_t plane_bytes = uint32_t(H * W) * 4u;
+  const __amdgpu_buffer_rsrc_t fsrc = uniform_rsrc(feats + int64_t(img) * kMhChannels * H * W,
+                                                   uint32_t(kMhChannels) * plane_bytes);
+  const int half = stride / 2;
+  // the run's own output rows: [2 ya, 2 yb) x 2W
+  const __amdgpu_buffer_rsrc_t osrc = uniform_rsrc(out + int64_t(j) * (2 * H) * (2 * W) + int64_t(4) * f0,
+                                                   uint32_t(f1 - f0) * 16u);
+
+  // the lane's pixel in the next register to be filled: start is a multiple of W
+  const int ly = lane / W;
+  int y = start / W + ly, x = lane - ly * W;
+  const int q64 = 64 / W, r64 = 64 - q64 * W;                             // a register further on: 64 pixels
+  int done = 0;                                                           // pixels of the run already computed
+
+  // the features of six registers (one full chunk) from run pixel `first` on, all in flight together
+  const uint32_t lane4 = uint32_t(lane) * 4u;
+  float2_t feat[3][kMhChannels];       // [register pair][plane]: .x / .y = the pair's two registers, as the layers take them
+  auto issue = [&](int first) {
+    const uint32_t pix = uint32_t(start + first) * 4u + lane4;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int c = 0; c < kMhChannels; ++c) {
+#if defined(VNX_MH_ABL) && (VNX_MH_ABL & 4)     // timing ablation: no feature loads
+          const float f = float(pix) * 1e-6f + float(c);
+#else
+          const float f = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(fsrc, int(pix + 256u * (2 * p + h)),
+                                                                               int(uint32_t(c) * plane_bytes), 0));
+#endif
+          if (h == 0) feat[p][c].x = f; else feat[p][c].y = f;
+        }
+      }
+    }
+  };
+  issue(0);
+
+  // the wave's LDS: [halo entries of the chunk before][384 of this chunk]
+  char* const lds = reinterpret_cast<char*>(mh_lds) + size_t(wave_in_block) * size_t(halo + 384) * 4u;
+  char* const at_d = lds + (uint32_t(halo) * 4u + lane4);                  // this lane's entry in register 0 of the chunk
+  char* const at_c = at_d - 4, * const at_b = at_d - W * 4, * const at_a = at_b - 4;
+  const int neg_lane16 = -16 * lane;
+
+  auto chunk = [&](auto tag) {
+    constexpr int RP = decltype(tag)::value, R = 2 * RP;
+    int xs[R], ys[R];
+    float2_t x0[RP][kMhChannels + 2];
+#pragma unroll
+    for (int p = 0; p < RP; ++p) {
+      float v[2][2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int r = 2 * p + h;
+        xs[r] = x; ys[r] = y;
+        // exactly the reference's arithmetic: location = x * stride + stride // 2 (an integer), one subtraction
+        v[h][0] = refx - float(__mul24(x, stride) + half);   // (24-bit multiply: full rate)
+        v[h][1] = refy - float(__mul24(y, stride) + half);
+        x += r64; y += q64;
+        if (x >= W) { x -= W; ++y; }
+      }
+      x0[p][0] = float2_t{v[0][0], v[1][0]};
+      x0[p][1] = float2_t{v[0][1], v[1][1]};
+#pragma unroll
+      for (int c = 0; c < kMhChannels; ++c) x0[p][2 + c] = feat[p][c];
+    }
+    float logit[R];
+    const int next = done + 64 * R;
+    // the next chunk's features leave once this chunk's are consumed (their registers are free): layers two and three
+    // and the stores below cover the latency
+#if defined(VNX_MH_ABL) && (VNX_MH_ABL & 2)     // timing ablation: no layers
+#pragma unroll
+    for (int p = 0; p < RP; ++p) {
+      float2_t t = x0[p][0];
+#pragma unroll
+      for (int c = 1; c < kMhChannels + 2; ++c) t += x0[p][c];
+      logit[2 * p] = t.x; logit[2 * p + 1] = t.y;
+    }
+    if (next < total) issue(next);
+#else
+    mask_logits<RP>(P, x0, logit, [&] { if (next < total) issue(next); });
+#endif
+#pragma unroll
+    for (int r = 0; r < R; ++r) *reinterpret_cast<float*>(at_d + 256 * r) = logit[r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // out[2y][2x] = (a+b+c+d)/4, out[2y][2x+1] = (b+d)/2, out[2y+1][2x] = (c+d)/2, out[2y+1][2x+1] = d with
+    // a = in[y-1][x-1], b = in[y-1][x], c = in[y][x-1], d = in[y][x], indices clamped at 0.  All LDS reads of the chunk
+    // first (no branch: a lane outside the run's own pixels reads something and stores nowhere).
+    float na[R], nb[R], nc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const bool inner = xs[r] > 0, below = ys[r] > 0;
+      const char* pc = inner ? at_c : at_d;
+      nc[r] = *reinterpret_cast<const float*>(pc + 256 * r);
+      nb[r] = *reinterpret_cast<const float*>((below ? at_b : at_d) + 256 * r);
+      na[r] = *reinterpret_cast<const float*>((below ? (inner ? at_a : at_b) : pc) + 256 * r);
+    }
+    const int chunk16 = (start + done - f0) * 16;     // byte offset of the chunk's first pixel's output, in the run's rows
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const float d = logit[r];
+      const float2_t top = {0.25f * ((na[r] + nb[r]) + (nc[r] + d)), 0.5f * (nb[r] + d)};
+      const float2_t bot = {0.5f * (nc[r] + d), d};
+      // byte offset of out[2y][2x] in the run's rows: 4 * (4 (y - ya) W + 2 x) = 16 (f - f0) - 8 x
+      const int off = (chunk16 + 1024 * r) - ((xs[r] << 3) + neg_lane16);
+#if defined(VNX_MH_ABL) && (VNX_MH_ABL & 1)     // timing ablation: no stores (but for results no run produces)
+      if (top.x != 1234.5f) continue;
+#endif
+      // write-once output streamed past the caches (`nt`)
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(store2_t, top), osrc, off, 0, 2);
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(store2_t, bot), osrc, off + 8 * W, 0, 2);
+    }
+    done = next;
+    if (RP == 3 && done < total) {
+      // the last `halo` logits move to the front (64 at a time, all read before any is written: the two ranges overlap
+      // when halo > 384)
+      float t[6];
+      const int regs = halo >> 6;
+      for (int g = 0; g < regs; g += 6) {
+#pragma unroll
+        for (int u = 0; u < 6; ++u)
+          if (g + u < regs) t[u] = *reinterpret_cast<const float*>(lds + lane4 + (384 + 64 * (g + u)) * 4);
+#pragma unroll
+        for (int u = 0; u < 6; ++u)
+          if (g + u < regs) *reinterpret_cast<float*>(lds + lane4 + 64 * (g + u) * 4) = t[u];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  };
+  while (done < total) {
+    const int left = total - done;                    // wave-uniform
+    if (left > 256) chunk(std::integral_constant<int, 3>{});
+    else if (left > 128) chunk(std::integral_constant<int, 2>{});
+    else chunk(std::integral_constant<int, 1>{});
+  }
+}
+
+// Runs per instance: the kernel is bound by vector-ALU issue, so its time is that of the most loaded SIMD --
+// ceil(waves / 1024) waves (1 024 SIMDs; workgroups of four waves spread over a CU's four) of ceil(pixels / 128) register
+// pairs each.  Among the run counts that fill two, three or four whole rounds of the chip (one wave per SIMD leaves its
+// stalls uncovered: 12.2 us against 10.7 with two at 360p, 300 instances) the one with the smallest product; on a tie the
+// one with fewer runs (fewer halo rows).  `forced` > 0: that many runs (development build).
+static int mask_head_runs(int n, int H, int W, int forced) {
+  if (forced > 0) return forced < H ? forced : H;
+  int best = 1; long long best_cost = -1;
+  for (int cap = 2; cap <= 4; ++cap) {
+    long long runs = (1024LL * cap) / n;
+    if (runs < 1) runs = 1;
+    if (runs > H) runs = H;
+    const long long rows = (H + runs - 1) / runs;
+    const long long px = rows * W + (runs > 1 ? W : 0);
+    const long long pairs = (px + 127) / 128;
+    const long long per_simd = (n * runs + 1023) / 1024;
+    const long long cost = per_simd * pairs;
+    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = int(runs); }
+  }
+  return best;
+}
 
 // ------------------------------------------------------------------------------ backward
 // Training path (forward_mask_head_train, segmentation_condInst.py:354-401: the matched
@@ -694,6 +953,23 @@ extern "C" int vnx_dynamic_mask_head_forward(int dtype, const void* mask_feats,
     set_error("vnx_dynamic_mask_head_forward: null pointer argument");
     return VNX_ERR_INVALID_ARGUMENT;
   }
+  const int variant = kernel_variant();
+  if (variant != 799) {                      // (development build: 799 = the strip kernel, 700 + r = r runs per instance)
+    const int runs = mask_head_runs(num_insts, height, width, variant > 700 && variant < 799 ? variant - 700 : 0);
+    const int halo = (width + 1 + 63) / 64 * 64;      // logits kept from the chunk before: the row above + the pixel to the left
+    const int64_t waves = int64_t(num_insts) * runs;
+    const size_t lds_bytes = size_t(4) * size_t(halo + 384) * sizeof(float);
+    if (waves >= (int64_t(1) << 31) || lds_bytes > 64 * 1024) {
+      set_error("vnx_dynamic_mask_head_forward: %lld waves / width %d exceed the kernel's limits", (long long)waves, width);
+      return VNX_ERR_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL(dynamic_mask_head_runs_kernel<0>, dim3(uint32_t((waves + 3) / 4)), dim3(256), lds_bytes,
+                       (hipStream_t)hip_stream, (const float*)mask_feats, (const float*)reference_points,
+                       (const float*)params, num_images == 1 ? (const int*)nullptr : (const int*)inst_image, (float*)out,
+                       height, width, num_insts, stride, runs, halo);
+    return check_launch("dynamic_mask_head");
+  }
+#ifdef VNX_DEV_VARIANTS
   // lanes spent per useful pixel by the two strip shapes (see the kernel): choose the tighter one
   const int sx1 = (width + 62) / 63, sy1 = (height + kMhStripH - 1) / kMhStripH;
   const int sx2 = (width + 30) / 31, sy2 = (height + 2 * kMhStripH - 1) / (2 * kMhStripH);
@@ -716,6 +992,9 @@ extern "C" int vnx_dynamic_mask_head_forward(int dtype, const void* mask_feats,
                        (const float*)params, (const int*)inst_image, (float*)out, height, width,
                        num_insts, stride, strips_x, strips_y);
   return check_launch("dynamic_mask_head");
+#else
+  return VNX_ERR_UNSUPPORTED;   // not reached: the product build has no variants
+#endif
 }
 
 extern "C" int vnx_dynamic_mask_head_backward(int dtype, const void* mask_feats, const void* reference_points,
