@@ -23,13 +23,14 @@ def asm(tmp_path_factory):
     if not os.path.exists(HIPCC):
         pytest.skip("hipcc not available")
     out = tmp_path_factory.mktemp("isa") / "mask_head.s"
-    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-S",
+    # the development build: the product's kernels (runs forward, backward) + the strip forward kernels kept for A/B
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-DVNX_DEV_VARIANTS", "-S",
                            "--cuda-device-only", "-o", str(out), SRC], stderr=subprocess.DEVNULL)
     text = open(out).read()
     funcs = {}
     for m in re.finditer(r"^(_ZN3vnx\w*mask_head\w*):[^\n]*\n(.*?)^\.Lfunc_end", text, re.S | re.M):
         funcs[m.group(1)] = m.group(2)
-    assert len(funcs) >= 3, list(funcs)
+    assert len(funcs) >= 4, list(funcs)
     return text, funcs
 
 
