@@ -590,6 +590,90 @@ __device__ __forceinline__ void wave_sum4_to_last(float& a, float& b, float& c, 
 #undef VNX_STEP
 }
 
+// Wave sums of MANY registers at once ("transposed" reduction).  Summing one register over the 64 lanes takes six shuffle +
+// add steps whatever is done; but after the first step only half of the lanes carry anything new, so two registers can
+// share one: fold(A, B) = a register whose one half holds A's pair sums and whose other half holds B's.  N registers
+// become N / 2, N / 4, ... and finally one, in which lane l holds the complete sum of register tree_index(l): about 2 N
+// operations instead of 6 N (+ 2 N to move each total to its lane).  The six folds, by the distance of the lanes they add
+// (each checked lane by lane on the hardware: tools/fold_probe.hip):
+//   32, 16: v_permlane32_swap / v_permlane16_swap (gfx950) exchange half of A with half of B in place, one add;
+//    8, 4:  two DPP adds, each writing only lanes it has a source for and whose quad its bank_mask names
+//           (row_shr:8 / row_shl:8; row_shr:4 on quads 1, 3 / row_shl:4 on quads 0, 2 -- a "bank" is a quad of a row);
+//    2, 1:  no write mask is finer than a quad: two selects on the lane's bit (the half to keep, the half to send) and one
+//           DPP add (quad_perm).
+// A fold with no partner (N not a power of two) is the first of its two operations.
+// asm: hipcc does not know that these statements are DPP / lane-swap instructions and adds no wait states after the
+// vector instruction that produced their source (the probe read unshuffled values without them): s_nop 1 in front.
+__device__ __forceinline__ float fold32(float a, float b) {     // lanes 0..31: a[l] + a[l + 32]; lanes 32..63: b[l - 32] + b[l]
+  asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));       // a = [a.lo | b.lo], b = [a.hi | b.hi]
+  return a + b;
+}
+__device__ __forceinline__ float fold16(float a, float b) {     // rows 0, 2 (of 16 lanes): a's rows 0 + 1, 2 + 3; rows 1, 3: b's
+  asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));       // a = [a0 b0 a2 b2], b = [a1 b1 a3 b3]
+  return a + b;
+}
+__device__ __forceinline__ float fold8(float a) {               // lanes 8..15 of a row: a[l - 8] + a[l]
+  float r = a;
+  asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf" : "+v"(r) : "v"(a));
+  return r;
+}
+__device__ __forceinline__ float fold8(float a, float b) {      // ... and lanes 0..7: b[l + 8] + b[l]
+  float r = fold8(a);
+  asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_shl:8 row_mask:0xf bank_mask:0xf" : "+v"(r) : "v"(b));
+  return r;
+}
+__device__ __forceinline__ float fold4(float a) {               // quads 1, 3 of a row: a[l - 4] + a[l]
+  float r = a;
+  asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xa" : "+v"(r) : "v"(a));
+  return r;
+}
+__device__ __forceinline__ float fold4(float a, float b) {      // ... and quads 0, 2: b[l + 4] + b[l]
+  float r = fold4(a);
+  asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5" : "+v"(r) : "v"(b));
+  return r;
+}
+__device__ __forceinline__ float quad_swap2(float v) {          // v[l ^ 2]
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4e, 0xf, 0xf, false));   // quad_perm:[2,3,0,1]
+}
+__device__ __forceinline__ float quad_swap1(float v) {          // v[l ^ 1]
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xb1, 0xf, 0xf, false));   // quad_perm:[1,0,3,2]
+}
+// the sums of r[0 .. N), N <= 64: lane l of the result holds the one of r[tree_index(l)] (if that is below N)
+template <int N>
+__device__ __forceinline__ float wave_sums(float (&r)[N], int lane) {
+  static_assert(N >= 1 && N <= 64, "one tree");
+  constexpr int n1 = (N + 1) / 2, n2 = (n1 + 1) / 2, n3 = (n2 + 1) / 2, n4 = (n3 + 1) / 2, n5 = (n4 + 1) / 2;
+  const float zero = 0.f;
+#pragma unroll
+  for (int m = 0; m < n1; ++m) r[m] = fold32(r[2 * m], 2 * m + 1 < N ? r[2 * m + 1] : zero);
+#pragma unroll
+  for (int m = 0; m < n2; ++m) r[m] = fold16(r[2 * m], 2 * m + 1 < n1 ? r[2 * m + 1] : zero);
+#pragma unroll
+  for (int m = 0; m < n3; ++m) r[m] = 2 * m + 1 < n2 ? fold8(r[2 * m], r[2 * m + 1]) : fold8(r[2 * m]);
+#pragma unroll
+  for (int m = 0; m < n4; ++m) r[m] = 2 * m + 1 < n3 ? fold4(r[2 * m], r[2 * m + 1]) : fold4(r[2 * m]);
+  // (written as keep + swap(send): a select between two shuffled sums invites the compiler to shuffle the selected
+  //  value instead, which mixes the two registers)
+  const bool bit1 = (lane & 2) != 0, bit0 = (lane & 1) != 0;
+#pragma unroll
+  for (int m = 0; m < n5; ++m) {
+    if (2 * m + 1 < n4) {
+      const float a = r[2 * m], b = r[2 * m + 1];
+      r[m] = (bit1 ? b : a) + quad_swap2(bit1 ? a : b);
+    } else {
+      r[m] = r[2 * m] + quad_swap2(r[2 * m]);
+    }
+  }
+  if (n5 > 1) return (bit0 ? r[1] : r[0]) + quad_swap1(bit0 ? r[0] : r[1]);
+  return r[0] + quad_swap1(r[0]);
+}
+// which register's sum lane l holds: bit k of the index = the side taken at the fold of distance 32 >> k
+// (32, 16: the upper half / the odd rows hold the second register; 8, 4: the LOWER lanes do; 2, 1: the lane's bit)
+__device__ __forceinline__ int tree_index(int l) {
+  return ((l >> 5) & 1) | (((l >> 4) & 1) << 1) | ((((l >> 3) & 1) ^ 1) << 2) | ((((l >> 2) & 1) ^ 1) << 3) |
+         (((l >> 1) & 1) << 4) | ((l & 1) << 5);
+}
+
 // PART: the 171 lane-local accumulators + the activations of a pixel were 268 VGPRs -- ONE wave per SIMD, and the
 // training shape (120 instances x 12 strips) is 1.4 waves per SIMD, each a 6 200-instruction dependent sequence: 44.7 us.
 // Two waves per strip instead: part 0 keeps the first layer's weight gradients (80) and sends the feature gradients,
@@ -826,56 +910,43 @@ mask_head_bwd_part(const int block, const float* __restrict__ feats, const float
   }
 #undef VNX_FENCE
 
-  // wave reductions, four at a time (fused v_add_f32_dpp; interleaved, so no dependent pair is back to back); total k
-  // lands in lane k % 64 of word k / 64, then three coalesced atomics
-  float res[3] = {0.f, 0.f, 0.f};
-  uint64_t mine[3] = {0, 0, 0};     // slots of this part: word 0 = parameters 0..63, 1 = 64..127, 2 = 128..168 + the reference point
-  auto place = [&](int k, float t) {
-    const int tot = __builtin_amdgcn_readlane(__builtin_bit_cast(int, t), 63);
-    asm("v_writelane_b32 %0, %1, %2" : "+v"(res[k >> 6]) : "s"(tot), "n"(k & 63));     // lane k % 64 of the word takes the total
-    mine[k >> 6] |= uint64_t(1) << (k & 63);
-  };
-  auto put4 = [&](int k0, float a, int k1, float b, int k2, float c, int k3, float d) {
-    wave_sum4_to_last(a, b, c, d);
-    place(k0, a); place(k1, b); place(k2, c); place(k3, d);
-  };
+  // wave sums (wave_sums above): the accumulators in the order of the parameters they belong to, 64 to a tree; the lane
+  // holding a total adds it to its parameter's gradient
+  float* GP = grad_params + int64_t(j) * kMhParams;
+  const int ti = tree_index(lane);
   if constexpr (kHas0) {
+    // part 0: the first layer's 80 weights = parameters 0 .. 79
+    float t0[64], t1[16];
 #pragma unroll
-    for (int o = 0; o < kMhHidden; ++o) {
-      const int base = W0 + o * (kMhChannels + 2);
-      put4(base, acc_w0[o][0].x, base + 1, acc_w0[o][0].y, base + 2, acc_w0[o][1].x, base + 3, acc_w0[o][1].y);
-      put4(base + 4, acc_w0[o][2].x, base + 5, acc_w0[o][2].y, base + 6, acc_w0[o][3].x, base + 7, acc_w0[o][3].y);
+    for (int f = 0; f < 80; ++f) {
+      const float2_t a = acc_w0[f / (kMhChannels + 2)][(f % (kMhChannels + 2)) / 2];
+      const float v = (f & 1) ? a.y : a.x;
+      if (f < 64) t0[f] = v; else t1[f - 64] = v;
     }
-#pragma unroll
-    for (int o = 0; o < kMhHidden; o += 2) {
-      const int b0 = W0 + o * (kMhChannels + 2) + 8, b1 = b0 + (kMhChannels + 2);
-      put4(b0, acc_w0[o][4].x, b0 + 1, acc_w0[o][4].y, b1, acc_w0[o + 1][4].x, b1 + 1, acc_w0[o + 1][4].y);
-    }
+    const float s0 = wave_sums(t0, lane), s1 = wave_sums(t1, lane);
+    atomic_add(GP + ti, s0);
+    if (ti < 16) atomic_add(GP + 64 + ti, s1);
   }
   if constexpr (kHas1) {
+    // part 1: the second layer's 64 weights = parameters 80 .. 143; then w2 (144 .. 151), b0, b1, b2 (152 .. 168) and
+    // the reference point (x, y) as slots 169, 170
+    float t0[64], t1[27];
 #pragma unroll
-    for (int o = 0; o < kMhHidden; ++o) {
-      const int base = W1 + o * kMhHidden;
-      put4(base, acc_w1[o][0].x, base + 1, acc_w1[o][0].y, base + 2, acc_w1[o][1].x, base + 3, acc_w1[o][1].y);
-      put4(base + 4, acc_w1[o][2].x, base + 5, acc_w1[o][2].y, base + 6, acc_w1[o][3].x, base + 7, acc_w1[o][3].y);
+    for (int f = 0; f < 64; ++f) {
+      const float2_t a = acc_w1[f / kMhHidden][(f % kMhHidden) / 2];
+      t0[f] = (f & 1) ? a.y : a.x;
     }
-    put4(W2, acc_w2[0].x, W2 + 1, acc_w2[0].y, W2 + 2, acc_w2[1].x, W2 + 3, acc_w2[1].y);
-    put4(W2 + 4, acc_w2[2].x, W2 + 5, acc_w2[2].y, W2 + 6, acc_w2[3].x, W2 + 7, acc_w2[3].y);
 #pragma unroll
-    for (int o = 0; o < kMhHidden; o += 4) {
-      put4(B0 + o, acc_b0[o], B0 + o + 1, acc_b0[o + 1], B0 + o + 2, acc_b0[o + 2], B0 + o + 3, acc_b0[o + 3]);
-      put4(B1 + o, acc_b1[o], B1 + o + 1, acc_b1[o + 1], B1 + o + 2, acc_b1[o + 2], B1 + o + 3, acc_b1[o + 3]);
+    for (int f = 0; f < 8; ++f) {
+      t1[f] = (f & 1) ? acc_w2[f / 2].y : acc_w2[f / 2].x;
+      t1[8 + f] = acc_b0[f];
+      t1[16 + f] = acc_b1[f];
     }
-    float pad = 0.f;
-    wave_sum4_to_last(acc_b2, acc_rx, acc_ry, pad);
-    place(168, acc_b2); place(169, acc_rx); place(170, acc_ry);  // slots 169, 170 of word 2: the reference point
-  }
-  float* GP = grad_params + int64_t(j) * kMhParams;
-  if ((mine[0] >> lane) & 1) atomic_add(GP + lane, res[0]);
-  if ((mine[1] >> lane) & 1) atomic_add(GP + 64 + lane, res[1]);
-  if ((mine[2] >> lane) & 1) {
-    if (lane < kMhParams - 128) atomic_add(GP + 128 + lane, res[2]);
-    else atomic_add(grad_ref + 2 * j + (lane - (kMhParams - 128)), res[2]);
+    t1[24] = acc_b2; t1[25] = acc_rx; t1[26] = acc_ry;
+    const float s0 = wave_sums(t0, lane), s1 = wave_sums(t1, lane);
+    atomic_add(GP + W1 + ti, s0);
+    if (ti < 25) atomic_add(GP + W2 + ti, s1);
+    else if (ti < 27) atomic_add(grad_ref + 2 * j + (ti - 25), s1);
   }
 }
 
