@@ -21,6 +21,7 @@ of scope is deliberately thin:
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -46,6 +47,15 @@ def scale_tensor(values, device):
             _SCALES.clear()
         t = _SCALES[key] = torch.tensor(key[0], dtype=torch.float32, device=device)
     return t
+
+
+# The ResNet trunk runs in channels-last memory format on the GPU: MIOpen's fp32 convolutions of these shapes are NHWC
+# implicit-GEMM kernels either way, and given NCHW tensors it transposes in and out around each of them (156 + 88
+# transpose / sub-tensor launches and ~2.2 ms of a 66 ms SeqFormer step, MI355X; the step went 66.3 -> 62.1 ms).  PyTorch
+# only hands MIOpen an NHWC problem when PYTORCH_MIOPEN_SUGGEST_NHWC is set; VNX_CHANNELS_LAST=0 opts out of both.
+CHANNELS_LAST = os.environ.get("VNX_CHANNELS_LAST", "1" if torch.cuda.is_available() else "0") == "1"
+if CHANNELS_LAST:
+    os.environ.setdefault("PYTORCH_MIOPEN_SUGGEST_NHWC", "1")
 
 
 class FrozenBatchNorm2d(nn.Module):
@@ -77,7 +87,8 @@ class FrozenBatchNorm2d(nn.Module):
         scale, _ = self.folded()
         cached = getattr(self, "_expanded", None)
         if cached is None or cached[0] is not scale or cached[1].shape != weight.shape or cached[1].device != weight.device:
-            cached = self._expanded = (scale, scale.reshape(-1, 1, 1, 1).expand_as(weight).contiguous())
+            fmt = torch.channels_last if CHANNELS_LAST else torch.contiguous_format
+            cached = self._expanded = (scale, scale.reshape(-1, 1, 1, 1).expand_as(weight).contiguous(memory_format=fmt))
         return cached[1]
 
     def forward(self, x):
@@ -172,6 +183,8 @@ class ResNet50Trunk(nn.Module):
         self.res3 = stage(256, 128, 512, 4, 2)
         self.res4 = stage(512, 256, 1024, 6, 2)
         self.res5 = stage(1024, 512, 2048, 3, 2)
+        if CHANNELS_LAST:
+            self.to(memory_format=torch.channels_last)
 
     def freeze(self, freeze_at=2):
         """detectron2's MODEL.BACKBONE.FREEZE_AT (default 2, kept by the reference's configs): the
@@ -183,6 +196,8 @@ class ResNet50Trunk(nn.Module):
         return self
 
     def forward(self, x):
+        if CHANNELS_LAST:
+            x = x.contiguous(memory_format=torch.channels_last)
         blocks = [b for stage in (self.res2, self.res3, self.res4, self.res5) for b in stage]
         folded = fold_all([(self.stem[0], self.stem[1])] + [p for b in blocks for p in b.pairs()])
         x = F.max_pool2d(F.relu(conv_bn(x, self.stem[0], self.stem[1], folded[self.stem[0]])), 3, 2, 1)
