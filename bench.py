@@ -520,7 +520,7 @@ def head_rooflines(device):
             us = event_time_us(capture(fns), len(fns), reps=9)
         nbytes = 4 * (8 * H * W + n * 171 + n * 4 * H * W)
         out[f"mask_head_fwd_{name}_n300"] = {
-            "bound": "hbm", "kernel": "dynamic_mask_head_kernel", "us_per_launch": us, "algorithmic_bytes": nbytes,
+            "bound": "hbm", "kernel": "dynamic_mask_head_runs_kernel", "us_per_launch": us, "algorithmic_bytes": nbytes,
             "achieved": nbytes / us / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / us / 1e3 / HBM_PEAK_GBS,
             "what": f"one {name} frame, 300 instances -> logits [300, {2 * H}, {2 * W}] fp32"}
     # training shape: T = 5 frames x 6 decoder layers x 4 matched instances, forward + backward
@@ -553,7 +553,7 @@ def head_rooflines(device):
         us = e0.elapsed_time(e1) * 1e3 / 20
     nbytes = 4 * (2 * 8 * n_img * H * W + 2 * n * 171 + 2 * n * 4 * H * W)      # forward traffic + the same for the gradients
     out["mask_head_fwd_bwd_train_360p_n120"] = {
-        "bound": "hbm", "kernel": "dynamic_mask_head_kernel + dynamic_mask_head_bwd_kernel", "timing": how,
+        "bound": "hbm", "kernel": "dynamic_mask_head_runs_kernel + dynamic_mask_head_bwd_kernel", "timing": how,
         "us_per_step": us, "algorithmic_bytes": nbytes, "achieved": nbytes / us / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": nbytes / us / 1e3 / HBM_PEAK_GBS, "what": "5 frames x 24 matched instances (6 decoder layers x 4 tracks), 360p"}
     # reid: 300 detections x 300 memory embeddings x 256 channels, dot and cosine, + bi-softmax

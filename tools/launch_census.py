@@ -22,7 +22,7 @@ clips = T.synthetic_clips(2, 5, 360, 640, dev, seed=100, num_instances=4)
 for _ in range(3):
     T.train_step(model, opt, clips)
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
     T.train_step(model, opt, clips)
     torch.cuda.synchronize()
 
@@ -53,3 +53,16 @@ for name, (n, t) in sorted(ops.items(), key=lambda kv: -kv[1][0])[:40]:
 print("--- by (frame, operator), most launches first")
 for (fr, name), (n, t) in sorted(by.items(), key=lambda kv: -kv[1][0])[:90]:
     print("%5d %9.1f us  %-60s %s" % (n, t, fr[:60], name[:50]))
+
+print("--- glue operators by input shapes, most device time first")
+shapes = collections.defaultdict(lambda: [0, 0.0])
+for ev in prof.events():
+    ks = getattr(ev, "kernels", None) or []
+    if not ks or ev.device_type != torch.autograd.DeviceType.CPU:
+        continue
+    if ev.name in ("aten::add_", "aten::sum", "aten::copy_", "aten::add", "aten::mul", "aten::cat", "aten::div", "aten::clamp_min",
+                   "aten::threshold_backward", "aten::fill_", "aten::sub", "aten::bmm", "aten::clamp"):
+        key = (ev.name, str(ev.input_shapes)[:90])
+        shapes[key][0] += len(ks); shapes[key][1] += sum(k.duration for k in ks)
+for (name, sh), (n, t) in sorted(shapes.items(), key=lambda kv: -kv[1][1])[:70]:
+    print("%5d %9.1f us  %-26s %s" % (n, t, name, sh))

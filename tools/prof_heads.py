@@ -1,6 +1,6 @@
 """Exercises every kernel of the path outside MSDeformAttn so that `rocprofv3 --kernel-trace --stats -- python
 tools/prof_heads.py` records them (nothing under profiles/ backed the bench numbers of these):
-dynamic_mask_head_kernel / dynamic_mask_head_bwd_kernel (inference frames at 360p / 720p, the training shape forward +
+dynamic_mask_head_runs_kernel / dynamic_mask_head_bwd_kernel (inference frames at 360p / 720p, the training shape forward +
 backward), reid_similarity_kernel, bisoftmax_kernel, mask_pack / mask_inter / tracker_frame_kernel (a 40-frame video),
 add_dropout_layernorm_fwd / bwd + layernorm_param_grad.  Prints the same timings bench.py reports (development tool)."""
 import json
