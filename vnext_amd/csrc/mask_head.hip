@@ -529,6 +529,10 @@ static int mask_head_runs(int n, int H, int W, int forced) {
 #define VNX_MB_ROWS 8
 #endif
 constexpr int kMbRows = VNX_MB_ROWS;
+#ifndef VNX_MB_GROUP
+#define VNX_MB_GROUP 4
+#endif
+constexpr int kMbGroup = VNX_MB_GROUP;   // waves (consecutive instances) per workgroup of the backward
 
 struct UpAdj { float d, c, b, a; };  // what a pixel's 2x2 output block sends to in[y][x], in[y][x-1], in[y-1][x], in[y-1][x-1]
 
@@ -686,18 +690,62 @@ mask_head_bwd_part(const int block, const float* __restrict__ feats, const float
                    const float* __restrict__ params, const int* __restrict__ inst_image,
                    const float* __restrict__ grad_out, float* __restrict__ grad_feats,
                    float* __restrict__ grad_ref, float* __restrict__ grad_params,
-                   int H, int W, int n_inst, int stride, int strips_x, int strips_y) {
-  const int lane = threadIdx.x;
+                   int H, int W, int n_inst, int stride, int strips_x, int strips_y, float* __restrict__ pool,
+                   int* __restrict__ pool_img) {
+  // `block` = (group of kMbGroup consecutive instances, strip): the wave's instance is group * kMbGroup + its index.
+  // pool: the workgroup's LDS [2][kMbGroup][8 planes][64 lanes] through which part 0's waves add up their feature
+  // gradients when they all belong to one frame (see the kernel below); null for part 1.
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int strips = strips_x * strips_y;
-  const int j = block / strips;  // instance
-  if (j >= n_inst) return;
-  const int s = block - j * strips;
+  const int q = block / strips;  // group
+  const int j = q * kMbGroup + wave;  // instance
+  const int s = block - q * strips;
   const int sy = s / strips_x, sx = s - sy * strips_x;
   const int x = sx * kMhStripW + lane;               // lane 63 is the right halo
   const int xc = x > W - 1 ? W - 1 : x;
   const int y0 = sy * kMbRows;
   const bool col_ok = x < W;
   const bool owner = col_ok && lane < kMhStripW;
+
+  constexpr bool kPools = PART == 0 && kMbGroup > 1;
+  bool pooled = false;
+  int pool_frame = 0;
+  if constexpr (kPools) {
+    // publish the frame of every wave's instance and agree on whether the group is one frame's
+    if (lane == 0) pool_img[wave] = j < n_inst ? inst_image[j] : -1;
+    __syncthreads();
+    pooled = true;
+    pool_frame = pool_img[0];                        // wave 0's instance exists if any of the group's does
+#pragma unroll
+    for (int w = 1; w < kMbGroup; ++w) pooled = pooled && (pool_img[w] == pool_frame || pool_img[w] < 0);
+  }
+  // Row r's feature gradients of the group's waves -> one atomic per pixel and plane: every wave stores its eight values
+  // in its slab (plain LDS stores: ds_add_f32 runs at 0.4 lanes per clock on this part), one barrier, then
+  // wave w sums plane w (w + kMbGroup, ...) over the slabs and sends it.  Two sets of slabs alternate by the row's parity,
+  // so a wave may write row r + 1 while another still reads row r.
+  auto exchange = [&](int r, int y, const float (&v)[kMhChannels]) {
+    float* const set = pool + (r & 1) * (kMbGroup * kMhChannels * 64);
+#pragma unroll
+    for (int c = 0; c < kMhChannels; ++c) set[(wave * kMhChannels + c) * 64 + lane] = v[c];
+    __syncthreads();
+    float* const GFq = grad_feats + int64_t(pool_frame) * kMhChannels * H * W;
+    for (int c = wave; c < kMhChannels; c += kMbGroup) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < kMbGroup; ++w) t += set[(w * kMhChannels + c) * 64 + lane];
+      if (owner) atomic_add(GFq + (int64_t(c) * H + y) * W + x, t);
+    }
+  };
+  if (j >= n_inst) {
+    if constexpr (kPools) {
+      if (pooled) {           // no instance: zeros into the exchange, but this wave's share of the sums is real
+        const float zeros[kMhChannels] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < kMbRows && y0 + r < H; ++r) exchange(r, y0 + r, zeros);
+      }
+    }
+    return;
+  }
 
   const float* P = params + int64_t(j) * kMhParams;
   constexpr int W0 = 0, W1 = 80, W2 = 144, B0 = 152, B1 = 160;
@@ -711,7 +759,11 @@ mask_head_bwd_part(const int block, const float* __restrict__ feats, const float
 
   auto up_adj = [&](int y) -> UpAdj {
     float2_t top = {0.f, 0.f}, bot = {0.f, 0.f};
+#if defined(VNX_MB_ABL) && (VNX_MB_ABL & 8)      // timing ablation: no upstream-gradient loads
+    if (y < H && col_ok && relx == 1234.5f) {
+#else
     if (y < H && col_ok) {
+#endif
       top = *reinterpret_cast<const float2_t*>(G + int64_t(2 * y) * (2 * W) + 2 * x);
       bot = *reinterpret_cast<const float2_t*>(G + int64_t(2 * y + 1) * (2 * W) + 2 * x);
     }
@@ -765,7 +817,11 @@ mask_head_bwd_part(const int block, const float* __restrict__ feats, const float
     for (int q = 0; q < 8; ++q) g.w[q] = t[q];
   };
   auto landed = [&](Group& g) {
+#if defined(VNX_MB_ABL) && (VNX_MB_ABL & 2)      // timing ablation: the parameter groups are not waited for
+    asm volatile("" : "+s"(g.w), "+s"(g.w2), "+s"(g.b)::"memory");
+#else
     asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(g.w), "+s"(g.w2), "+s"(g.b)::"memory");
+#endif
   };
   auto wpair = [](const Group& g, int k) -> uint64_t {   // weights 2k, 2k + 1 of the group as one SGPR pair
     return k < 8 ? (uint64_t(g.w[2 * k + 1]) << 32) | g.w[2 * k] : (uint64_t(g.w2[2 * (k - 8) + 1]) << 32) | g.w2[2 * (k - 8)];
@@ -797,7 +853,11 @@ mask_head_bwd_part(const int block, const float* __restrict__ feats, const float
     x0[0] = float2_t{relx, refy - (float(y * stride) + half)};
 #pragma unroll
     for (int c = 0; c < kMhChannels; c += 2)
+#if defined(VNX_MB_ABL) && (VNX_MB_ABL & 4)      // timing ablation: no feature loads
+      x0[1 + c / 2] = float2_t{relx * float(c), refy * float(y)};
+#else
       x0[1 + c / 2] = float2_t{F[(int64_t(c) * H + y) * W + xc], F[(int64_t(c + 1) * H + y) * W + xc]};
+#endif
 
     // ---- forward, recomputed: a dot product is a chain of packed FMAs over input pairs + one add of the halves
     float2_t x1[kP1], x2[kP1];
@@ -899,7 +959,20 @@ mask_head_bwd_part(const int block, const float* __restrict__ feats, const float
 #undef VNX_BWD1
     if constexpr (kHas1) { acc_rx += g0[0].x; acc_ry += g0[0].y; }     // rel = ref - pixel centre
     if constexpr (kHas0) {
-      if (owner) {
+      bool direct = true;
+      if constexpr (kPools) {
+        if (pooled) {
+          float v[kMhChannels];
+#pragma unroll
+          for (int c = 0; c < kMhChannels; c += 2) {
+            v[c] = owner ? g0[1 + c / 2].x : 0.f;
+            v[c + 1] = owner ? g0[1 + c / 2].y : 0.f;
+          }
+          exchange(r, y, v);
+          direct = false;
+        }
+      }
+      if (direct && owner) {
 #pragma unroll
         for (int c = 0; c < kMhChannels; c += 2) {
           atomic_add(GF + (int64_t(c) * H + y) * W + x, g0[1 + c / 2].x);
@@ -969,31 +1042,30 @@ zero3_kernel(float* __restrict__ a, size_t na, float* __restrict__ b, size_t nb,
 }
 
 // one launch, the two parts of a strip in neighbouring workgroups (they read the same features and upstream gradients)
-// (VNX_MH_BWD_SINGLE: A/B build, one wave per strip doing both parts -- no recomputation, 256 VGPRs + 19 spilled)
-#ifdef VNX_MH_BWD_SINGLE
-constexpr int kMbParts = 1;
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
-#else
+// One launch; a workgroup = kMbGroup waves = the same strip and part for kMbGroup consecutive instances, the two parts of a
+// (group, strip) in neighbouring workgroups (they read the same features and upstream gradients).
+// Why groups: the feature gradients of all instances of a frame add into the same [8, H, W] planes, and the chip does
+// 322 G fp32 atomics per second (tools/atomic_bench.hip): 120 instances x 12 strips x 8 rows x 8 planes x 63 lanes = 5.8 M
+// of them are 18 us on their own, under a kernel whose arithmetic is 15 us (without them the forward + backward graph ran
+// 35.2 instead of 40.2 us).  Consecutive instances are the same frame's (the callers pass per-frame counts), so the waves of
+// a group add into LDS first and the workgroup issues one global atomic per pixel and plane; a group that straddles two
+// frames falls back to per-wave atomics.
 constexpr int kMbParts = 2;
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
-#endif
+__global__ void __launch_bounds__(64 * kMbGroup) __attribute__((amdgpu_waves_per_eu(3, 3)))
 dynamic_mask_head_bwd_kernel(const float* __restrict__ feats, const float* __restrict__ ref,
                              const float* __restrict__ params, const int* __restrict__ inst_image,
                              const float* __restrict__ grad_out, float* __restrict__ grad_feats,
                              float* __restrict__ grad_ref, float* __restrict__ grad_params,
                              int H, int W, int n_inst, int stride, int strips_x, int strips_y) {
-#ifdef VNX_MH_BWD_SINGLE
-  mask_head_bwd_part<2>(int(blockIdx.x), feats, ref, params, inst_image, grad_out, grad_feats, grad_ref, grad_params, H, W, n_inst,
-                        stride, strips_x, strips_y);
-#else
+  __shared__ float pool[kMbGroup > 1 ? 2 * kMbGroup * kMhChannels * 64 : 1];
+  __shared__ int pool_img[kMbGroup];
   const int block = int(blockIdx.x >> 1);
   if (blockIdx.x & 1)
     mask_head_bwd_part<1>(block, feats, ref, params, inst_image, grad_out, grad_feats, grad_ref, grad_params, H, W, n_inst,
-                          stride, strips_x, strips_y);
+                          stride, strips_x, strips_y, nullptr, nullptr);
   else
     mask_head_bwd_part<0>(block, feats, ref, params, inst_image, grad_out, grad_feats, grad_ref, grad_params, H, W, n_inst,
-                          stride, strips_x, strips_y);
-#endif
+                          stride, strips_x, strips_y, pool, pool_img);
 }
 
 }  // namespace vnx
@@ -1115,12 +1187,13 @@ extern "C" int vnx_dynamic_mask_head_backward(int dtype, const void* mask_feats,
   }
   const int strips_x = (width + kMhStripW - 1) / kMhStripW;
   const int strips_y = (height + kMbRows - 1) / kMbRows;
-  const int64_t blocks = int64_t(num_insts) * strips_x * strips_y * kMbParts;      // two parts per strip
+  const int64_t groups = (int64_t(num_insts) + kMbGroup - 1) / kMbGroup;
+  const int64_t blocks = groups * strips_x * strips_y * kMbParts;                  // two parts per (group, strip)
   if (blocks >= (int64_t(1) << 31)) {
     set_error("vnx_dynamic_mask_head_backward: %lld workgroups exceed the grid limit", (long long)blocks);
     return VNX_ERR_UNSUPPORTED;
   }
-  hipLaunchKernelGGL(dynamic_mask_head_bwd_kernel, dim3(uint32_t(blocks)), dim3(64), 0, stream,
+  hipLaunchKernelGGL(dynamic_mask_head_bwd_kernel, dim3(uint32_t(blocks)), dim3(64 * kMbGroup), 0, stream,
                      (const float*)mask_feats, (const float*)reference_points, (const float*)params,
                      (const int*)inst_image, (const float*)grad_out, (float*)grad_feats, (float*)grad_ref,
                      (float*)grad_params, height, width, num_insts, stride, strips_x, strips_y);
