@@ -49,10 +49,15 @@ def scale_tensor(values, device):
     return t
 
 
-# The ResNet trunk runs in channels-last memory format on the GPU: MIOpen's fp32 convolutions of these shapes are NHWC
-# implicit-GEMM kernels either way, and given NCHW tensors it transposes in and out around each of them (156 + 88
-# transpose / sub-tensor launches and ~2.2 ms of a 66 ms SeqFormer step, MI355X; the step went 66.3 -> 62.1 ms).  PyTorch
-# only hands MIOpen an NHWC problem when PYTORCH_MIOPEN_SUGGEST_NHWC is set; VNX_CHANNELS_LAST=0 opts out of both.
+# TRAINING steps run the ResNet trunk in channels-last memory format on the GPU: MIOpen's fp32 convolutions of these shapes
+# are NHWC implicit-GEMM kernels in the backward either way, and given NCHW tensors it transposes in and out around each of
+# them (156 + 88 transpose / sub-tensor launches, ~2.2 ms of a 66 ms SeqFormer step on MI355X).  PyTorch only hands MIOpen an
+# NHWC problem when PYTORCH_MIOPEN_SUGGEST_NHWC is set.  Measured on one box (bench.py model legs, ms per step, NCHW -> this):
+# SeqFormer fp32 two clips 66.2 -> 64.3, one clip 52.4 -> 50.6, bf16 autocast 76.9 -> 74.3, IDOL bf16 pair 67.1 -> 65.8.
+# Inference keeps NCHW (forward-only NHWC is slower: SeqFormer 12.0 -> 12.9 ms per clip, IDOL 720p 185 -> 172 frames/s),
+# which is why the filters stay NCHW (channels-last filters select NHWC whatever the input is).  A training-only process can
+# set VNX_CHANNELS_LAST_WEIGHTS=1 to store the filters channels-last as well (no per-call filter conversion: IDOL pair
+# 65.8 -> 60.7 ms, bf16 autocast 74.3 -> 69.7; fp32 SeqFormer unchanged).  VNX_CHANNELS_LAST=0 opts out of all of it.
 CHANNELS_LAST = os.environ.get("VNX_CHANNELS_LAST", "1" if torch.cuda.is_available() else "0") == "1"
 if CHANNELS_LAST:
     os.environ.setdefault("PYTORCH_MIOPEN_SUGGEST_NHWC", "1")
@@ -87,7 +92,8 @@ class FrozenBatchNorm2d(nn.Module):
         scale, _ = self.folded()
         cached = getattr(self, "_expanded", None)
         if cached is None or cached[0] is not scale or cached[1].shape != weight.shape or cached[1].device != weight.device:
-            fmt = torch.channels_last if CHANNELS_LAST else torch.contiguous_format
+            fmt = torch.channels_last if weight.dim() == 4 and weight.is_contiguous(memory_format=torch.channels_last) \
+                and not weight.is_contiguous() else torch.contiguous_format
             cached = self._expanded = (scale, scale.reshape(-1, 1, 1, 1).expand_as(weight).contiguous(memory_format=fmt))
         return cached[1]
 
@@ -183,7 +189,7 @@ class ResNet50Trunk(nn.Module):
         self.res3 = stage(256, 128, 512, 4, 2)
         self.res4 = stage(512, 256, 1024, 6, 2)
         self.res5 = stage(1024, 512, 2048, 3, 2)
-        if CHANNELS_LAST:
+        if CHANNELS_LAST and os.environ.get("VNX_CHANNELS_LAST_WEIGHTS", "0") == "1":
             self.to(memory_format=torch.channels_last)
 
     def freeze(self, freeze_at=2):
@@ -196,7 +202,7 @@ class ResNet50Trunk(nn.Module):
         return self
 
     def forward(self, x):
-        if CHANNELS_LAST:
+        if CHANNELS_LAST and self.training and torch.is_grad_enabled():
             x = x.contiguous(memory_format=torch.channels_last)
         blocks = [b for stage in (self.res2, self.res3, self.res4, self.res5) for b in stage]
         folded = fold_all([(self.stem[0], self.stem[1])] + [p for b in blocks for p in b.pairs()])
