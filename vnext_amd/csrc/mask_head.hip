@@ -9,14 +9,14 @@
 //   :640-662  "aligned bilinear" x2 up-sampling (replicate pad, align_corners interpolate, pad, crop).
 // Here it is one kernel: nothing but the [n, 2H, 2W] logits is ever written.
 //
-// Mapping: one wave per (instance, strip of 63 columns x R rows).  The instance is wave-uniform:
-// its 169 parameters are fetched with three vector loads, kept across the lanes and broadcast
-// into SGPRs with v_readlane as the three layers (v_pk_fma_f32 chains) consume them; the 8 features of a pixel are 8 coalesced loads; relative
-// coordinates are computed, never stored.  The up-sampling needs each pixel's left / upper
-// neighbours: the strip's rows (and one halo row above) are all held in registers, the upper
-// neighbour is the previous row's register and the left neighbour comes from the lane below with
-// one DPP move; lane 0 and the first row are a one-pixel halo (computed, not stored), so no LDS
-// and no barrier is used at all.
+// Forward (dynamic_mask_head_runs_kernel): a wave takes a run of whole image rows of one instance in row-major order --
+// every lane a pixel, 64 consecutive pixels per register -- and walks it in chunks of up to three register pairs.  The
+// instance is wave-uniform: its 169 parameters stream through the scalar file in groups of two output channels and feed
+// v_pk_fma_f32 chains; the 8 features of a pixel are 8 coalesced loads, prefetched a chunk ahead; relative coordinates are
+// computed, never stored.  The up-sampling needs each pixel's left / upper neighbours: the wave keeps its logits (and the
+// last row of the chunk before) in its own piece of LDS and reads them there; a run that does not start at the top of
+// the frame computes the row above it first.  (Rounds 1 - 3: strips of 63 columns x 5 rows per wave, neighbours by DPP --
+// kept in the development build, variant 799.)
 // out[2y  ][2x] = (a+b+c+d)/4   out[2y  ][2x+1] = (b+d)/2      a = in[y-1][x-1]  b = in[y-1][x]
 // out[2y+1][2x] = (c+d)/2       out[2y+1][2x+1] = d            c = in[y  ][x-1]  d = in[y  ][x]
 // with indices clamped at 0 -- the closed form of the reference's pad/interpolate/pad/crop.
@@ -547,17 +547,6 @@ __device__ __forceinline__ float dpp_fold(float v) {
   return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
 }
 
-// sum over the 64 lanes; valid in lane 63
-__device__ __forceinline__ float wave_sum_to_last(float v) {
-  v = dpp_fold<0x111, 0xF>(v);  // row_shr:1
-  v = dpp_fold<0x112, 0xF>(v);  // row_shr:2
-  v = dpp_fold<0x114, 0xF>(v);  // row_shr:4
-  v = dpp_fold<0x118, 0xF>(v);  // row_shr:8   -> lane 15 of each row holds the row's sum
-  v = dpp_fold<0x142, 0xA>(v);  // row_bcast:15 -> rows 1, 3
-  v = dpp_fold<0x143, 0xC>(v);  // row_bcast:31 -> rows 2, 3
-  return v;
-}
-
 // packed FMA forms of the backward kernel (two FMAs per issued instruction):
 //   pk_fma_sv:  d += (scalar pair of weights) * (pair of inputs)
 //   pk_fma_sb:  d += (scalar pair of weights) * (one gradient, the low / high half of g, for both lanes)
@@ -574,24 +563,6 @@ template <bool HI>
 __device__ __forceinline__ void pk_fma_bv(float2_t& d, float2_t g, float2_t x) {
   if (HI) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(d) : "v"(g), "v"(x));
   else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(d) : "v"(g), "v"(x));
-}
-
-// four wave sums at once, each valid in lane 63: the steps of wave_sum_to_last as fused DPP adds, the four chains
-// interleaved so that no instruction reads the result of the one before it (a lane without a source keeps its value)
-__device__ __forceinline__ void wave_sum4_to_last(float& a, float& b, float& c, float& d) {
-#define VNX_STEP(ctrl) \
-      "v_add_f32_dpp %0, %0, %0 " ctrl "\n\tv_add_f32_dpp %1, %1, %1 " ctrl "\n\tv_add_f32_dpp %2, %2, %2 " ctrl "\n\tv_add_f32_dpp %3, %3, %3 " ctrl "\n\t"
-  asm volatile(
-      "s_nop 1\n\t"
-      VNX_STEP("row_shr:1 row_mask:0xf bank_mask:0xf")
-      VNX_STEP("row_shr:2 row_mask:0xf bank_mask:0xf")
-      VNX_STEP("row_shr:4 row_mask:0xf bank_mask:0xf")
-      VNX_STEP("row_shr:8 row_mask:0xf bank_mask:0xf")
-      VNX_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
-      VNX_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
-      "s_nop 0"
-      : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
-#undef VNX_STEP
 }
 
 // Wave sums of MANY registers at once ("transposed" reduction).  Summing one register over the 64 lanes takes six shuffle +
