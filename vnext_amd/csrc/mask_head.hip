@@ -1073,8 +1073,8 @@ extern "C" int vnx_dynamic_mask_head_forward(int dtype, const void* mask_feats,
     const int halo = (width + 1 + 63) / 64 * 64;      // logits kept from the chunk before: the row above + the pixel to the left
     const int64_t waves = int64_t(num_insts) * runs;
     const size_t lds_bytes = size_t(4) * size_t(halo + 384) * sizeof(float);
-    if (waves >= (int64_t(1) << 31) || lds_bytes > 64 * 1024) {
-      set_error("vnx_dynamic_mask_head_forward: %lld waves / width %d exceed the kernel's limits", (long long)waves, width);
+    if (waves >= (int64_t(1) << 31) || lds_bytes > 64 * 1024 || int64_t(height) * width >= (int64_t(1) << 26)) {   // 32-bit byte offsets into a frame's output
+      set_error("vnx_dynamic_mask_head_forward: %lld waves / frame %d x %d exceed the kernel's limits", (long long)waves, height, width);
       return VNX_ERR_UNSUPPORTED;
     }
     hipLaunchKernelGGL(dynamic_mask_head_runs_kernel<0>, dim3(uint32_t((waves + 3) / 4)), dim3(256), lds_bytes,
