@@ -102,8 +102,8 @@ enum {
  * tags); from 1 024 queries up (4 levels x 4 points) 8 B per (batch, head, level, query tile), a tile
  * being the queries one wave of the grad_loc kernel handles (4 on calls of up to 262 144 query rows, 8
  * beyond), plus the fp32 partial rows in which the query pieces of the coarse levels meet (at most
- * 8 x min(S, 4 096) rows of 128 B per (batch, head)) -- size the scratch with this function, not by
- * hand.  16-bit values additionally need an fp32 [B, S, M, 32] image of grad_value when the levels are
+ * 16 x min(S, 4 096) rows of 128 B per (batch, head) on calls of fewer than 32 (batch, head) pairs, 4 x
+ * from 32 pairs up) -- size the scratch with this function, not by hand.  16-bit values additionally need an fp32 [B, S, M, 32] image of grad_value when the levels are
  * not promised packed (the general path accumulates with fp32 atomics), or on the record-fed path with
  * >= 1 024 queries (other level / point counts than 4 x 4).  Other head widths: that image for 16-bit
  * values, else 0.
