@@ -108,7 +108,11 @@ __device__ __forceinline__ void mask_logits(const float* P, const float2_t (&x0)
                  : "memory");
   };
   auto landed = [&](Group& g) {   // everything issued so far is in its registers (the loads are invisible to hipcc's own counting)
+#if defined(VNX_MH_ABL) && (VNX_MH_ABL & 8)     // timing ablation: the parameter groups are not waited for
+    asm volatile("" : "+s"(g.w), "+s"(g.w2), "+s"(g.b)::"memory");
+#else
     asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(g.w), "+s"(g.w2), "+s"(g.b)::"memory");
+#endif
   };
   auto wpair = [](const Group& g, int k) -> uint64_t {   // weights 2k, 2k + 1 of the group as one SGPR pair
     return k < 8 ? (uint64_t(g.w[2 * k + 1]) << 32) | g.w[2 * k] : (uint64_t(g.w2[2 * (k - 8) + 1]) << 32) | g.w2[2 * (k - 8)];
