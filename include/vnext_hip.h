@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define VNX_ABI_VERSION 11
+#define VNX_ABI_VERSION 12
 
 /* element types */
 enum {
@@ -93,13 +93,25 @@ enum {
    * issues both the fast kernels and the general ones, each set exiting at once when
    * the predicate is not theirs (no host synchronisation, ~2 empty launches).
    */
-  VNX_MSDA_LEVELS_PACKED = 1
+  VNX_MSDA_LEVELS_PACKED = 1,
+  /*
+   * Fork the call: a backward call below 1 024 queries (32-channel heads) is two kernels neither of which reads what the
+   * other writes (grad_value; grad_sampling_loc + grad_attn_weight).  By default they run one after the other on
+   * `hip_stream`.  With this flag the grad_value kernel is launched on a side stream the library keeps per host thread
+   * and device (created on first use, never synchronised with the host), between an event recorded on `hip_stream` and an
+   * event `hip_stream` then waits for: the two kernels share the GPU, `hip_stream` sees the call as one operation, a stream
+   * capture records a fork and a join.  Measured on MI355X / ROCm 7.2: the pair then spans 24.3
+   * instead of 29.1 us, but the two cross-queue dependencies cost a captured graph 9 us per call and an eager caller
+   * 19 us -- a loss today, hence opt-in.
+   */
+  VNX_MSDA_FORK = 2
 };
 
 /*
- * Bytes of scratch vnx_msda_backward needs for these sizes and flags.  32-channel heads: what the
- * grad_loc kernel hands the grad_value kernel -- below 1 024 queries 20 B per sample (records + unit
- * tags); from 1 024 queries up (4 levels x 4 points) 8 B per (batch, head, level, query tile), a tile
+ * Bytes of scratch vnx_msda_backward needs for these sizes and flags.  32-channel heads: below 1 024
+ * queries NONE (since ABI 12: the grad_value kernel decodes the op's own inputs; until ABI 11 the grad_loc
+ * kernel left it 20 B per sample of records + unit tags); from 1 024 queries up (4 levels x 4 points) what
+ * the grad_loc kernel hands the grad_value kernel -- 8 B per (batch, head, level, query tile), a tile
  * being the queries one wave of the grad_loc kernel handles (4 on calls of up to 262 144 query rows, 8
  * beyond), plus the fp32 partial rows in which the query pieces of the coarse levels meet (at most
  * 16 x min(S, 4 096) rows of 128 B per (batch, head) on calls of fewer than 32 (batch, head) pairs, 4 x

@@ -14,15 +14,8 @@
 extern "C" {
 #endif
 
-/*
- * Kernel-span stamps.  While a buffer is armed every launch of a tuned MSDA kernel takes a region of
- * 2 x gridDim 64-bit words and each workgroup leaves {its start, its last wave's end} there in
- * constant-rate wall-clock ticks (vnx_debug_wall_clock_khz).  buf: n_words zero-filled 64-bit words;
- * nullptr disarms.  vnx_debug_stamp_regions -> number of regions handed out since arming; per region the
- * kernel kind (1 forward, 2 grad_loc / grad_attn, 3 grad_value), word offset, workgroups.
- */
-void vnx_debug_arm_stamps(void* buf, long long n_words);
-int vnx_debug_stamp_regions(int* kinds, long long* offsets, long long* blocks, int n);
+/* Rate of the constant-rate wall clock the kernel-span stamps of the development build are taken in
+ * (include/vnext_hip_dev.h: vnx_debug_arm_stamps), kHz; 0 when it cannot be read. */
 int vnx_debug_wall_clock_khz(void);
 
 /*
@@ -44,6 +37,13 @@ int vnx_debug_row_gather_probe(const void* rows, size_t n_rows, const uint32_t* 
  * write into the next (batch, head)'s); 0 on success.  No GPU needed (tests/test_units_bound.py). */
 int vnx_debug_gvtiles_units(const int64_t* host_shapes, int levels, int num_query, int batch, int heads, int units_min,
                             int* units_used, int* units_bound, long long* partial_rows_used, long long* partial_rows_bound);
+
+/* The same check for the self-decoding grad_value kernel of calls below 1 024 queries (msda_d32_gvdirect.hip;
+ * gvd_level_split in vnx_common.h).  Writes, per (batch, head), the workgroups the kernel's level table yields and the
+ * launcher's bound; per level (any of the three arrays may be null; `levels` entries each) the units, the rows per unit
+ * and log2 of the 8-lane groups that share a row.  0 on success.  No GPU needed (tests/test_gvdirect_model.py). */
+int vnx_debug_gvdirect_units(const int64_t* host_shapes, int levels, int num_query, int num_point, int* units_used,
+                             int* units_bound, int* level_units, int* level_rows_per_unit, int* level_group_shift);
 
 #ifdef __cplusplus
 }

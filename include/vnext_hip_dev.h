@@ -26,6 +26,16 @@ extern "C" {
 void vnx_set_kernel_variant(int variant);
 int vnx_get_kernel_variant(void);
 
+/*
+ * Kernel-span stamps (process-wide state, hence development build only).  While a buffer is armed every launch of a tuned
+ * MSDA kernel takes a region of 2 x gridDim 64-bit words and each workgroup leaves {its start, its last wave's end} there in
+ * constant-rate wall-clock ticks (vnx_debug_wall_clock_khz, vnext_hip_debug.h).  buf: n_words zero-filled 64-bit words;
+ * nullptr disarms.  vnx_debug_stamp_regions -> number of regions handed out since arming; per region the kernel kind
+ * (1 forward, 2 grad_loc / grad_attn, 3 grad_value), word offset, workgroups.
+ */
+void vnx_debug_arm_stamps(void* buf, long long n_words);
+int vnx_debug_stamp_regions(int* kinds, long long* offsets, long long* blocks, int n);
+
 /* phase stamps of the record-fed grad_value kernel (variants 408 / 412) and of the tiled forward (701 / 702): copies
  * n 64-bit words of the kernel's fixed device array to `host`; returns a hipError_t as int */
 int vnx_debug_read_rec_stamps(unsigned long long* host, int n);

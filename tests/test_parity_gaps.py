@@ -120,6 +120,24 @@ def test_grid_sample_fallback_matches_the_reference_goldens(name):
             np.testing.assert_allclose(v.grad.numpy(), g["grad_value"], rtol=1e-8, atol=1e-11 * scale(g["grad_value"]))
 
 
+@pytest.mark.parametrize("name", [n for n in golden_names() if "d1025" not in n and "d2048" not in n and "d3096" not in n])
+def test_frame_loop_fallback_matches_the_reference_goldens(name):
+    """msda_core_frames -- the reference's function as the module's frame loop drives it, what bench.py reports as
+    `cpu_baseline.value` since round 5 -- on the same vectors, every batch element presented as a frame of one clip."""
+    from oracle.msda_torch_fallback import msda_core_frames
+    g = load_golden(name)
+    v, l, a = (torch.from_numpy(np.ascontiguousarray(g[k])).double().requires_grad_(True) for k in ("value", "loc", "attn"))
+    sizes = [tuple(int(x) for x in hw) for hw in g["shapes"]]
+    out = msda_core_frames(v.unsqueeze(0), sizes, l.unsqueeze(0), a.unsqueeze(0))[0]
+    np.testing.assert_allclose(out.detach().numpy(), g["out_f64"], rtol=1e-9, atol=1e-12 * scale(g["out_f64"]))
+    if "grad_out" in g and "grad_loc" in g:
+        out.backward(torch.from_numpy(np.ascontiguousarray(g["grad_out"])).double())
+        np.testing.assert_allclose(l.grad.numpy(), g["grad_loc"], rtol=1e-8, atol=1e-11 * scale(g["grad_loc"]))
+        np.testing.assert_allclose(a.grad.numpy(), g["grad_attn"], rtol=1e-8, atol=1e-11 * scale(g["grad_attn"]))
+        if "grad_value" in g:
+            np.testing.assert_allclose(v.grad.numpy(), g["grad_value"], rtol=1e-8, atol=1e-11 * scale(g["grad_value"]))
+
+
 # --------------------------------------------------------------------------- (d) the INTEGRATION.md stub
 def integration_stub_source():
     text = open(os.path.join(ROOT, "INTEGRATION.md")).read()

@@ -250,7 +250,7 @@ int main(int argc, char** argv) {
   std::string shape = "dec360", dist = "U", op = "fwd", variants = "0", dtype = "f32";
   int B = 5, lq = 0, inner = 24, reps = 15, voff = 0;   // voff: floats added to every `value` base (alignment experiments)
   double warm_s = 0.06;
-  bool check = false, cold_only = false, dma = false, stamps = false, timeline = false, hbm = false;
+  bool check = false, cold_only = false, dma = false, stamps = false, timeline = false, hbm = false, eager = false;
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
     auto next = [&]() { return std::string(i + 1 < argc ? argv[++i] : ""); };
@@ -271,6 +271,7 @@ int main(int argc, char** argv) {
     else if (a == "--stamps") stamps = true;
     else if (a == "--timeline") timeline = true;
     else if (a == "--hbm-probe") hbm = true;
+    else if (a == "--eager") eager = true;        // also time plain (uncaptured) launches, cold inputs
     else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 1; }
   }
   if (dma) { run_dma_probe(); run_dma_high_probe(); }
@@ -399,10 +400,11 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(h, dd, 8, hipMemcpyDeviceToHost));
     return h[0] / std::max(h[1], 1e-30f);
   };
+  bool step_mode = false;      // --op step: a graph of forward + backward pairs (the headline's step)
   auto time_graph = [&](bool is_bwd, bool cold) {
     hipGraph_t g; hipGraphExec_t ge;
     CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-    for (int i = 0; i < inner; ++i) { Set& s = sets[cold ? i % nsets : 0]; if (is_bwd) bwd(s); else fwd(s); }
+    for (int i = 0; i < inner; ++i) { Set& s = sets[cold ? i % nsets : 0]; if (step_mode) { fwd(s); bwd(s); } else if (is_bwd) bwd(s); else fwd(s); }
     CK(hipStreamEndCapture(st, &g));
     CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
     {   // warm-up: the first ~50 ms of a run are up to 10 % slow on this part (clocks / TLBs); replay until they are over
@@ -419,6 +421,20 @@ int main(int argc, char** argv) {
     }
     std::sort(ts.begin(), ts.end());
     CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
+    return ts[ts.size() / 2];
+  };
+  // plain launches on the stream, no graph: what an eager caller (a training step) pays per call incl. the host's launch path
+  auto time_eager = [&](bool is_bwd) {
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    std::vector<float> ts;
+    for (int r = 0; r < reps + 3; ++r) {
+      CK(hipEventRecord(e0, st));
+      for (int i = 0; i < inner; ++i) { Set& s = sets[i % nsets]; if (is_bwd) bwd(s); else fwd(s); }
+      CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      if (r >= 3) ts.push_back(ms * 1e3f / inner);
+    }
+    std::sort(ts.begin(), ts.end());
     return ts[ts.size() / 2];
   };
   size_t pos = 0;
@@ -443,6 +459,13 @@ int main(int argc, char** argv) {
       const double by = is_bwd ? bytes_bwd : bytes_fwd;
       printf("  variant %4d %s: cold %8.2f us %6.2f TB/s %7.2f Gpt/s | warm %8.2f us %6.2f TB/s%s\n", v, is_bwd ? "bwd" : "fwd", cold,
              by / cold / 1e6, n_s / cold / 1e3, warm, by / warm / 1e6, chk);
+      if (is_bwd && op == "step") {
+        step_mode = true;
+        const float sc = time_graph(true, true);
+        step_mode = false;
+        printf("  variant %4d fwd+bwd step: cold %8.2f us %7.2f Gpt/s\n", v, sc, n_s / sc / 1e3);
+      }
+      if (eager) printf("  variant %4d %s: eager (no graph) %8.2f us per call\n", v, is_bwd ? "bwd" : "fwd", time_eager(is_bwd));
       fflush(stdout);
     }
   }

@@ -1,5 +1,5 @@
 """Offline GEMM solution selection for the models' Linear / attention GEMMs on MI355X (PyTorch TunableOp over rocBLAS and
-hipBLASLt): runs the fp32 legs bench.py times -- SeqFormer-R50 training (two and one T=5 360p clips per GPU), SeqFormer clip
+hipBLASLt): runs the fp32 legs bench.py times -- SeqFormer-R50 training (two and one T=5 360p clips per GPU, one 720p clip), SeqFormer clip
 inference, IDOL video inference at 360p and 720p -- once with tuning enabled and writes the chosen solutions to a CSV that
 `vnext_amd.tuning.enable()` loads at run time with tuning OFF.
 
@@ -59,7 +59,9 @@ opt = T.build_optimizer(model)
 for n_clips in (2, 1):
     clips = T.synthetic_clips(n_clips, 5, 360, 640, dev, seed=100, num_instances=4)
     tune(f"seqformer train, {n_clips} clip(s)/GPU", lambda: T.train_step(model, opt, clips))
-del opt
+clips = T.synthetic_clips(1, 5, 720, 1280, dev, seed=104, num_instances=4)      # BASELINE config 4 at N = 1 (bench: seqformer_train_step_720p)
+tune("seqformer train, 1 clip/GPU, 720p", lambda: T.train_step(model, opt, clips), warm=2, reps=3)
+del opt, clips
 model.eval()
 model.graph_inference = False            # tune eagerly; the graph-replayed trunk then dispatches the recorded solutions
 clip = T.synthetic_clips(1, 5, 360, 640, dev, seed=7, num_instances=0)

@@ -16,8 +16,9 @@ DEV_LIB_PATH = os.path.join(_HERE, "lib", "libvnext_hip_dev.so")
 
 VNX_F32, VNX_F64, VNX_BF16, VNX_F16 = 0, 1, 2, 3
 VNX_OK = 0
-ABI_VERSION = 11
+ABI_VERSION = 12
 MSDA_LEVELS_PACKED = 1
+MSDA_FORK = 2              # vnx_msda_backward: grad_value kernel on the library's side stream (include/vnext_hip.h)
 
 _vp, _i, _sz, _ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_longlong
 
@@ -51,17 +52,18 @@ SIGNATURES = {
 }
 # measurement aids of include/vnext_hip_debug.h (bench.py, tools/): not part of the drop-in boundary
 DEBUG_SIGNATURES = {
-    "vnx_debug_arm_stamps": (None, [_vp, _ll]),
-    "vnx_debug_stamp_regions": (_i, [ctypes.POINTER(_i), ctypes.POINTER(_ll), ctypes.POINTER(_ll), _i]),
     "vnx_debug_wall_clock_khz": (_i, []),
     "vnx_debug_row_gather_probe": (_i, [_vp, _sz, _vp, _sz, _i, _vp, _vp]),
     "vnx_debug_gvtiles_units": (_i, [_vp, _i, _i, _i, _i, _i, ctypes.POINTER(_i), ctypes.POINTER(_i),
                                     ctypes.POINTER(_ll), ctypes.POINTER(_ll)]),
+    "vnx_debug_gvdirect_units": (_i, [_vp, _i, _i, _i, ctypes.POINTER(_i), ctypes.POINTER(_i), _vp, _vp, _vp]),
 }
 # include/vnext_hip_dev.h: exported by the development library only
 DEV_SIGNATURES = {
     "vnx_set_kernel_variant": (None, [_i]),
     "vnx_get_kernel_variant": (_i, []),
+    "vnx_debug_arm_stamps": (None, [_vp, _ll]),
+    "vnx_debug_stamp_regions": (_i, [ctypes.POINTER(_i), ctypes.POINTER(_ll), ctypes.POINTER(_ll), _i]),
     "vnx_debug_read_rec_stamps": (_i, [ctypes.POINTER(ctypes.c_ulonglong), _i]),
     "vnx_debug_read_tile_stamps": (_i, [ctypes.POINTER(ctypes.c_ulonglong), _i]),
 }

@@ -76,6 +76,9 @@ int msda_backward_gvrec_d32(int vdt, const int64_t*, const int64_t*, const void*
                             void*, MsdaDims, int variant, float* split_image, hipStream_t);
 int msda_split_levels_convert(int vdt, const int64_t*, const int64_t*, const float* image, void* grad_value, MsdaDims, bool tiles,
                               hipStream_t);
+bool msda_d32_gvdirect_supported(int vdt, int ldt, const MsdaDims& d);
+int msda_backward_gvdirect_d32(int vdt, int ldt, const int64_t*, const int64_t*, const void* loc, const void* attn,
+                               const void* grad_out, void* grad_value, MsdaDims, hipStream_t);
 
 static int check_common(const char* fn, int vdt, int ldt, const void* value,
                         const int64_t* shapes, const int64_t* lsi, const void* loc,
@@ -135,14 +138,52 @@ int gv_units_min(const MsdaDims& d, bool tiles, int v) {
 }
 }  // namespace vnx
 
-// ---- kernel-span stamps (development / bench aid, not in the public header) ------------------
+// ---- the side stream of the forked backward (include/vnext_hip.h: VNX_MSDA_FORK) -----------------------------------
+// One lane per host thread and device, created on first use and kept: a non-blocking stream and two timing-less events.
+// Creating them is not a stream operation, but a thread in a global-mode stream capture may not call "unsafe" runtime
+// functions: the creation runs in relaxed mode.  No lane (creation failed) = the call stays on the caller's stream.
+namespace vnx {
+struct SideLane { int device; hipStream_t side; hipEvent_t fork, join; };
+static SideLane* side_lane() {
+  static thread_local SideLane lanes[16];
+  static thread_local int n_lanes = 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  for (int i = 0; i < n_lanes; ++i)
+    if (lanes[i].device == dev) return lanes[i].side ? &lanes[i] : nullptr;
+  if (n_lanes >= 16) return nullptr;
+  SideLane& l = lanes[n_lanes++];
+  l = SideLane{dev, nullptr, nullptr, nullptr};
+  hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+  const bool swapped = hipThreadExchangeStreamCaptureMode(&mode) == hipSuccess;
+  bool ok = hipStreamCreateWithFlags(&l.side, hipStreamNonBlocking) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&l.fork, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&l.join, hipEventDisableTiming) == hipSuccess;
+  if (swapped) (void)hipThreadExchangeStreamCaptureMode(&mode);
+  if (!ok) {
+    (void)hipGetLastError();
+    if (l.fork) (void)hipEventDestroy(l.fork);
+    if (l.side) (void)hipStreamDestroy(l.side);
+    l.side = nullptr;
+    return nullptr;
+  }
+  return &l;
+}
+}  // namespace vnx
+
+// ---- kernel-span stamps (development build only: include/vnext_hip_dev.h) ----------------------------------------
+// The armed buffer is process-wide state, so it does not exist in the product library: there every launch passes a null
+// stamp pointer and nothing outside a call's arguments can change what the call does or costs.
+#ifdef VNX_DEV_VARIANTS
 static unsigned long long* g_stamp_buf = nullptr;
 static long long g_stamp_words = 0, g_stamp_used = 0;
 static int g_stamp_n = 0;
 static int g_stamp_kind[4096];
 static long long g_stamp_off[4096], g_stamp_blocks[4096];
+#endif
 namespace vnx {
 unsigned long long* take_stamp_region(int kernel, long long blocks) {
+#ifdef VNX_DEV_VARIANTS
   if (!g_stamp_buf || g_stamp_n >= 4096 || g_stamp_used + 2 * blocks > g_stamp_words) return nullptr;
   g_stamp_kind[g_stamp_n] = kernel;
   g_stamp_off[g_stamp_n] = g_stamp_used;
@@ -151,6 +192,10 @@ unsigned long long* take_stamp_region(int kernel, long long blocks) {
   unsigned long long* p = g_stamp_buf + g_stamp_used;
   g_stamp_used += 2 * blocks;
   return p;
+#else
+  (void)kernel; (void)blocks;
+  return nullptr;
+#endif
 }
 }  // namespace vnx
 
@@ -176,6 +221,7 @@ void vnx_set_kernel_variant(int variant) { g_kernel_variant.store(variant, std::
 int vnx_get_kernel_variant(void) { return g_kernel_variant.load(std::memory_order_relaxed); }
 #endif
 
+#ifdef VNX_DEV_VARIANTS
 // buf: device memory of n_words 64-bit words, ZERO-filled by the caller before every measured run
 // (slots of workgroups that never ran stay {0, 0} and are skipped); nullptr disarms
 void vnx_debug_arm_stamps(void* buf, long long n_words) {
@@ -194,6 +240,7 @@ int vnx_debug_stamp_regions(int* kinds, long long* offsets, long long* blocks, i
   }
   return g_stamp_n;
 }
+#endif
 int vnx_debug_wall_clock_khz(void) {
   int dev = 0, khz = 0;
   if (hipGetDevice(&dev) != hipSuccess) return 0;
@@ -261,13 +308,22 @@ static bool use_tiles(int vdt, int ldt, const MsdaDims& d, int variant) {
   if (d.P != 4 || d.L * d.P != 16 || !msda_d32_gvtiles_supported(vdt, ldt, d)) return false;
   return variant == 431 || d.Lq >= 1024;
 }
+// Calls below 1 024 queries (the decoders'): grad_value by the self-decoding kernel (msda_d32_gvdirect.hip) -- no records, no
+// tags, no workspace, and no dependence on the grad_loc kernel, so the two run concurrently (side_lane below).  The
+// development build keeps the record-fed kernels reachable for A/B runs (variant 430 and the variants that name one).
+static bool use_direct(int vdt, int ldt, const MsdaDims& d, int variant) {
+  if (variant == 430 || variant == 408 || variant == 412 || variant == 420 || variant == 425) return false;
+  if (use_tiles(vdt, ldt, d, variant)) return false;
+  return msda_d32_gvdirect_supported(vdt, ldt, d);
+}
 // RECORD-fed path with 16-bit values and enough queries for the query split of the coarse levels (gv_query_splits): the
 // pieces of such a level meet through fp32 atomics, which need an fp32 target -- the same [B, S, M, 32] fp32 image the
 // general path of unpacked levels uses (the two never run on the same call: one needs packed levels, the other unpacked
 // ones).  The tile-fed path (every call the models make with >= 1 024 queries) needs none since round 4: its pieces store
 // fp32 partial rows (msda_gvtiles_partial_bytes) and a finishing kernel writes grad_value in its own dtype.
 static bool split_image_needed(int vdt, int ldt, const MsdaDims& d, int variant) {
-  return (vdt == VNX_BF16 || vdt == VNX_F16) && d.P == 4 && d.Lq >= 1024 && !use_tiles(vdt, ldt, d, variant);
+  return (vdt == VNX_BF16 || vdt == VNX_F16) && d.P == 4 && d.Lq >= 1024 && !use_tiles(vdt, ldt, d, variant) &&
+         !use_direct(vdt, ldt, d, variant);
 }
 // Tile path: does the grad_loc kernel leave a copy of the locations / weights laid out for the grad_value kernel
 // ([batch][head][level][query][point], fp32, 12 B per sample)?  The fused backward always does (it has to materialise
@@ -286,6 +342,7 @@ static size_t tiles_partials_offset(const MsdaDims& d, int variant) {
 }
 static size_t fast_path_scratch_bytes(int vdt, int ldt, const MsdaDims& d, int variant) {
   if (use_tiles(vdt, ldt, d, variant)) return tiles_partials_offset(d, variant) + align256(msda_gvtiles_partial_bytes(d));
+  if (use_direct(vdt, ldt, d, variant)) return 0;
   return align256(msda_gvrec_record_bytes(d));
 }
 
@@ -353,6 +410,53 @@ int vnx_msda_backward(int value_dtype, int loc_dtype, const void* value,
     //     does nothing on the device when the levels ARE packed.  No host sync either way.
     // (The record-less predecessor of (2) -- every unit re-deriving its level's geometry -- and the side
     //  stream that overlapped it with (1) are archived under tools/experiments/msda_d32_gv.hip.)
+    if (use_direct(value_dtype, loc_dtype, d, variant)) {
+      // (1) grad_value from the op's own inputs and (2) grad_loc / grad_attn: neither reads what the other writes.  One after
+      // the other on the caller's stream -- or, with VNX_MSDA_FORK, (1) on the side stream between two events and (2) on the
+      // caller's stream, which then waits for (1).  Development build: 441 = fork, 442 = (1) alone, 100..199 = (2) alone (timing).
+      const bool only_gl = variant >= 100 && variant < 200;
+      const bool only_gv = variant == 442;
+      SideLane* lane = (((flags & VNX_MSDA_FORK) || variant == 441) && !only_gl && !only_gv) ? side_lane() : nullptr;
+      if (lane) {
+        if (hipEventRecord(lane->fork, stream) != hipSuccess || hipStreamWaitEvent(lane->side, lane->fork, 0) != hipSuccess) {
+          (void)hipGetLastError();
+          lane = nullptr;
+        }
+      }
+      int st_gv = VNX_OK;
+      if (!only_gl)
+        st_gv = msda_backward_gvdirect_d32(value_dtype, loc_dtype, spatial_shapes, level_start_index, sampling_loc, attn_weight,
+                                           grad_output, grad_value, d, lane ? lane->side : stream);
+      if (lane && hipEventRecord(lane->join, lane->side) != hipSuccess) {
+        set_error("vnx_msda_backward: hipEventRecord on the side stream failed");
+        st_gv = VNX_ERR_LAUNCH;
+      }
+      st = VNX_OK;
+      if (!only_gv)
+        st = msda_backward_d32(value_dtype, loc_dtype, value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
+                               grad_output, nullptr, grad_sampling_loc, grad_attn_weight, d,
+                               only_gl ? variant : 100 + (variant < 100 ? variant : 0), nullptr, nullptr, nullptr, stream);
+      if (lane && hipStreamWaitEvent(stream, lane->join, 0) != hipSuccess) {      // the join: always, once forked
+        set_error("vnx_msda_backward: hipStreamWaitEvent on the caller's stream failed");
+        return VNX_ERR_LAUNCH;
+      }
+      if (st_gv != VNX_OK) return st_gv;
+      if (st != VNX_OK) return st;
+      if (!(flags & VNX_MSDA_LEVELS_PACKED) && !only_gl && !only_gv) {
+        // the general path, every kernel of which does nothing on the device when the levels ARE packed
+        void* gv_acc = sixteen ? workspace : grad_value;
+        const size_t acc_bytes = sixteen ? image_bytes : n_value * size_t(elem_size(value_dtype));
+        st = zero_if_not_packed(spatial_shapes, level_start_index, num_levels, spatial_size, gv_acc, acc_bytes, stream);
+        if (st != VNX_OK) return st;
+        st = msda_backward_generic(value_dtype, loc_dtype, value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
+                                   grad_output, gv_acc, grad_sampling_loc, grad_attn_weight, d, /*only_if_not_packed=*/1, stream);
+        if (st != VNX_OK) return st;
+        if (sixteen)
+          return convert_f32_to(value_dtype, workspace, grad_value, int64_t(n_value), spatial_shapes, level_start_index,
+                                num_levels, spatial_size, stream);
+      }
+      return VNX_OK;
+    }
     const bool tiles = use_tiles(value_dtype, loc_dtype, d, variant);
     const size_t rec_bytes = fast_path_scratch_bytes(value_dtype, loc_dtype, d, variant);
     void* records = tiles ? nullptr : workspace;
@@ -608,6 +712,29 @@ extern "C" int vnx_debug_gvtiles_units(const int64_t* host_shapes, int levels, i
   *units_bound = vnx::msda_gvtiles_units_bound(d, units_min);
   if (partial_rows_used) *partial_rows_used = rows;
   if (partial_rows_bound) *partial_rows_bound = gv_partial_rows_bound(int(S), levels, batch * heads);
+  return VNX_OK;
+}
+
+// ---- unit grid of the self-decoding grad_value kernel, seen from the host (include/vnext_hip_debug.h) -----------
+namespace vnx { int msda_gvdirect_units_bound(const MsdaDims& d); }
+extern "C" int vnx_debug_gvdirect_units(const int64_t* host_shapes, int levels, int num_query, int num_point, int* units_used,
+                                        int* units_bound, int* level_units, int* level_rows_per_unit, int* level_group_shift) {
+  if (!host_shapes || levels <= 0 || !units_used || !units_bound) return VNX_ERR_INVALID_ARGUMENT;
+  const int ut = gvd_units_by_taps(num_query, num_point);
+  int64_t S = 0;
+  int used = 0;
+  for (int l = 0; l < levels; ++l) {
+    const int H = int(host_shapes[2 * l]), W = int(host_shapes[2 * l + 1]);
+    S += int64_t(H) * W;
+    const GvdSplit sp = gvd_level_split(H * W, ut, num_query, num_point);      // the kernel's level table
+    used += sp.units;
+    if (level_units) level_units[l] = sp.units;
+    if (level_rows_per_unit) level_rows_per_unit[l] = sp.rpu;
+    if (level_group_shift) level_group_shift[l] = sp.gshift;
+  }
+  const MsdaDims d{1, int(S), 8, 32, levels, num_query, num_point};
+  *units_used = used;
+  *units_bound = vnx::msda_gvdirect_units_bound(d);
   return VNX_OK;
 }
 

@@ -202,6 +202,42 @@ __host__ __device__ inline GvSplit gv_level_split(int n, int units_min, int rows
   return s;
 }
 
+// Units of the self-decoding grad_value kernel (msda_d32_gvdirect.hip; calls below 1 024 queries -- the decoders').  A unit is
+// a pixel range of one level and reads + decodes the level's samples of ALL queries itself, so what the kernel fetches grows
+// with the number of units (every one of them stages all grad_out rows of its head): units are LARGE -- up to VNX_GVD_ROWS
+// rows, 10 per (batch, head) at 360p -- and hold no rows in registers: after one sort an 8-lane group walks its rows one
+// after the other and stores each at once.  Every level receives the same number of taps (4 x points x queries) whatever
+// its size, so a row of a coarse level (80 taps at the 60-pixel level of a 300-query call) is spread over 1 << gshift
+// adjacent groups whose partial sums meet in registers; `ut` (VNX_GVD_TAPS) can cut such a level further.
+#ifndef VNX_GVD_QC
+#define VNX_GVD_QC 320            // queries staged per pass: 40 KiB of grad_out rows in LDS (all 300 of a decoder call)
+#endif
+#ifndef VNX_GVD_ROWS
+#define VNX_GVD_ROWS 640
+#endif
+#ifndef VNX_GVD_TAPS
+#define VNX_GVD_TAPS 8192         // taps per unit aimed at when a small level is cut (8192: never)
+#endif
+struct GvdSplit { int units, rpu, gshift; };
+__host__ __device__ inline int gvd_units_by_taps(int Lq, int P) {
+  const int64_t taps = int64_t(4) * P * (Lq < VNX_GVD_QC ? Lq : VNX_GVD_QC);
+  const int64_t ut = (taps + VNX_GVD_TAPS - 1) / VNX_GVD_TAPS;
+  return ut < 1 ? 1 : (ut > 8 ? 8 : int(ut));
+}
+__host__ __device__ inline GvdSplit gvd_level_split(int n, int ut, int Lq, int P) {
+  GvdSplit s{0, 1, 0};
+  if (n <= 0) return s;
+  int units = (n + VNX_GVD_ROWS - 1) / VNX_GVD_ROWS;
+  if (units < ut) units = ut;
+  if (units > n) units = n;
+  s.rpu = (n + units - 1) / units;
+  s.units = (n + s.rpu - 1) / s.rpu;
+  // taps a row expects: 4 x points x (queries of a pass) / pixels of the level; from 16 up a row takes 2 groups, 32: 4, 64: 8
+  const int64_t taps = int64_t(4) * P * (Lq < VNX_GVD_QC ? Lq : VNX_GVD_QC);
+  while (s.gshift < 3 && taps >= (int64_t(16) << s.gshift) * n) ++s.gshift;
+  return s;
+}
+
 // Units of the tile-fed grad_value kernel (msda_d32_gvtiles.hip): RECTANGLES of a level, at most rows_max pixels each.
 // A narrow level (W < 32) is cut into bands of whole image rows; a wider one also into columns of about 32 pixels --
 // blocks of 32 x 8: a band of a 160-pixel-wide level would be 1.6 image rows thin while samples reach +-6 rows, i.e.

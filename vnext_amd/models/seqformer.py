@@ -57,10 +57,10 @@ def scale_tensor(values, device):
 # Inference keeps NCHW (forward-only NHWC is slower: SeqFormer 12.0 -> 12.9 ms per clip, IDOL 720p 185 -> 172 frames/s),
 # which is why the filters stay NCHW (channels-last filters select NHWC whatever the input is).  A training-only process can
 # set VNX_CHANNELS_LAST_WEIGHTS=1 to store the filters channels-last as well (no per-call filter conversion: IDOL pair
-# 65.8 -> 60.7 ms, bf16 autocast 74.3 -> 69.7; fp32 SeqFormer unchanged).  VNX_CHANNELS_LAST=0 opts out of all of it.
-CHANNELS_LAST = os.environ.get("VNX_CHANNELS_LAST", "1" if torch.cuda.is_available() else "0") == "1"
-if CHANNELS_LAST:
-    os.environ.setdefault("PYTORCH_MIOPEN_SUGGEST_NHWC", "1")
+# 65.8 -> 60.7 ms, bf16 autocast 74.3 -> 69.7; fp32 SeqFormer unchanged).
+# OFF unless the process asks for it: vnext_amd.train.enable_channels_last() sets the MIOpen variable and this switch
+# together (importing this module changes nothing process-wide; until round 4 it did both at import time).
+CHANNELS_LAST = False
 
 
 class FrozenBatchNorm2d(nn.Module):

@@ -210,6 +210,27 @@ def enable_tuned_gemms(path=None):
     return tuning.enable(path)
 
 
+def enable_channels_last() -> dict:
+    """Opt in to the channels-last ResNet trunk for TRAINING steps (vnext_amd/models/seqformer.py: MIOpen's fp32 backward
+    convolutions are NHWC kernels either way; given NCHW tensors it transposes around each: SeqFormer step 66.2 -> 64.3 ms).
+    Two process-wide settings, which is why this is an explicit call and not an import side effect:
+      * PYTORCH_MIOPEN_SUGGEST_NHWC=1 -- PyTorch hands MIOpen an NHWC problem only with it, and reads it ONCE: call this
+        before the process runs its first convolution (a later call converts inputs for nothing and is refused here when
+        the caller says a convolution already ran);
+      * the trunk's switch `models.seqformer.CHANNELS_LAST`.
+    VNX_CHANNELS_LAST=0 or an explicit PYTORCH_MIOPEN_SUGGEST_NHWC=0 opt out.  -> {"enabled", "why"} for the bench line."""
+    from .models import seqformer
+    if os.environ.get("VNX_CHANNELS_LAST", "1") == "0":
+        return {"enabled": False, "why": "VNX_CHANNELS_LAST=0"}
+    if not torch.cuda.is_available():
+        return {"enabled": False, "why": "no GPU"}
+    if os.environ.get("PYTORCH_MIOPEN_SUGGEST_NHWC", "1") != "1":
+        return {"enabled": False, "why": "PYTORCH_MIOPEN_SUGGEST_NHWC is set to something else"}
+    os.environ["PYTORCH_MIOPEN_SUGGEST_NHWC"] = "1"
+    seqformer.CHANNELS_LAST = True
+    return {"enabled": True, "why": "PYTORCH_MIOPEN_SUGGEST_NHWC=1 set before the first convolution; training trunk in channels-last"}
+
+
 def build_optimizer(model, base_lr=2e-4, backbone_multiplier=0.1, weight_decay=1e-4):
     """AdamW, backbone at base_lr * multiplier (train_net.py:85-113)."""
     backbone, rest = [], []

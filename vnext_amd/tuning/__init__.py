@@ -40,8 +40,15 @@ def enable(path: str | None = None) -> dict:
         import torch.cuda.tunable as tunable
         tunable.enable(True)
         tunable.tuning_enable(False)          # never time anything at run time
-        # TunableOp writes its results back at exit: keep that away from the working directory and the repo
+        # PyTorch builds that write TunableOp's results back at exit have `write_file_on_exit`: switch it off -- tuning is off,
+        # there is nothing new to persist, and every process that enables the recorded GEMMs (each DDP rank, each bench leg)
+        # would leave a CSV behind.  PyTorch 2.10 has no such switch (it writes a result when tuning produces
+        # one, i.e. never here); the file name is moved away from the working directory and the repo either way, and
+        # disable() puts it back.
+        _state["prev_filename"] = tunable.get_filename()
         tunable.set_filename(os.path.join(tempfile.gettempdir(), "vnx_tunableop_%d.csv" % os.getpid()))
+        if hasattr(tunable, "write_file_on_exit"):
+            tunable.write_file_on_exit(False)
         ok = bool(tunable.read_file(path))
         n = len(tunable.get_results())
         if not ok or n == 0:
@@ -60,6 +67,8 @@ def disable() -> None:
     if _state["enabled"]:
         import torch.cuda.tunable as tunable
         tunable.enable(False)
+        if _state.get("prev_filename"):
+            tunable.set_filename(_state.pop("prev_filename"))
         _state.update(enabled=False, entries=0, why="disabled")
 
 
