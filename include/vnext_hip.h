@@ -202,6 +202,8 @@ int vnx_msda_fused_backward(int value_dtype, int query_dtype, const void* value,
  *                    `num_insts` list, expanded; DEVICE memory)
  *   out              [num_insts, 2*height, 2*width], fully written
  * `stride` is mask_feat_stride (8): pixel centres are x*stride + stride/2.
+ * Limits (VNX_ERR_UNSUPPORTED beyond them): width <= 3 711 columns of the stride-8 feature map -- images up to 29 688 pixels
+ * wide; the kernel keeps one row of logits + 384 pixels per wave in LDS -- and height * width < 2^26.
  */
 int vnx_dynamic_mask_head_forward(int dtype, const void* mask_feats, const void* reference_points,
                                   const void* params, const int32_t* inst_image, void* out,

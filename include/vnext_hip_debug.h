@@ -39,11 +39,13 @@ int vnx_debug_gvtiles_units(const int64_t* host_shapes, int levels, int num_quer
                             int* units_used, int* units_bound, long long* partial_rows_used, long long* partial_rows_bound);
 
 /* The same check for the self-decoding grad_value kernel of calls below 1 024 queries (msda_d32_gvdirect.hip;
- * gvd_level_split in vnx_common.h).  Writes, per (batch, head), the workgroups the kernel's level table yields and the
+ * gvd_level_split in vnx_common.h; batch_heads = batch x heads decides whether small levels are cut in two).  Writes, per
+ * (batch, head), the workgroups the kernel's level table yields and the
  * launcher's bound; per level (any of the three arrays may be null; `levels` entries each) the units, the rows per unit
  * and log2 of the 8-lane groups that share a row.  0 on success.  No GPU needed (tests/test_gvdirect_model.py). */
-int vnx_debug_gvdirect_units(const int64_t* host_shapes, int levels, int num_query, int num_point, int* units_used,
-                             int* units_bound, int* level_units, int* level_rows_per_unit, int* level_group_shift);
+int vnx_debug_gvdirect_units(const int64_t* host_shapes, int levels, int num_query, int num_point, int batch_heads,
+                             int* units_used, int* units_bound, int* level_units, int* level_rows_per_unit,
+                             int* level_group_shift);
 
 #ifdef __cplusplus
 }

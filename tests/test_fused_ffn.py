@@ -104,6 +104,23 @@ def test_bias_relu_dropout_pass_mask_scaling_and_backward():
 
 
 @pytest.mark.gpu
+def test_a_nan_activation_lets_its_gradient_through_like_aten():
+    """threshold_backward is `x <= 0 ? 0 : g`: a NaN activation is not <= 0, so its gradient passes.  The fused backward
+    tested `y > 0` until round 4 and zeroed it -- a diverging run looked healthy one layer further down."""
+    g = torch.Generator().manual_seed(9)
+    h0 = torch.randn(64, 256, generator=g).to(DEV)
+    h0[3, 17] = float("nan")
+    h0[40, 200] = float("inf")
+    b = torch.zeros(256, device=DEV, requires_grad=True)
+    h = h0.clone().requires_grad_(True)
+    _BiasReluDropout.apply(h * 1.0, b, 0.0, 1, None).backward(torch.ones(64, 256, device=DEV))
+    ref = h0.clone().requires_grad_(True)
+    torch.relu(ref).backward(torch.ones(64, 256, device=DEV))
+    assert torch.equal(h.grad, ref.grad)
+    assert float(h.grad[3, 17]) == 1.0 and float(h.grad[40, 200]) == 1.0
+
+
+@pytest.mark.gpu
 def test_add_norm_with_a_folded_bias_returns_its_gradient():
     """add_dropout_norm(x, r, ..., r_bias=b) = norm(x + dropout(r + b)); p = 0 against fp64 autograd, and p > 0 against
     the same call with the bias added by torch beforehand and the same seed (same mask): outputs and gradients equal,

@@ -16,12 +16,12 @@ from vnext_amd import _lib
 QC, ROWS = 320, 640
 
 
-def level_table(shapes, Lq, P):
+def level_table(shapes, Lq, P, batch_heads=2):
     arr = np.asarray(shapes, dtype=np.int64)
     L = len(shapes)
     used, bound = ctypes.c_int(), ctypes.c_int()
     units, rpu, gs = (np.zeros(L, dtype=np.int32) for _ in range(3))
-    rc = _lib.lib().vnx_debug_gvdirect_units(arr.ctypes.data, L, Lq, P, ctypes.byref(used), ctypes.byref(bound),
+    rc = _lib.lib().vnx_debug_gvdirect_units(arr.ctypes.data, L, Lq, P, batch_heads, ctypes.byref(used), ctypes.byref(bound),
                                              units.ctypes.data, rpu.ctypes.data, gs.ctypes.data)
     assert rc == 0
     return used.value, bound.value, units, rpu, gs
@@ -31,7 +31,7 @@ def model_grad_value(value_shape, shapes, lsi, loc, attn, grad_out, rng):
     """grad_value [B, S, M, 32] by the kernel's scheme (float64 accumulation: only the bookkeeping is under test)."""
     B, S, M, D = value_shape
     _, Lq, _, L, P, _ = loc.shape
-    used, bound, units, rpu, gs = level_table(shapes, Lq, P)
+    used, bound, units, rpu, gs = level_table(shapes, Lq, P, B * M)
     assert used <= bound
     gv = np.full((B, S, M, D), np.nan)
     go = grad_out.reshape(B, Lq, M, D).astype(np.float64)
@@ -142,12 +142,15 @@ def test_scheme_reproduces_the_oracle(shapes, Lq, P, concentrate):
 
 
 def test_baseline_level_tables():
-    # T=5 decoder call at 360p: 6 + 2 + 1 + 1 units; a row of the 60-pixel level (80 taps) on eight groups, of the 240-pixel
-    # level (20 taps) on two
-    used, bound, units, rpu, gs = level_table([(48, 80), (24, 40), (12, 20), (6, 10)], 300, 4)
-    assert list(units) == [6, 2, 1, 1] and list(rpu) == [640, 480, 240, 60] and list(gs) == [0, 0, 1, 3]
-    assert used == 10 <= bound
-    used, bound, units, rpu, gs = level_table([(92, 160), (46, 80), (23, 40), (12, 20)], 300, 4)
+    # T=5 decoder call at 360p (40 (batch, head) pairs: the grid fits one round, the two small levels are cut in two):
+    # 6 + 2 + 2 + 2 units; a row of the 60-pixel level (80 taps) on eight groups, of the 240-pixel level (20 taps) on two
+    used, bound, units, rpu, gs = level_table([(48, 80), (24, 40), (12, 20), (6, 10)], 300, 4, 40)
+    assert list(units) == [6, 2, 2, 2] and list(rpu) == [640, 480, 120, 30] and list(gs) == [0, 0, 1, 3]
+    assert used == 12 <= bound
+    # B = 10: two rounds of workgroups either way, one unit per small level
+    used, bound, units, rpu, gs = level_table([(48, 80), (24, 40), (12, 20), (6, 10)], 300, 4, 80)
+    assert list(units) == [6, 2, 1, 1] and list(rpu) == [640, 480, 240, 60] and used == 10 <= bound
+    used, bound, units, rpu, gs = level_table([(92, 160), (46, 80), (23, 40), (12, 20)], 300, 4, 40)
     assert used <= bound and list(units)[0] == 23 and all(r <= ROWS for r in rpu)
 
 
@@ -164,8 +167,9 @@ def test_random_pyramids_never_pass_the_bound(seed):
             shapes[rnd.randrange(L)] = (1, rnd.choice([1, 2, 7, 70000]))
         Lq = rnd.choice([1, 7, 100, 300, 900, 1023, 5000])
         P = rnd.choice([1, 2, 4, 8])
-        used, bound, units, rpu, gs = level_table(shapes, Lq, P)
-        assert used <= bound, (shapes, Lq, P, used, bound)
+        bm = rnd.choice([1, 2, 8, 40, 80, 1000])
+        used, bound, units, rpu, gs = level_table(shapes, Lq, P, bm)
+        assert used <= bound, (shapes, Lq, P, bm, used, bound)
         for (h, w), u, r, g in zip(shapes, units, rpu, gs):
             n = h * w
             assert 1 <= r <= ROWS and (u - 1) * r < n <= u * r, (shapes, Lq, P)     # every row has one owner, no unit is empty

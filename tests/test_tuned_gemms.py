@@ -21,8 +21,18 @@ def test_recorded_file_is_well_formed():
         assert "float" in op.lower(), f"only fp32 GEMMs are recorded, got {op}"       # (the bf16 tuning pass faulted, see tuning/__init__)
         assert solution == "Default" or solution.startswith(("Gemm_Hipblaslt_", "Gemm_Rocblas_"))
         assert float(ms) > 0
-    # the shapes that decide the SeqFormer step: the encoder FFN weight gradients of two T=5 360p clips (51 000 rows)
-    assert any("51000" in r[1] and "1024" in r[1] for r in entries)
+    # the shapes that decide the SeqFormer step: the encoder's FFN and value projection over two T=5 360p clips (51 000 rows).
+    # Since the FFN fusion and the masked value projection (round 4) their forward GEMMs are BIAS-LESS F.linear calls --
+    # GemmTunableOp, not GemmAndBiasTunableOp: a table recorded before that change matched none of them and the GEMMs fell
+    # back to the library default silently.  Forward (TN), input gradient (NN) and weight gradient (NT) of each.
+    keys = {(r[0], r[1].split("_ld_")[0]) for r in entries}
+    for op, shape in (("GemmTunableOp_float_TN", "tn_1024_51000_256"), ("GemmTunableOp_float_TN", "tn_256_51000_1024"),
+                      ("GemmTunableOp_float_TN", "tn_256_51000_256"), ("GemmTunableOp_float_NN", "nn_256_51000_1024"),
+                      ("GemmTunableOp_float_NN", "nn_1024_51000_256"), ("GemmTunableOp_float_NT", "nt_1024_256_51000"),
+                      ("GemmTunableOp_float_NT", "nt_256_1024_51000")):
+        assert (op, shape) in keys, f"no recorded solution for {op} {shape}: re-run tools/tune_gemms.py at HEAD"
+    # config 4's N = 1 point (one T=5 720p clip: 97 800 rows) is tuned too
+    assert any("97800" in r[1] for r in entries)
 
 
 def test_enable_is_a_noop_without_a_rocm_device():

@@ -56,7 +56,7 @@ DEBUG_SIGNATURES = {
     "vnx_debug_row_gather_probe": (_i, [_vp, _sz, _vp, _sz, _i, _vp, _vp]),
     "vnx_debug_gvtiles_units": (_i, [_vp, _i, _i, _i, _i, _i, ctypes.POINTER(_i), ctypes.POINTER(_i),
                                     ctypes.POINTER(_ll), ctypes.POINTER(_ll)]),
-    "vnx_debug_gvdirect_units": (_i, [_vp, _i, _i, _i, ctypes.POINTER(_i), ctypes.POINTER(_i), _vp, _vp, _vp]),
+    "vnx_debug_gvdirect_units": (_i, [_vp, _i, _i, _i, _i, ctypes.POINTER(_i), ctypes.POINTER(_i), _vp, _vp, _vp]),
 }
 # include/vnext_hip_dev.h: exported by the development library only
 DEV_SIGNATURES = {

@@ -78,7 +78,7 @@ int msda_split_levels_convert(int vdt, const int64_t*, const int64_t*, const flo
                               hipStream_t);
 bool msda_d32_gvdirect_supported(int vdt, int ldt, const MsdaDims& d);
 int msda_backward_gvdirect_d32(int vdt, int ldt, const int64_t*, const int64_t*, const void* loc, const void* attn,
-                               const void* grad_out, void* grad_value, MsdaDims, hipStream_t);
+                               const void* grad_out, void* grad_value, MsdaDims, bool compact, hipStream_t);
 
 static int check_common(const char* fn, int vdt, int ldt, const void* value,
                         const int64_t* shapes, const int64_t* lsi, const void* loc,
@@ -414,6 +414,8 @@ int vnx_msda_backward(int value_dtype, int loc_dtype, const void* value,
       // (1) grad_value from the op's own inputs and (2) grad_loc / grad_attn: neither reads what the other writes.  One after
       // the other on the caller's stream -- or, with VNX_MSDA_FORK, (1) on the side stream between two events and (2) on the
       // caller's stream, which then waits for (1).  Development build: 441 = fork, 442 = (1) alone, 100..199 = (2) alone (timing).
+      // (Launching (2) without the packet's barrier bit -- hipExtAnyOrderLaunch, same stream, no events -- was tried: the flag is
+      // not honoured on gfx9 parts (hip_ext.h says so; measured 23.70 vs 23.93 us eager, no overlap in the kernel trace).)
       const bool only_gl = variant >= 100 && variant < 200;
       const bool only_gv = variant == 442;
       SideLane* lane = (((flags & VNX_MSDA_FORK) || variant == 441) && !only_gl && !only_gv) ? side_lane() : nullptr;
@@ -426,7 +428,7 @@ int vnx_msda_backward(int value_dtype, int loc_dtype, const void* value,
       int st_gv = VNX_OK;
       if (!only_gl)
         st_gv = msda_backward_gvdirect_d32(value_dtype, loc_dtype, spatial_shapes, level_start_index, sampling_loc, attn_weight,
-                                           grad_output, grad_value, d, lane ? lane->side : stream);
+                                           grad_output, grad_value, d, false, lane ? lane->side : stream);
       if (lane && hipEventRecord(lane->join, lane->side) != hipSuccess) {
         set_error("vnx_msda_backward: hipEventRecord on the side stream failed");
         st_gv = VNX_ERR_LAUNCH;
@@ -590,11 +592,17 @@ int vnx_msda_fused_forward(int value_dtype, int query_dtype, const void* value, 
 // always takes the automatic configuration, hence tile queries of variant 0): [tile words | decoded locations, fp32,
 // 8 B per sample | softmax weights, fp32, 4 B per sample] -- the two tensors the fused prologue otherwise never
 // materialises, 12 B per sample against the records' 16 + 4.
-struct FusedScratch { bool tiles; size_t words, loc, attn, partials, total; };
+struct FusedScratch { bool tiles, direct; size_t words, loc, attn, partials, total; };
 static FusedScratch fused_scratch(int vdt, const MsdaDims& d, int variant) {
   FusedScratch f{};
   f.tiles = use_tiles(vdt, VNX_F32, d, variant);
-  if (f.tiles) {
+  f.direct = !f.tiles && use_direct(vdt, VNX_F32, d, variant);
+  if (f.direct) {      // self-decoding grad_value kernel (below 1 024 queries): only the decoded locations / weights, fp32
+    const size_t samples = size_t(d.B) * d.Lq * d.M * d.L * d.P;
+    f.loc = align256(samples * 8);
+    f.attn = align256(samples * 4);
+    f.total = f.loc + f.attn;
+  } else if (f.tiles) {
     const size_t samples = size_t(d.B) * d.Lq * d.M * d.L * d.P;
     f.words = align256(msda_gvtiles_summary_bytes(d, msda_bwd_tile_queries(d, 0)));
     f.loc = align256(samples * 8);
@@ -657,7 +665,21 @@ int vnx_msda_fused_backward(int value_dtype, int query_dtype, const void* value,
     return VNX_ERR_WORKSPACE;
   }
   float* split_image = split16 ? (float*)((char*)workspace + rec_bytes) : nullptr;
-  void* fp32_target = fs.tiles ? nullptr : (value_dtype == VNX_F32 ? grad_value : (void*)split_image);
+  void* fp32_target = (fs.tiles || fs.direct) ? nullptr : (value_dtype == VNX_F32 ? grad_value : (void*)split_image);
+  if (fs.direct) {
+    // (1) grad of the Linear outputs (+ reference points) and the decoded locations / softmax weights, laid out
+    // [batch][head][level][query][point]; (2) grad_value by the self-decoding kernel from those (msda_d32_gvdirect.hip):
+    // 12 B per sample where the record-fed kernel was left 16 + 4, no tags to select by, no chunk loop
+    float* d_loc = (float*)workspace;
+    float* d_attn = (float*)((char*)workspace + fs.loc);
+    st = msda_fused_d32(true, value_dtype, query_dtype, value, spatial_shapes, level_start_index, sampling_offsets,
+                        attention_logits, grad_output, grad_sampling_offsets, grad_attention_logits, d, nullptr,
+                        reference_points, grad_reference_points, ref_dim, reference_batch_div, nullptr, nullptr, d_loc, d_attn,
+                        stream);
+    if (st != VNX_OK) return st;
+    return msda_backward_gvdirect_d32(value_dtype, VNX_F32, spatial_shapes, level_start_index, d_loc, d_attn, grad_output,
+                                      grad_value, d, true, stream);
+  }
   if (fs.tiles) {
     // (1) grad of the Linear outputs (+ reference points), one word per (level, tile of queries) and the decoded
     // locations / weights; (2) grad_value from those.  Packed levels are required (no-op on the device otherwise).
@@ -717,22 +739,23 @@ extern "C" int vnx_debug_gvtiles_units(const int64_t* host_shapes, int levels, i
 
 // ---- unit grid of the self-decoding grad_value kernel, seen from the host (include/vnext_hip_debug.h) -----------
 namespace vnx { int msda_gvdirect_units_bound(const MsdaDims& d); }
-extern "C" int vnx_debug_gvdirect_units(const int64_t* host_shapes, int levels, int num_query, int num_point, int* units_used,
-                                        int* units_bound, int* level_units, int* level_rows_per_unit, int* level_group_shift) {
+extern "C" int vnx_debug_gvdirect_units(const int64_t* host_shapes, int levels, int num_query, int num_point, int batch_heads,
+                                        int* units_used, int* units_bound, int* level_units, int* level_rows_per_unit,
+                                        int* level_group_shift) {
   if (!host_shapes || levels <= 0 || !units_used || !units_bound) return VNX_ERR_INVALID_ARGUMENT;
-  const int ut = gvd_units_by_taps(num_query, num_point);
   int64_t S = 0;
+  for (int l = 0; l < levels; ++l) S += host_shapes[2 * l] * host_shapes[2 * l + 1];
+  const int ut = gvd_units_min(int(S), levels, batch_heads);
   int used = 0;
   for (int l = 0; l < levels; ++l) {
     const int H = int(host_shapes[2 * l]), W = int(host_shapes[2 * l + 1]);
-    S += int64_t(H) * W;
     const GvdSplit sp = gvd_level_split(H * W, ut, num_query, num_point);      // the kernel's level table
     used += sp.units;
     if (level_units) level_units[l] = sp.units;
     if (level_rows_per_unit) level_rows_per_unit[l] = sp.rpu;
     if (level_group_shift) level_group_shift[l] = sp.gshift;
   }
-  const MsdaDims d{1, int(S), 8, 32, levels, num_query, num_point};
+  const MsdaDims d{batch_heads, int(S), 1, 32, levels, num_query, num_point};
   *units_used = used;
   *units_bound = vnx::msda_gvdirect_units_bound(d);
   return VNX_OK;

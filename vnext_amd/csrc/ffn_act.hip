@@ -57,7 +57,8 @@ bias_relu_dropout_fwd_kernel(float* __restrict__ h, const float* __restrict__ bi
       continue;
     }
     ffn_f4 v = *reinterpret_cast<const ffn_f4*>(h + i * 4) + b;
-    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    // (a comparison, not fmaxf: fmaxf(NaN, 0) is 0, ATen's relu(NaN) is NaN -- a diverging run must stay visible)
+    if (relu) { v.x = v.x <= 0.f ? 0.f : v.x; v.y = v.y <= 0.f ? 0.f : v.y; v.z = v.z <= 0.f ? 0.f : v.z; v.w = v.w <= 0.f ? 0.f : v.w; }
     if (threshold != 0u) {
       const uint32_t base = uint32_t(i) * 4u;                          // element index mod 2^32 ...
       const uint32_t hi = seed_hi ^ uint32_t(uint64_t(i) >> 30);       // ... and what lies above it
@@ -83,11 +84,13 @@ bias_relu_dropout_bwd_kernel(const float* g, const float* __restrict__ y, const 
     ffn_f4 gv = *reinterpret_cast<const ffn_f4*>(g + at);
     if (row_zero != nullptr && row_zero[row]) gv = ffn_f4{0.f, 0.f, 0.f, 0.f};
     if (y != nullptr) {                         // ReLU (+ dropout): y > 0 <=> passed and kept
+      // written as !(y <= 0), ATen's threshold_backward: a NaN activation lets its gradient through instead of
+      // silently zeroing it (a diverging run must stay visible downstream)
       const ffn_f4 yv = *reinterpret_cast<const ffn_f4*>(y + at);
-      gv.x = yv.x > 0.f ? gv.x * scale : 0.f;
-      gv.y = yv.y > 0.f ? gv.y * scale : 0.f;
-      gv.z = yv.z > 0.f ? gv.z * scale : 0.f;
-      gv.w = yv.w > 0.f ? gv.w * scale : 0.f;
+      gv.x = !(yv.x <= 0.f) ? gv.x * scale : 0.f;
+      gv.y = !(yv.y <= 0.f) ? gv.y * scale : 0.f;
+      gv.z = !(yv.z <= 0.f) ? gv.z * scale : 0.f;
+      gv.w = !(yv.w <= 0.f) ? gv.w * scale : 0.f;
     }
     acc += gv;
     *reinterpret_cast<ffn_f4*>(out + at) = gv;

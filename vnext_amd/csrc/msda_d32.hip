@@ -1280,18 +1280,19 @@ static int launch_bwd_cfg(const void* value, const int64_t* shapes, const int64_
   void* unit_ids = (records != nullptr && d.P == 4) ? (void*)((char*)records + gv_unit_ids_offset(d)) : nullptr;
   const int units_min = gv_units_min(d, tile_summary != nullptr, kernel_variant());
   constexpr int kLpr = (sizeof(TV) == 2 || VNX_K1_F32_LPR4(WPB)) ? 4 : 8;    // 16-bit rows as 4 lanes x 16 B; fp32: VNX_K1_F32_LPR4
-#define VNX_LAUNCH(LPT, AT)                                                                     \
-  hipLaunchKernelGGL((msda_bwd_d32_kernel<TV, TL, QPW, WPB, LPT, AT, false, ((LPT) == 16 && !(AT)) ? kLpr : 8>), dim3(uint32_t(blocks)),   \
-                     dim3(64 * WPB), lds, stream, (const TV*)value, shapes, lsi, (const TL*)loc, \
-                     (const TL*)attn, (const TV*)grad_out, (float*)gv, (TL*)grad_loc,            \
+#define VNX_BWD_ARGS (const TV*)value, shapes, lsi, (const TL*)loc, (const TL*)attn, (const TV*)grad_out, (float*)gv, (TL*)grad_loc, \
                      (TL*)grad_attn, d, tiles_per_batch, (uint4_t*)records, (uint32_t*)unit_ids,                \
                      (uint32_t*)tile_summary, units_min,                                                          \
                      take_stamp_region(kStampGradLoc, blocks),                                                   \
                      FusedArgs{nullptr, nullptr, 0, 0, (float*)qsplit_zero, tile_copy,                            \
-                               tile_copy ? tile_copy + 2 * (int64_t(d.B) * d.Lq * d.M * d.L * d.P) : nullptr})
+                               tile_copy ? tile_copy + 2 * (int64_t(d.B) * d.Lq * d.M * d.L * d.P) : nullptr}
+#define VNX_LAUNCH(LPT, AT)                                                                     \
+  hipLaunchKernelGGL((msda_bwd_d32_kernel<TV, TL, QPW, WPB, LPT, AT, false, ((LPT) == 16 && !(AT)) ? kLpr : 8>), dim3(uint32_t(blocks)),   \
+                     dim3(64 * WPB), lds, stream, VNX_BWD_ARGS)
   if (!atomics) { if (LP == 16) VNX_LAUNCH(16, false); else VNX_LAUNCH(0, false); }
   else { if (LP == 16) VNX_LAUNCH(16, true); else VNX_LAUNCH(0, true); }
 #undef VNX_LAUNCH
+#undef VNX_BWD_ARGS
   return check_launch("msda_bwd_d32");
 }
 

@@ -49,8 +49,11 @@ namespace rec {
 #ifndef VNX_GVD_LATE_ROWS
 #define VNX_GVD_LATE_ROWS 0       // A/B: request the first pass's grad_out rows after the level table, with the samples
 #endif
-#ifndef VNX_GVD_PLAIN_STORE
-#define VNX_GVD_PLAIN_STORE 0     // A/B: rows written with plain stores (fp32)
+#ifndef VNX_GVD_STORE_POLICY
+#define VNX_GVD_STORE_POLICY 0    // A/B, fp32 rows: 0 = nt, 1 = plain, 2 = sc1 nt, 3 = sc0 sc1, 4 = sc0 sc1 nt, 5 = sc1
+#endif
+#ifndef VNX_GVD_WALK
+#define VNX_GVD_WALK 1            // rows a group has in flight while it walks (1 | 2)
 #endif
 
 constexpr int kGvdQc = VNX_GVD_QC;
@@ -67,7 +70,7 @@ template <typename TV, typename TL, int P_T>
 __global__ void __launch_bounds__(kThreads, VNX_GVD_UNITS_PER_CU * kWaves / 4)
 msda_bwd_gv_direct_kernel(const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
                           const TL* __restrict__ loc, const TL* __restrict__ attn, const TV* __restrict__ grad_out,
-                          TV* __restrict__ grad_value, MsdaDims d, int ut, unsigned long long* stamps) {
+                          TV* __restrict__ grad_value, MsdaDims d, int ut, int compact, unsigned long long* stamps) {
   stamp_begin(stamps);
   constexpr int D = 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -177,12 +180,15 @@ msda_bwd_gv_direct_kernel(const int64_t* __restrict__ shapes, const int64_t* __r
   const int rows = r1 - r0;
 
   const int LP = d.L * P;
-  // sample (q, head m, level lvl, point k) of this batch element: element  q * (M * LP) + k  from s_base on
-  const int64_t s_base = (int64_t(b) * d.Lq * d.M + m) * LP + lvl * P;
+  // sample (q, head m, level lvl, point k) of this batch element: element  q * (M * LP) + k  from s_base on in the op's own
+  // layout; compact (the fused backward: its grad_loc kernel leaves the decoded locations and softmax weights laid out
+  // [batch][head][level][query][point], msda_d32.hip): q * P + k -- consecutive bytes
+  const int64_t s_base = compact ? ((int64_t(b) * d.M + m) * d.L + lvl) * int64_t(d.Lq) * P
+                                 : (int64_t(b) * d.Lq * d.M + m) * LP + lvl * P;
   const TL* attn_bm = attn + s_base;
   const TL* loc_bm = loc + 2 * s_base;
-  const uint32_t s_stride = uint32_t(d.M) * uint32_t(LP);
-  const uint32_t n_samp = uint32_t(d.Lq) * s_stride;
+  const uint32_t s_stride = compact ? uint32_t(P) : uint32_t(d.M) * uint32_t(LP);
+  const uint32_t n_samp = uint32_t(d.Lq) * s_stride;      // from s_base on, at most
   const __amdgpu_buffer_rsrc_t loc_src = uniform_rsrc(loc_bm, n_samp * 2u * uint32_t(sizeof(TL)));
   const __amdgpu_buffer_rsrc_t attn_src = uniform_rsrc(attn_bm, n_samp * uint32_t(sizeof(TL)));
   const float Hf = float(Hl), Wf = float(Wl);
@@ -309,42 +315,83 @@ msda_bwd_gv_direct_kernel(const int64_t* __restrict__ shapes, const int64_t* __r
       const uint32_t step = gmask + 1u;
       const float4_t* g4 = grows + ch4;
       const int n_slots = rows << gshift;
-      for (int sb = 0; sb < n_slots; sb += kGroups) {      // uniform
-        const int slot = sb + grp;
-        const int row = slot >> gshift;
-        const uint32_t part = uint32_t(slot) & gmask;
-        uint32_t n = 0, o = 0;
-        if (slot < n_slots) { n = VNX_GVD_ABL == 3 ? 0u : cnt[row]; o = offs[row]; }
-        float4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
-        uint32_t i = part;
-        for (; i + step < n; i += 2 * step) {        // two taps in flight
-          const uint32_t s0 = l_slot[o + i], s1 = l_slot[o + i + step];
-          const float w0 = l_wt[o + i], w1 = l_wt[o + i + step];
-          const float4_t x0 = g4[s0 * 8], x1 = g4[s1 * 8];
-          a0 += w0 * x0;
-          a1 += w1 * x1;
-        }
-        if (i < n) a1 += l_wt[o + i] * g4[uint32_t(l_slot[o + i]) * 8];
-        a0 += a1;
-        // a row spread over 1 << gshift groups (adjacent groups of one wave): their partial sums meet in the first
+      constexpr int KS = VNX_GVD_WALK;
+      for (int sb = 0; sb < n_slots; sb += KS * kGroups) {      // uniform
+        int slot[KS], row[KS];
+        uint32_t n[KS], o[KS], i[KS];
+        float4_t acc[KS];
 #pragma unroll
-        for (int sh = 0; sh < 3; ++sh)
-          if (sh < gshift) {
-            a0.x += __shfl_xor(a0.x, 8 << sh, 64); a0.y += __shfl_xor(a0.y, 8 << sh, 64);
-            a0.z += __shfl_xor(a0.z, 8 << sh, 64); a0.w += __shfl_xor(a0.w, 8 << sh, 64);
+        for (int k = 0; k < KS; ++k) {
+          slot[k] = sb + k * kGroups + grp;
+          row[k] = slot[k] >> gshift;
+          n[k] = 0; o[k] = 0;
+          if (slot[k] < n_slots) { n[k] = VNX_GVD_ABL == 3 ? 0u : cnt[row[k]]; o[k] = offs[row[k]]; }
+          i[k] = uint32_t(slot[k]) & gmask;        // part: the entries of the row this group takes are part, part + step, ...
+          acc[k] = float4_t{0.f, 0.f, 0.f, 0.f};
+        }
+        if constexpr (KS == 1) {
+          float4_t a1 = {0.f, 0.f, 0.f, 0.f};
+          uint32_t j = i[0];
+          for (; j + step < n[0]; j += 2 * step) {        // two taps in flight
+            const uint32_t s0 = l_slot[o[0] + j], s1 = l_slot[o[0] + j + step];
+            const float w0 = l_wt[o[0] + j], w1 = l_wt[o[0] + j + step];
+            const float4_t x0 = g4[s0 * 8], x1 = g4[s1 * 8];
+            acc[0] += w0 * x0;
+            a1 += w1 * x1;
           }
-        if (VNX_GVD_ABL == 4) continue;
-        if (part == 0u && slot < n_slots) {
-          TV* p = out + __umul24(uint32_t(row), q_stride) + ch4 * 4;
-          // several passes: the later ones add onto what the first stored (this lane wrote it: program order).  Non-temporal
-          // stores in every case: written with plain stores the 26 MB of rows of a T = 5 call stay dirty in L2 until the
-          // end-of-kernel write-back, which then takes 10 us (kernel 18.0 us; 7.8 without any store) -- and a branch that
-          // stores the same value plain on one side and `nt` on the other is merged by the compiler into the plain form.
-          if (pass > 0) a0 += load4<TV>(p);
-#if VNX_GVD_PLAIN_STORE
-          if constexpr (sizeof(TV) == 4) *reinterpret_cast<float4_t*>(p) = a0; else
+          if (j < n[0]) a1 += l_wt[o[0] + j] * g4[uint32_t(l_slot[o[0] + j]) * 8];
+          acc[0] += a1;
+        } else {
+          // KS rows side by side, one tap of each per step (fine levels have one or two taps per row: the rows, not the taps
+          // of a row, are what can be in flight together)
+          bool more = true;
+          while (more) {
+            more = false;
+#pragma unroll
+            for (int k = 0; k < KS; ++k)
+              if (i[k] < n[k]) {
+                acc[k] += l_wt[o[k] + i[k]] * g4[uint32_t(l_slot[o[k] + i[k]]) * 8];
+                i[k] += step;
+                more = true;
+              }
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+          float4_t a0 = acc[k];
+          // a row spread over 1 << gshift groups (adjacent groups of one wave): their partial sums meet in the first
+#pragma unroll
+          for (int sh = 0; sh < 3; ++sh)
+            if (sh < gshift) {
+              a0.x += __shfl_xor(a0.x, 8 << sh, 64); a0.y += __shfl_xor(a0.y, 8 << sh, 64);
+              a0.z += __shfl_xor(a0.z, 8 << sh, 64); a0.w += __shfl_xor(a0.w, 8 << sh, 64);
+            }
+          if (VNX_GVD_ABL == 4) continue;
+          if ((uint32_t(slot[k]) & gmask) == 0u && slot[k] < n_slots) {
+            TV* p = out + __umul24(uint32_t(row[k]), q_stride) + ch4 * 4;
+            // several passes: the later ones add onto what the first stored (this lane wrote it: program order).  Non-temporal
+            // stores in every case: written with plain stores the 26 MB of rows of a T = 5 call stay dirty in L2 until the
+            // end-of-kernel write-back, which then takes 10 us (kernel 18.0 us; 7.8 without any store; 14.8 with `nt`) -- and a
+            // branch that stores the same value plain on one side and `nt` on the other is merged by the compiler into the
+            // plain form.
+            if (pass > 0) a0 += load4<TV>(p);
+            if constexpr (sizeof(TV) == 4 && VNX_GVD_STORE_POLICY != 0) {
+              float* fp = reinterpret_cast<float*>(p);
+#if VNX_GVD_STORE_POLICY == 1
+              *reinterpret_cast<float4_t*>(fp) = a0;
+#elif VNX_GVD_STORE_POLICY == 2
+              asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(fp), "v"(a0) : "memory");
+#elif VNX_GVD_STORE_POLICY == 3
+              asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(fp), "v"(a0) : "memory");
+#elif VNX_GVD_STORE_POLICY == 4
+              asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(fp), "v"(a0) : "memory");
+#elif VNX_GVD_STORE_POLICY == 5
+              asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(fp), "v"(a0) : "memory");
 #endif
-          store4<TV>(p, a0);
+            } else {
+              store4<TV>(p, a0);
+            }
+          }
         }
       }
     }
@@ -356,10 +403,11 @@ msda_bwd_gv_direct_kernel(const int64_t* __restrict__ shapes, const int64_t* __r
 }  // namespace rec
 
 // Workgroups per (batch, head): the host knows S, not the level shapes.  A level of n pixels has
-// max(ceil(n / ROWS), min(ut, n)) <= ceil(n / ROWS) + ut units (gvd_level_split), and sum ceil(n_l / ROWS) <= S / ROWS + L.
+// max(ceil(n / ROWS), min(ut, n)) units (gvd_level_split): ceil(n / ROWS) + 1 bounds it for ut <= 2, and
+// sum ceil(n_l / ROWS) <= S / ROWS + L.
 int msda_gvdirect_units_bound(const MsdaDims& d) {
-  const int ut = gvd_units_by_taps(d.Lq, d.P);
-  return d.S / VNX_GVD_ROWS + d.L + d.L * (ut > 1 ? ut : 0);
+  const int ut = gvd_units_min(d.S, d.L, d.B * d.M);
+  return d.S / VNX_GVD_ROWS + d.L + (ut > 1 ? d.L : 0);
 }
 
 bool msda_d32_gvdirect_supported(int vdt, int ldt, const MsdaDims& d) {
@@ -376,8 +424,8 @@ bool msda_d32_gvdirect_supported(int vdt, int ldt, const MsdaDims& d) {
 
 template <typename TV, typename TL>
 static int launch_gvdirect(const int64_t* shapes, const int64_t* lsi, const void* loc, const void* attn, const void* grad_out,
-                           void* grad_value, const MsdaDims& d, hipStream_t stream) {
-  const int ut = gvd_units_by_taps(d.Lq, d.P);
+                           void* grad_value, const MsdaDims& d, int compact, hipStream_t stream) {
+  const int ut = gvd_units_min(d.S, d.L, d.B * d.M);
   const int64_t blocks = ((int64_t(d.B) * msda_gvdirect_units_bound(d) + 1) & ~int64_t(1)) * d.M;   // (unit, batch) pairs: even (gv_decode_block)
   // more than 64 KiB of LDS per workgroup: the limit is raised once per kernel (and device: the attribute is per function)
 #define VNX_LAUNCH(PT)                                                                                                    \
@@ -393,17 +441,19 @@ static int launch_gvdirect(const int64_t* shapes, const int64_t* lsi, const void
     }                                                                                                                     \
     hipLaunchKernelGGL((rec::msda_bwd_gv_direct_kernel<TV, TL, PT>), dim3(uint32_t(blocks)), dim3(rec::kThreads),        \
                        rec::kGvdLdsBytes, stream, shapes, lsi, (const TL*)loc, (const TL*)attn, (const TV*)grad_out,     \
-                       (TV*)grad_value, d, ut, take_stamp_region(kStampGradValue, blocks));                              \
+                       (TV*)grad_value, d, ut, compact, take_stamp_region(kStampGradValue, blocks));                     \
   } while (0)
   if (d.P == 4) VNX_LAUNCH(4); else VNX_LAUNCH(0);
 #undef VNX_LAUNCH
   return check_launch("msda_bwd_gv_direct");
 }
 
-// grad_value from the op's own inputs; a no-op on the device when the levels are not packed.
+// grad_value from the op's own inputs (compact = false) or from the fused grad_loc kernel's copy of the decoded locations /
+// weights (compact = true: [batch][head][level][query][point], fp32); a no-op on the device when the levels are not packed.
 int msda_backward_gvdirect_d32(int vdt, int ldt, const int64_t* shapes, const int64_t* lsi, const void* loc,
-                               const void* attn, const void* grad_out, void* grad_value, MsdaDims d, hipStream_t stream) {
-#define VNX_ARGS shapes, lsi, loc, attn, grad_out, grad_value, d, stream
+                               const void* attn, const void* grad_out, void* grad_value, MsdaDims d, bool compact,
+                               hipStream_t stream) {
+#define VNX_ARGS shapes, lsi, loc, attn, grad_out, grad_value, d, int(compact), stream
   if (vdt == VNX_F32) return launch_gvdirect<float, float>(VNX_ARGS);
   if (vdt == VNX_BF16 && ldt == VNX_F32) return launch_gvdirect<bf16_t, float>(VNX_ARGS);
   if (vdt == VNX_BF16 && ldt == VNX_BF16) return launch_gvdirect<bf16_t, bf16_t>(VNX_ARGS);

@@ -208,21 +208,25 @@ __host__ __device__ inline GvSplit gv_level_split(int n, int units_min, int rows
 // rows, 10 per (batch, head) at 360p -- and hold no rows in registers: after one sort an 8-lane group walks its rows one
 // after the other and stores each at once.  Every level receives the same number of taps (4 x points x queries) whatever
 // its size, so a row of a coarse level (80 taps at the 60-pixel level of a 300-query call) is spread over 1 << gshift
-// adjacent groups whose partial sums meet in registers; `ut` (VNX_GVD_TAPS) can cut such a level further.
+// adjacent groups whose partial sums meet in registers; `ut` (gvd_units_min) cuts such a level in two when the grid has room.
 #ifndef VNX_GVD_QC
 #define VNX_GVD_QC 320            // queries staged per pass: 40 KiB of grad_out rows in LDS (all 300 of a decoder call)
 #endif
 #ifndef VNX_GVD_ROWS
 #define VNX_GVD_ROWS 640
 #endif
-#ifndef VNX_GVD_TAPS
-#define VNX_GVD_TAPS 8192         // taps per unit aimed at when a small level is cut (8192: never)
+#ifndef VNX_GVD_ONE_ROUND
+#define VNX_GVD_ONE_ROUND 512     // workgroups resident at once: 2 per CU x 256 CUs
 #endif
 struct GvdSplit { int units, rpu, gshift; };
-__host__ __device__ inline int gvd_units_by_taps(int Lq, int P) {
-  const int64_t taps = int64_t(4) * P * (Lq < VNX_GVD_QC ? Lq : VNX_GVD_QC);
-  const int64_t ut = (taps + VNX_GVD_TAPS - 1) / VNX_GVD_TAPS;
-  return ut < 1 ? 1 : (ut > 8 ? 8 : int(ut));
+// Units per level at least.  A level that fits one unit (the 240- and 60-pixel levels at 360p) receives as many taps as a
+// whole fine level, so its unit is the call's longest: when the grid has room for it in ONE round of resident workgroups such
+// a level is cut in two (T = 5 decoder call: 10 -> 12 units per (batch, head), 480 workgroups, kernel 14.8 -> 13.6 us; at
+// B = 10 the grid takes two rounds either way and the extra units cost 0.6 us: there 1).
+__host__ __device__ inline int gvd_units_min(int S, int L, int batch_heads) {
+  // (the host knows S and L, not the level sizes: S / ROWS + L bounds the units of the 640-row split; the levels that gain a
+  //  unit are the one or two smallest -- a heuristic for a tuning choice, any value is correct)
+  return int64_t(batch_heads) * (S / VNX_GVD_ROWS + L) <= VNX_GVD_ONE_ROUND ? 2 : 1;
 }
 __host__ __device__ inline GvdSplit gvd_level_split(int n, int ut, int Lq, int P) {
   GvdSplit s{0, 1, 0};
@@ -316,9 +320,19 @@ __host__ __device__ inline int gv_split_pieces_max(int batch_heads) {          /
   const int coarse = batch_heads < 32 ? VNX_QS_COARSE_SMALL : VNX_QS_COARSE;
   return mid > coarse ? mid : coarse;
 }
+// A split level is either coarse (<= 2 units: <= 2 x 256 pixels, `coarse` pieces) or middle (3-4 units: <= 4 x 256 pixels,
+// `mid` pieces), never both: a level contributes at most max(512 coarse, 1024 mid) rows, and all of them at most S x the
+// larger piece count.  (Until round 4 the bound was min(S, 1024 L) x max(mid, coarse): twice this, 134 MB at B = 2 for the
+// ~25 MB the pieces write, allocated by every backward call -- ADVICE r4.)
+static_assert(VNX_QS_MID <= VNX_QS_COARSE && 4 * VNX_QS_MID <= VNX_QS_COARSE_SMALL,
+              "msda_gvtiles_units_bound counts the extra workgroups of the split levels with the COARSE cap");
 __host__ __device__ inline int64_t gv_partial_rows_bound(int S, int L, int batch_heads) {      // partial rows per (batch, head), an upper bound
-  const int64_t px = int64_t(4) * kGvTileRowsMax * L;
-  return (px < S ? px : int64_t(S)) * gv_split_pieces_max(batch_heads);
+  const int64_t mid = batch_heads < 32 ? 4 * VNX_QS_MID : VNX_QS_MID;
+  const int64_t coarse = batch_heads < 32 ? VNX_QS_COARSE_SMALL : VNX_QS_COARSE;
+  const int64_t per_level_c = int64_t(2) * kGvTileRowsMax * coarse, per_level_m = int64_t(4) * kGvTileRowsMax * mid;
+  const int64_t by_levels = int64_t(L) * (per_level_c > per_level_m ? per_level_c : per_level_m);
+  const int64_t by_pixels = int64_t(S) * (coarse > mid ? coarse : mid);
+  return by_levels < by_pixels ? by_levels : by_pixels;
 }
 
 inline int elem_size(int dtype) {

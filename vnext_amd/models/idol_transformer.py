@@ -18,12 +18,12 @@ import torch
 from torch import nn
 from torch.nn.init import constant_, normal_, xavier_uniform_
 
-from ..ops.functions import level_tensors
 from ..ops.fused_ffn import ffn_block
 from ..ops.fused_norm import add_dropout_norm
 from ..ops.modules import MSDeformAttnIDOL
 from .seqformer_transformer import DeformableTransformerEncoder as _ClipEncoder
-from .seqformer_transformer import _get_activation_fn, _get_clones, inverse_sigmoid
+from .seqformer_transformer import _get_activation_fn, _get_clones
+from .transformer_common import ReferenceScaler, flatten_levels, refine_reference
 
 
 class DeformableTransformerEncoderLayer(nn.Module):
@@ -103,36 +103,27 @@ class DeformableTransformerDecoder(nn.Module):
 
     def forward(self, tgt, reference_points, src, src_spatial_shapes, src_level_start_index, src_valid_ratios,
                 query_pos=None, src_padding_mask=None):
-        output = tgt
-        inter, inter_refs, inter_samples = [], [], []
+        """tgt [N, Q, C], reference_points [N, Q, 2] -> stacked per-layer (queries [Ld, N, Q, C], references [Ld, N, Q, 4],
+        kept sampling points [Ld, N, Q, 30, 2] | None), or the last layer's (queries, references)."""
+        scaled = ReferenceScaler(src_valid_ratios, extra_axes=1)       # [N, 1, L, 2|4] against [N, Q, 1, 2|4]
+        unscale = src_valid_ratios[:, None, None, None, :, :]
+        queries = tgt
+        kept, kept_refs, kept_samples = [], [], []
         for lid, layer in enumerate(self.layers):
-            if reference_points.shape[-1] == 4:
-                ref_in = reference_points[:, :, None] * torch.cat([src_valid_ratios, src_valid_ratios], -1)[:, None]
-            else:
-                assert reference_points.shape[-1] == 2
-                ref_in = reference_points[:, :, None] * src_valid_ratios[:, None]
-            output, loc, w = layer(output, query_pos, ref_in, src, src_spatial_shapes, src_level_start_index,
-                                   src_padding_mask)
-            if self.return_samples:   # the 30 heaviest sampling points of every query (:352-358)
-                N, Lq = loc.shape[:2]
-                loc = (loc / src_valid_ratios[:, None, None, None, :, :]).view(N, Lq, -1, 2)
-                top = w.view(N, Lq, -1).topk(30, dim=2)[1]
-                inter_samples.append(torch.gather(loc, 2, top.unsqueeze(-1).expand(-1, -1, -1, 2)))
+            queries, loc, w = layer(queries, query_pos, scaled(reference_points), src, src_spatial_shapes,
+                                    src_level_start_index, src_padding_mask)
+            if self.return_samples:   # the 30 heaviest sampling points of every query, in unpadded image coordinates
+                flat = (loc / unscale).flatten(2, 4)
+                heaviest = w.flatten(2).topk(30, dim=2)[1]
+                kept_samples.append(torch.gather(flat, 2, heaviest.unsqueeze(-1).expand(-1, -1, -1, 2)))
             if self.bbox_embed is not None:
-                tmp = self.bbox_embed[lid](output)
-                if reference_points.shape[-1] == 4:
-                    new_ref = (tmp + inverse_sigmoid(reference_points)).sigmoid()
-                else:
-                    new_ref = tmp
-                    new_ref[..., :2] = tmp[..., :2] + inverse_sigmoid(reference_points)
-                    new_ref = new_ref.sigmoid()
-                reference_points = new_ref.detach()
+                reference_points = refine_reference(self.bbox_embed[lid](queries), reference_points)
             if self.return_intermediate:
-                inter.append(output)
-                inter_refs.append(reference_points)
-        if self.return_intermediate:
-            return torch.stack(inter), torch.stack(inter_refs), (torch.stack(inter_samples) if inter_samples else None)
-        return output, reference_points
+                kept.append(queries)
+                kept_refs.append(reference_points)
+        if not self.return_intermediate:
+            return queries, reference_points
+        return torch.stack(kept), torch.stack(kept_refs), (torch.stack(kept_samples) if kept_samples else None)
 
 
 class DeformableTransformer(nn.Module):
@@ -184,22 +175,13 @@ class DeformableTransformer(nn.Module):
         """srcs: per level [N, C, H_l, W_l]; -> (hs [Ld, N, Q, C], memory [N, S, C], init_reference
         [N, Q, 2], inter_references [Ld, N, Q, 4], inter_samples | None, None, None)  (:135-198)"""
         assert query_embed is not None
-        src_flatten, mask_flatten, pos_flatten, shapes = [], [], [], []
-        for lvl, (src, mask, pos) in enumerate(zip(srcs, masks, pos_embeds)):
-            shapes.append(tuple(src.shape[-2:]))
-            src_flatten.append(src.flatten(2).transpose(1, 2))
-            mask_flatten.append(mask.flatten(1))
-            pos_flatten.append(pos.flatten(2).transpose(1, 2) + self.level_embed[lvl].view(1, 1, -1))
-        src_flatten, mask_flatten, pos_flatten = torch.cat(src_flatten, 1), torch.cat(mask_flatten, 1), torch.cat(pos_flatten, 1)
-        spatial_shapes, level_start_index = level_tensors(shapes, src_flatten.device)
+        memory_in, padding, pos, shapes_t, start_t, sizes = flatten_levels(srcs, masks, pos_embeds, self.level_embed)
         valid_ratios = torch.stack([self.get_valid_ratio(m) for m in masks], 1)
-        memory = self.encoder(src_flatten, spatial_shapes, level_start_index, valid_ratios, pos_flatten,
-                              mask_flatten, spatial_shapes_list=shapes)
-        bs, _, c = memory.shape
-        query_embed, tgt = torch.split(query_embed, c, dim=1)
-        query_embed = query_embed.unsqueeze(0).expand(bs, -1, -1)
-        tgt = tgt.unsqueeze(0).expand(bs, -1, -1)
-        reference_points = self.reference_points(query_embed).sigmoid()
-        hs, inter_references, inter_samples = self.decoder(tgt, reference_points, memory, spatial_shapes,
-                                                           level_start_index, valid_ratios, query_embed, mask_flatten)
-        return hs, memory, reference_points, inter_references, inter_samples, None, None
+        memory = self.encoder(memory_in, shapes_t, start_t, valid_ratios, pos, padding, spatial_shapes_list=sizes)
+        images, channels = memory.shape[0], memory.shape[-1]
+        query_pos = query_embed[:, :channels].unsqueeze(0).expand(images, -1, -1)
+        tgt = query_embed[:, channels:].unsqueeze(0).expand(images, -1, -1)
+        init_reference = self.reference_points(query_pos).sigmoid()
+        hs, inter_references, inter_samples = self.decoder(tgt, init_reference, memory, shapes_t, start_t, valid_ratios,
+                                                           query_pos, padding)
+        return hs, memory, init_reference, inter_references, inter_samples, None, None

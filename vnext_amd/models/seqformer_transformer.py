@@ -19,18 +19,11 @@ import torch.nn.functional as F
 from torch import nn
 from torch.nn.init import constant_, normal_, xavier_uniform_
 
-from ..ops.functions import level_tensors
 from ..ops.fused_ffn import ffn_block
 from ..ops.fused_norm import add_dropout_norm
 from ..ops.modules import MSDeformAttnSeqFormer
+from .transformer_common import ReferenceScaler, flatten_levels, inverse_sigmoid, refine_reference  # noqa: F401  (inverse_sigmoid: re-exported)
 
-
-def inverse_sigmoid(x, eps=1e-5):
-    # projects/SeqFormer/seqformer/util/misc.py:493-497
-    x = x.clamp(min=0, max=1)
-    x1 = x.clamp(min=eps)
-    x2 = (1 - x).clamp(min=eps)
-    return torch.log(x1 / x2)
 
 
 def _get_clones(module, n):
@@ -196,35 +189,23 @@ class DeformableTransformerDecoder(nn.Module):
 
     def forward(self, tgt, reference_points, src, src_spatial_shapes, src_level_start_index, src_valid_ratios,
                 query_pos=None, src_padding_mask=None):
-        output = tgt
-        output_box = tgt
-        intermediate, intermediate_box, intermediate_reference_points = [], [], []
+        """tgt [N, Q, C] (both query streams start from it), reference_points [N, T, Q, 2] ->
+        stacked per-layer (mask/class queries [Ld, N, Q, C], box queries [Ld, N, T, Q, C], references [Ld, N, T, Q, 4], None),
+        or the last layer's (queries, references) without `return_intermediate`."""
+        scaled = ReferenceScaler(src_valid_ratios, extra_axes=2)       # [N, 1, 1, L, 2|4] against [N, T, Q, 1, 2|4]
+        queries, box_queries = tgt, tgt
+        kept = ([], [], [])
         for lid, layer in enumerate(self.layers):
-            if reference_points.shape[-1] == 4:
-                reference_points_input = reference_points[:, :, :, None] \
-                    * torch.cat([src_valid_ratios, src_valid_ratios], -1)[:, None, None]
-            else:
-                assert reference_points.shape[-1] == 2
-                reference_points_input = reference_points[:, :, :, None] * src_valid_ratios[:, None, None]
-            output, output_box, _, _ = layer(output, output_box, query_pos, reference_points_input, src,
-                                             src_spatial_shapes, src_level_start_index, src_padding_mask)
+            queries, box_queries, _, _ = layer(queries, box_queries, query_pos, scaled(reference_points), src,
+                                               src_spatial_shapes, src_level_start_index, src_padding_mask)
             if self.bbox_embed is not None:
-                tmp = self.bbox_embed[lid](output_box)
-                if reference_points.shape[-1] == 4:
-                    new_reference_points = (tmp + inverse_sigmoid(reference_points)).sigmoid()
-                else:
-                    new_reference_points = tmp
-                    new_reference_points[..., :2] = tmp[..., :2] + inverse_sigmoid(reference_points)
-                    new_reference_points = new_reference_points.sigmoid()
-                reference_points = new_reference_points.detach()
+                reference_points = refine_reference(self.bbox_embed[lid](box_queries), reference_points)
             if self.return_intermediate:
-                intermediate.append(output)
-                intermediate_box.append(output_box)
-                intermediate_reference_points.append(reference_points)
-        if self.return_intermediate:
-            return (torch.stack(intermediate), torch.stack(intermediate_box),
-                    torch.stack(intermediate_reference_points), None)
-        return output, reference_points
+                for store, item in zip(kept, (queries, box_queries, reference_points)):
+                    store.append(item)
+        if not self.return_intermediate:
+            return queries, reference_points
+        return tuple(torch.stack(store) for store in kept) + (None,)
 
 
 class DeformableTransformer(nn.Module):
@@ -267,33 +248,18 @@ class DeformableTransformer(nn.Module):
         return torch.stack([valid_W.float() / W, valid_H.float() / H], -1)
 
     def forward(self, srcs, masks, pos_embeds, query_embed=None):
+        """srcs / pos_embeds per level [N, T, C, H_l, W_l], masks [N, T, H_l, W_l], query_embed [Q, 2C] ->
+        (hs, hs_box, memory [N, T, S, C], initial references [N, T, Q, 2], per-layer references, None, None, valid_ratios)."""
         assert query_embed is not None
-        src_flatten, mask_flatten, lvl_pos_embed_flatten, spatial_shapes = [], [], [], []
-        for lvl, (src, mask, pos_embed) in enumerate(zip(srcs, masks, pos_embeds)):
-            bs, nf, c, h, w = src.shape
-            spatial_shapes.append((h, w))
-            src_flatten.append(src.flatten(3).transpose(2, 3))
-            mask_flatten.append(mask.flatten(2))
-            lvl_pos_embed_flatten.append(pos_embed.flatten(3).transpose(2, 3) + self.level_embed[lvl].view(1, 1, 1, -1))
-        src_flatten = torch.cat(src_flatten, 2)
-        mask_flatten = torch.cat(mask_flatten, 2)
-        lvl_pos_embed_flatten = torch.cat(lvl_pos_embed_flatten, 2)
-        shapes_list = spatial_shapes
-        # cached device tensors, tagged as packed (the op's backward then skips the general-path
-        # launches) and with their host-side sizes (no device read for the length checks)
-        spatial_shapes, level_start_index = level_tensors(shapes_list, src_flatten.device)
-        valid_ratios = torch.stack([self.get_valid_ratio(m[:, 0]) for m in masks], 1)
+        memory_in, padding, pos, shapes_t, start_t, sizes = flatten_levels(srcs, masks, pos_embeds, self.level_embed)
+        valid_ratios = torch.stack([self.get_valid_ratio(m[:, 0]) for m in masks], 1)      # of the clip's first frame
+        memory = self.encoder(memory_in, shapes_t, start_t, valid_ratios, pos, padding, spatial_shapes_list=sizes)
 
-        memory = self.encoder(src_flatten, spatial_shapes, level_start_index, valid_ratios, lvl_pos_embed_flatten,
-                              mask_flatten, spatial_shapes_list=shapes_list)
-
-        bs, nf, _, c = memory.shape
-        query_embed, tgt = torch.split(query_embed, c, dim=1)
-        query_embed = query_embed.unsqueeze(0).expand(bs, -1, -1)
-        tgt = tgt.unsqueeze(0).expand(bs, -1, -1)
-        reference_points = self.reference_points(query_embed).sigmoid()
-        reference_points = reference_points.unsqueeze(1).repeat(1, nf, 1, 1)
-        init_reference_out = reference_points
-        hs, hs_box, inter_references, inter_samples = self.decoder(
-            tgt, reference_points, memory, spatial_shapes, level_start_index, valid_ratios, query_embed, mask_flatten)
-        return hs, hs_box, memory, init_reference_out, inter_references, inter_samples, None, valid_ratios
+        clips, frames, channels = memory.shape[0], memory.shape[1], memory.shape[-1]
+        query_pos = query_embed[:, :channels].unsqueeze(0).expand(clips, -1, -1)
+        tgt = query_embed[:, channels:].unsqueeze(0).expand(clips, -1, -1)
+        # one learned reference point per query, the same in every frame of the clip to begin with
+        init_reference = self.reference_points(query_pos).sigmoid().unsqueeze(1).repeat(1, frames, 1, 1)
+        hs, hs_box, inter_references, inter_samples = self.decoder(tgt, init_reference, memory, shapes_t, start_t,
+                                                                   valid_ratios, query_pos, padding)
+        return hs, hs_box, memory, init_reference, inter_references, inter_samples, None, valid_ratios

@@ -19,6 +19,7 @@ import tempfile
 
 TUNED_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tunableop_mi355x.csv")
 _state = {"enabled": False, "entries": 0, "why": "not requested"}
+_prev = {}        # TunableOp's results file name before enable() moved it (restored by disable())
 
 
 def enable(path: str | None = None) -> dict:
@@ -45,7 +46,7 @@ def enable(path: str | None = None) -> dict:
         # would leave a CSV behind.  PyTorch 2.10 has no such switch (it writes a result when tuning produces
         # one, i.e. never here); the file name is moved away from the working directory and the repo either way, and
         # disable() puts it back.
-        _state["prev_filename"] = tunable.get_filename()
+        _prev["filename"] = tunable.get_filename()
         tunable.set_filename(os.path.join(tempfile.gettempdir(), "vnx_tunableop_%d.csv" % os.getpid()))
         if hasattr(tunable, "write_file_on_exit"):
             tunable.write_file_on_exit(False)
@@ -67,8 +68,8 @@ def disable() -> None:
     if _state["enabled"]:
         import torch.cuda.tunable as tunable
         tunable.enable(False)
-        if _state.get("prev_filename"):
-            tunable.set_filename(_state.pop("prev_filename"))
+        if _prev.get("filename"):
+            tunable.set_filename(_prev.pop("filename"))
         _state.update(enabled=False, entries=0, why="disabled")
 
 
