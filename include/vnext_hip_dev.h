@@ -40,6 +40,9 @@ int vnx_debug_stamp_regions(int* kinds, long long* offsets, long long* blocks, i
  * n 64-bit words of the kernel's fixed device array to `host`; returns a hipError_t as int */
 int vnx_debug_read_rec_stamps(unsigned long long* host, int n);
 int vnx_debug_read_tile_stamps(unsigned long long* host, int n);
+/* the same for the self-decoding grad_value kernel (msda_d32_gvdirect.hip), 8 stamps per workgroup, of a library built with
+ * -DVNX_GVD_STAMPS (zeros otherwise) */
+int vnx_debug_read_gvd_stamps(unsigned long long* host, int n);
 
 #ifdef __cplusplus
 }

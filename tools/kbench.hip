@@ -250,7 +250,7 @@ int main(int argc, char** argv) {
   std::string shape = "dec360", dist = "U", op = "fwd", variants = "0", dtype = "f32";
   int B = 5, lq = 0, inner = 24, reps = 15, voff = 0;   // voff: floats added to every `value` base (alignment experiments)
   double warm_s = 0.06;
-  bool check = false, cold_only = false, dma = false, stamps = false, timeline = false, hbm = false, eager = false;
+  bool check = false, cold_only = false, dma = false, stamps = false, timeline = false, hbm = false, eager = false, gvd_stamps = false;
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
     auto next = [&]() { return std::string(i + 1 < argc ? argv[++i] : ""); };
@@ -272,6 +272,7 @@ int main(int argc, char** argv) {
     else if (a == "--timeline") timeline = true;
     else if (a == "--hbm-probe") hbm = true;
     else if (a == "--eager") eager = true;        // also time plain (uncaptured) launches, cold inputs
+    else if (a == "--gvd-stamps") gvd_stamps = true;   // phase stamps of the self-decoding grad_value kernel (library built with -DVNX_GVD_STAMPS)
     else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 1; }
   }
   if (dma) { run_dma_probe(); run_dma_high_probe(); }
@@ -468,6 +469,35 @@ int main(int argc, char** argv) {
       if (eager) printf("  variant %4d %s: eager (no graph) %8.2f us per call\n", v, is_bwd ? "bwd" : "fwd", time_eager(is_bwd));
       fflush(stdout);
     }
+  }
+  if (gvd_stamps) {   // mean phase durations of msda_bwd_gv_direct_kernel over its workgroups, cold inputs, grad_value kernel alone
+    vnx_set_kernel_variant(442);
+    const char* nm[8] = {"", "table", "issue", "load+decode+rank", "barrier", "scan+barrier", "scatter+rows+barrier", "walk+store"};
+    double sum[8] = {0}, dur_sum = 0; int n = 0;
+    std::vector<double> st0, en;
+    for (int rep = 0; rep < 6; ++rep) {
+      for (int i = 0; i < nsets; ++i) bwd(sets[i]);       // the last launch's stamps are read: preceded by cold launches
+      CK(hipStreamSynchronize(st));
+      std::vector<unsigned long long> hs(4096 * 8);
+      vnx_debug_read_gvd_stamps(hs.data(), 4096 * 8);
+      unsigned long long t0 = ~0ull;
+      for (int w = 0; w < 4096; ++w) if (hs[w * 8 + 7] > hs[w * 8] && hs[w * 8 + 1]) t0 = std::min(t0, hs[w * 8]);
+      for (int w = 0; w < 4096; ++w) {
+        const unsigned long long* t = &hs[w * 8];
+        if (!(t[7] > t[0]) || t[1] == 0) continue;
+        ++n;
+        for (int k = 1; k < 8; ++k) sum[k] += (t[k] - t[k - 1]) * 0.01;
+        dur_sum += (t[7] - t[0]) * 0.01;
+        st0.push_back((t[0] - t0) * 0.01); en.push_back((t[7] - t0) * 0.01);
+      }
+    }
+    std::sort(st0.begin(), st0.end()); std::sort(en.begin(), en.end());
+    auto pc = [](const std::vector<double>& x, double p) { return x.empty() ? 0.0 : x[std::min(x.size() - 1, size_t(p * x.size()))]; };
+    printf("  gv_direct phases over %d workgroups (us):", n);
+    for (int k = 1; k < 8; ++k) printf(" %s %.2f", nm[k], sum[k] / std::max(n, 1));
+    printf(" | total %.2f | start p50 %.2f p90 %.2f max %.2f | end p50 %.2f p90 %.2f max %.2f\n", dur_sum / std::max(n, 1), pc(st0, .5), pc(st0, .9),
+           st0.empty() ? 0 : st0.back(), pc(en, .5), pc(en, .9), en.empty() ? 0 : en.back());
+    vnx_set_kernel_variant(0);
   }
   if (timeline) {   // per-workgroup {start, end} of the forward kernel on cold inputs (100 MHz wall clock, 10 ns ticks)
     size_t pos2 = 0;

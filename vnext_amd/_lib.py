@@ -66,6 +66,7 @@ DEV_SIGNATURES = {
     "vnx_debug_stamp_regions": (_i, [ctypes.POINTER(_i), ctypes.POINTER(_ll), ctypes.POINTER(_ll), _i]),
     "vnx_debug_read_rec_stamps": (_i, [ctypes.POINTER(ctypes.c_ulonglong), _i]),
     "vnx_debug_read_tile_stamps": (_i, [ctypes.POINTER(ctypes.c_ulonglong), _i]),
+    "vnx_debug_read_gvd_stamps": (_i, [ctypes.POINTER(ctypes.c_ulonglong), _i]),
 }
 
 

@@ -173,6 +173,38 @@ __device__ __forceinline__ int gv_rows_per_unit(int n, int units_min, int rows_m
 //     workgroup, <= 4 096 rows), and at compile time: the same choice made by a run-time flag cost 0.3 us.
 template <typename T> __device__ __forceinline__ T nt_load(const T* p) { return __builtin_nontemporal_load(p); }
 
+// One lane's sample: its level's size and first pixel, its location and its attention weight -- FOUR requests issued
+// together, one wait (fp32 locations).  Written as asm because the compiler sinks ordinary loads to their first use: the
+// level start and the attention weight are used only inside the in-bounds branch, so they went out after the location had
+// arrived -- the T = 5 forward ran locations -> (level start, attention weight) -> gathers, three dependent round trips
+// instead of two, the grad_loc kernel locations -> shapes -> level start -> gathers (ISA, round 5).  The two geometry loads
+// hit L2 and are requested first: a wave's loads return in order, the cold location load sets the pace.
+template <bool NT>
+__device__ __forceinline__ void load_sample_f32(const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
+                                                const float* __restrict__ loc, const float* __restrict__ attn, int l, int64_t wi,
+                                                int& H, int& W, int& start, float& x, float& y, float& a) {
+  typedef int i4_t __attribute__((ext_vector_type(4)));
+  typedef int i2_t __attribute__((ext_vector_type(2)));
+  i4_t hw;
+  i2_t st;
+  float2_t xy;
+  if constexpr (NT)
+    asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx2 %1, %5, off\n\t"
+                 "global_load_dwordx2 %2, %6, off nt\n\tglobal_load_dword %3, %7, off nt"
+                 : "=&v"(hw), "=&v"(st), "=&v"(xy), "=&v"(a)
+                 : "v"(shapes + 2 * l), "v"(lsi + l), "v"(loc + 2 * wi), "v"(attn + wi)
+                 : "memory");
+  else
+    asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx2 %1, %5, off\n\t"
+                 "global_load_dwordx2 %2, %6, off\n\tglobal_load_dword %3, %7, off"
+                 : "=&v"(hw), "=&v"(st), "=&v"(xy), "=&v"(a)
+                 : "v"(shapes + 2 * l), "v"(lsi + l), "v"(loc + 2 * wi), "v"(attn + wi)
+                 : "memory");
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(hw), "+v"(st), "+v"(xy), "+v"(a) : : "memory");
+  H = hw.x; W = hw.z; start = st.x;      // int64 entries, narrowed as the reference does (cuh:276-277)
+  x = xy.x; y = xy.y;
+}
+
 __device__ __forceinline__ float row16_max(float v) {
 #pragma unroll
   for (int k = 1; k < 16; k <<= 1) v = fmaxf(v, __shfl_xor(v, k, 16));
@@ -363,6 +395,7 @@ msda_fwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
 
   // ---- phase 1: one (query, sample) pair per lane and step --------------------
   const int pairs = QPW * LP;
+  constexpr bool kOneRequest = !PF && !FUSED && sizeof(TL) == 4 && LP_T > 0 && QPW * LP_T <= 64;      // see load_sample_f32
   for (int e = lane; e < pairs; e += 64) {
     const int qi = e / LP, p = e - qi * LP;
     const int q = q0 + qi;
@@ -381,8 +414,10 @@ msda_fwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
       if constexpr (PF) {
         x = pf_x; y = pf_y; a = pf_a;
       } else if constexpr (!FUSED) {
-        if constexpr (sizeof(TL) == 4) {
-          if constexpr (WPB == 1) {   // the small-call configuration (pick_fwd_cfg): `nt` loads, see nt_load
+        if constexpr (kOneRequest) {
+          // (filled below, together with the level geometry: load_sample_f32)
+        } else if constexpr (sizeof(TL) == 4) {
+          if constexpr (WPB == 1) {
             x = to_acc(nt_load(loc + 2 * wi)); y = to_acc(nt_load(loc + 2 * wi + 1));
             a = to_acc(nt_load(attn + wi));
           } else {
@@ -395,16 +430,9 @@ msda_fwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
         }
       }
       int H, W, start;
-      if constexpr (PF) {
-        // level geometry through the scalar cache (lgkmcnt): a vector load here would queue behind the
-        // stream above and its s_waitcnt vmcnt(0) would wait for all of it.  PF launches have L <= 4.
-        H = W = 1; start = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-          if (k < d.L) {
-            const int Hk = int(shapes[2 * k]), Wk = int(shapes[2 * k + 1]), sk = int(lsi[k]);
-            if (l == k) { H = Hk; W = Wk; start = sk; }
-          }
+      if constexpr (kOneRequest) {      // one (query, sample) per lane, fp32 locations: geometry, location and weight in one request
+        load_sample_f32<WPB == 1>(shapes, lsi, reinterpret_cast<const float*>(loc), reinterpret_cast<const float*>(attn), l, wi,
+                                  H, W, start, x, y, a);      // (WPB == 1: the small-call configuration, `nt` loads, see nt_load)
       } else {
         H = int(shapes[2 * l]); W = int(shapes[2 * l + 1]);
         start = int(lsi[l]);
@@ -870,9 +898,14 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
       g4.w = a;   // the softmax weight of every sample, in or out of the map (softmax backward, phase 3)
     }
     if (q < d.Lq) {
-      if constexpr (!FUSED) {
-        if constexpr (WPB == 1 && sizeof(TL) == 4) {     // small-call configuration: `nt` loads as in the forward (headline
-          x = to_acc(nt_load(loc + 2 * wi)); y = to_acc(nt_load(loc + 2 * wi + 1));      // backward 27.3 -> 27.1 us)
+      int H = 1, W = 1, start = 0;
+      constexpr bool kOneRequest = !FUSED && sizeof(TL) == 4 && LP_T > 0 && QPW * LP_T <= 64;      // see load_sample_f32
+      if constexpr (kOneRequest) {      // (WPB == 1, the small-call configuration: `nt` loads as in the forward)
+        load_sample_f32<WPB == 1>(shapes, lsi, reinterpret_cast<const float*>(loc), reinterpret_cast<const float*>(attn), l, wi,
+                                  H, W, start, x, y, a);
+      } else if constexpr (!FUSED) {
+        if constexpr (WPB == 1 && sizeof(TL) == 4) {
+          x = to_acc(nt_load(loc + 2 * wi)); y = to_acc(nt_load(loc + 2 * wi + 1));
           a = to_acc(nt_load(attn + wi));
         } else {
           x = to_acc(loc[2 * wi]); y = to_acc(loc[2 * wi + 1]);
@@ -887,8 +920,7 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
           fa.tile_attn[ci] = a;
         }
       }
-      const int H = int(shapes[2 * l]), W = int(shapes[2 * l + 1]);
-      const int start = int(lsi[l]);
+      if constexpr (!kOneRequest) { H = int(shapes[2 * l]); W = int(shapes[2 * l + 1]); start = int(lsi[l]); }
       keep_H = H; keep_W = W;
       const float h = y * float(H) - 0.5f, w = x * float(W) - 0.5f;
       uint4_t record = {0xffffffffu, 0u, 0u, 0u};  // sample outside the map: no taps

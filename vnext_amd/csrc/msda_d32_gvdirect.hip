@@ -36,7 +36,7 @@ namespace rec {
 #define VNX_GVD_UNITS_PER_CU 2
 #endif
 #ifndef VNX_GVD_DMA
-#define VNX_GVD_DMA 1             // fp32 grad_out rows -> LDS by buffer_load ... lds (0: through registers)
+#define VNX_GVD_DMA 0             // A/B: fp32 grad_out rows -> LDS by buffer_load ... lds (0: through registers, see request_rows)
 #endif
 #ifndef VNX_GVD_AUX
 #define VNX_GVD_AUX 0             // cache policy of the location / weight loads (2 = nt)
@@ -46,14 +46,19 @@ namespace rec {
 #ifndef VNX_GVD_ABL
 #define VNX_GVD_ABL 0
 #endif
-#ifndef VNX_GVD_LATE_ROWS
-#define VNX_GVD_LATE_ROWS 0       // A/B: request the first pass's grad_out rows after the level table, with the samples
+#ifndef VNX_GVD_FULL_BARRIERS
+#define VNX_GVD_FULL_BARRIERS 0   // A/B: __syncthreads() (waits for the rows in flight) where the kernel has LDS-only barriers
 #endif
-#ifndef VNX_GVD_STORE_POLICY
-#define VNX_GVD_STORE_POLICY 0    // A/B, fp32 rows: 0 = nt, 1 = plain, 2 = sc1 nt, 3 = sc0 sc1, 4 = sc0 sc1 nt, 5 = sc1
-#endif
-#ifndef VNX_GVD_WALK
-#define VNX_GVD_WALK 1            // rows a group has in flight while it walks (1 | 2)
+
+
+// Development aid (-DVNX_GVD_STAMPS, development library only): per-workgroup phase timestamps in constant-rate wall-clock
+// ticks, 8 per workgroup -- 0 start, 1 level table read, 2 loads issued, 3 decoded + ranked (the loads have arrived),
+// 4 first barrier, 5 offsets + second barrier, 6 scattered + rows staged + third barrier, 7 rows walked and stored.
+#ifdef VNX_GVD_STAMPS
+__device__ unsigned long long g_gvd_stamps[4096 * 8];
+#define VNX_GVD_STAMP(k) do { if (tid == 0 && blockIdx.x < 4096) g_gvd_stamps[blockIdx.x * 8 + (k)] = (unsigned long long)wall_clock64(); } while (0)
+#else
+#define VNX_GVD_STAMP(k) do { } while (0)
 #endif
 
 constexpr int kGvdQc = VNX_GVD_QC;
@@ -65,6 +70,15 @@ constexpr int kGvdRowPieces = (kGvdQc * 8 + kThreads - 1) / kThreads;   // 16-B 
 constexpr size_t kGvdLdsBytes = size_t(kGvdQc) * 128 + size_t(kGvdCap) * 6 + size_t(kGvdRows) * 12 + 16 + 4 * kLevelsMax * 4;
 static_assert(kGvdLdsBytes * VNX_GVD_UNITS_PER_CU <= 160 * 1024, "the units that share a CU must fit its LDS");
 static_assert(kGvdCap < 65536 && kGvdQc < 65536, "tap ranks and query slots fit 16 bits");
+
+// A barrier that orders LDS only.  __syncthreads() is a workgroup-scope fence over ALL memory: on gfx9 (one counter for
+// vector loads and stores) it waits for every outstanding global load -- here the 38 KB of grad_out rows a workgroup has in
+// flight while it decodes and sorts.  The fences below name the local address space, so only lgkmcnt is waited for.
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
 
 template <typename TV, typename TL, int P_T>
 __global__ void __launch_bounds__(kThreads, VNX_GVD_UNITS_PER_CU * kWaves / 4)
@@ -91,9 +105,15 @@ msda_bwd_gv_direct_kernel(const int64_t* __restrict__ shapes, const int64_t* __r
   if (kGvPair16 && sizeof(TV) == 2 && (d.M & 1) == 0) gv_decode_block<true>(blockIdx.x, d.M, d.B, rest, b, m);
   else gv_decode_block<false>(blockIdx.x, d.M, d.B, rest, b, m);
   const int unit = rest / d.B;
+  VNX_GVD_STAMP(0);
 
-  // ---- the grad_out rows of this head (all queries of a pass: 16 B per thread and step) depend on (batch, head) only: the
-  //      first pass's are requested before anything else, and arrive while the level table is read -----------------------------
+  // ---- the grad_out rows of this head, all queries of a pass: 16 B per thread and step, into registers, written to LDS just
+  //      before the walk.  They are REQUESTED behind the pass's samples and stay in flight across the decode, the ranking and
+  //      the two LDS-only barriers of the sort (lds_barrier).  The first forms of the round requested them first -- by LDS-DMA,
+  //      before the level table -- and lost 1.3 us to three things the phase stamps showed: a wave's loads return in order,
+  //      so nothing requested after the rows could be used before they had landed; __syncthreads() waits for every load in
+  //      flight; and with an LDS-DMA pending the compiler makes every LDS access wait for it (it cannot tell the DMA's
+  //      target from the access).  VNX_GVD_DMA = 1 keeps the DMA form for A/B runs. -----------------------------
   const TV* go_head = grad_out + (int64_t(b) * d.Lq * d.M + m) * D;
   const uint32_t q_stride = uint32_t(d.M) * uint32_t(D);
   constexpr uint32_t kOutOfRange = 0x80000000u;          // byte ranges stay below 2^31 (msda_d32_gvdirect_supported)
@@ -129,24 +149,19 @@ msda_bwd_gv_direct_kernel(const int64_t* __restrict__ shapes, const int64_t* __r
       }
     }
   };
-#if !VNX_GVD_LATE_ROWS
-  request_rows(0);
-#endif
-
+  int lvl = -1, r0 = 0, r1 = 0, Hl = 0, Wl = 0, start = 0, gshift = 0;
+  bool packed = true;
   if (tid < d.L) {      // level table: lane l works out level l's unit split once
-    const int H = int(shapes[2 * tid]), W = int(shapes[2 * tid + 1]);
-    const GvdSplit sp = gvd_level_split(H * W, ut, d.Lq, P);
-    meta[4 * tid] = H; meta[4 * tid + 1] = W; meta[4 * tid + 2] = int(lsi[tid]);
+    const int H = int(shapes[2 * tid]), W = int(shapes[2 * tid + 1]), first = int(lsi[tid]);     // (one round trip: both requested
+    const GvdSplit sp = gvd_level_split(H * W, ut, d.Lq, P);                                     //  before the divisions below)
+    meta[4 * tid] = H; meta[4 * tid + 1] = W; meta[4 * tid + 2] = first;
     meta[4 * tid + 3] = sp.units | (sp.rpu << 18) | (sp.gshift << 29);      // units < 2^18 (S < 2^27), rpu <= 2047, gshift <= 3
   }
   for (int i = tid; i < 2 * kGvdRows; i += kThreads) cnt2[i] = 0;
   if (tid == 0) alloc[0] = 0;
-  __syncthreads();
-
-  int lvl = -1, r0 = 0, r1 = 0, Hl = 0, Wl = 0, start = 0, gshift = 0;
+  lds_barrier();
   {
     int running = 0;
-    bool packed = true;
     int u = unit;
     for (int l = 0; l < d.L; ++l) {
       packed = packed && (meta[4 * l + 2] == running);
@@ -167,17 +182,21 @@ msda_bwd_gv_direct_kernel(const int64_t* __restrict__ shapes, const int64_t* __r
       }
     }
     packed = packed && (running == d.S);
-    if (!packed || lvl < 0) {        // uniform over the workgroup (unpacked levels: the general path does the call, capi.hip)
-      if constexpr (kDma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the rows in flight land in LDS this workgroup still owns
-      return;
-    }
   }
-  // uniform over the workgroup, but it came through LDS: scalarise (SGPRs instead of VGPRs, see opaque())
+  if (!packed || lvl < 0) {        // uniform over the workgroup (unpacked levels: the general path does the call, capi.hip)
+    if constexpr (kDma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the rows in flight land in LDS this workgroup still owns
+    return;
+  }
+  // uniform over the workgroup, but it came through LDS: scalarise (SGPRs instead of VGPRs, see opaque()).
+  // (Tried: every lane reading the level sizes through the scalar cache and working the unit out in registers, no LDS -- the
+  //  phase stamps showed why it buys nothing, 2.6 vs 2.3 us: the first barrier of the kernel waits for the row DMA requested
+  //  above either way; what this phase costs is those 38 KB arriving, not the table.)
   lvl = __builtin_amdgcn_readfirstlane(lvl); r0 = __builtin_amdgcn_readfirstlane(r0); r1 = __builtin_amdgcn_readfirstlane(r1);
   Hl = __builtin_amdgcn_readfirstlane(Hl); Wl = __builtin_amdgcn_readfirstlane(Wl); start = __builtin_amdgcn_readfirstlane(start);
   gshift = __builtin_amdgcn_readfirstlane(gshift);
   if (VNX_GVD_ABL == 1) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
   const int rows = r1 - r0;
+  VNX_GVD_STAMP(1);
 
   const int LP = d.L * P;
   // sample (q, head m, level lvl, point k) of this batch element: element  q * (M * LP) + k  from s_base on in the op's own
@@ -227,7 +246,8 @@ msda_bwd_gv_direct_kernel(const int64_t* __restrict__ shapes, const int64_t* __r
         }
       }
     }
-    if (pass > 0 || VNX_GVD_LATE_ROWS) request_rows(q_lo);      // (the first pass's rows were requested before the level table)
+    request_rows(q_lo);      // behind the samples: a wave's loads return in order, and the samples are needed first
+    if (pass == 0) VNX_GVD_STAMP(2);
 
     // ---- decode (cuh:285-288, 38-45), rank every tap inside its row ------------------------------------------------------
     uint32_t mask = 0;                 // 4 bits per sample: which corners land in [r0, r1)
@@ -263,7 +283,9 @@ msda_bwd_gv_direct_kernel(const int64_t* __restrict__ shapes, const int64_t* __r
         }
       mask |= mj << (4 * j);
     }
-    __syncthreads();
+    if (pass == 0) VNX_GVD_STAMP(3);
+    if (VNX_GVD_FULL_BARRIERS) __syncthreads(); else lds_barrier();      // (the rows stay in flight)
+    if (pass == 0) VNX_GVD_STAMP(4);
 
     // ---- row counts -> segment offsets: DPP wave scan + one LDS allocation per wave and 512 rows ------------------------------
     for (int rb = 0; rb < rows; rb += kThreads) {      // uniform
@@ -277,7 +299,8 @@ msda_bwd_gv_direct_kernel(const int64_t* __restrict__ shapes, const int64_t* __r
       base = uint32_t(__builtin_amdgcn_readfirstlane(int(base)));
       if (r < rows) { offs[r] = base + incl - my_cnt; cnt_next[r] = 0; }
     }
-    __syncthreads();
+    if (VNX_GVD_FULL_BARRIERS) __syncthreads(); else lds_barrier();
+    if (pass == 0) VNX_GVD_STAMP(5);
 
     // ---- scatter {query slot, weight} into the rows' segments --------------------------------------------------------------
 #pragma unroll
@@ -306,6 +329,7 @@ msda_bwd_gv_direct_kernel(const int64_t* __restrict__ shapes, const int64_t* __r
         if (((i * kThreads + tg) >> 3) < kGvdQc) grows[i * kThreads + tg] = pg[i];
     }
     __syncthreads();
+    if (pass == 0) VNX_GVD_STAMP(6);
     if (tid == 0) alloc[0] = 0;
 
     // ---- 8-lane groups walk the rows: slot = row * groups-per-row + part; a row's segment summed in registers, stored at once ----
@@ -315,92 +339,64 @@ msda_bwd_gv_direct_kernel(const int64_t* __restrict__ shapes, const int64_t* __r
       const uint32_t step = gmask + 1u;
       const float4_t* g4 = grows + ch4;
       const int n_slots = rows << gshift;
-      constexpr int KS = VNX_GVD_WALK;
-      for (int sb = 0; sb < n_slots; sb += KS * kGroups) {      // uniform
-        int slot[KS], row[KS];
-        uint32_t n[KS], o[KS], i[KS];
-        float4_t acc[KS];
-#pragma unroll
-        for (int k = 0; k < KS; ++k) {
-          slot[k] = sb + k * kGroups + grp;
-          row[k] = slot[k] >> gshift;
-          n[k] = 0; o[k] = 0;
-          if (slot[k] < n_slots) { n[k] = VNX_GVD_ABL == 3 ? 0u : cnt[row[k]]; o[k] = offs[row[k]]; }
-          i[k] = uint32_t(slot[k]) & gmask;        // part: the entries of the row this group takes are part, part + step, ...
-          acc[k] = float4_t{0.f, 0.f, 0.f, 0.f};
+      for (int sb = 0; sb < n_slots; sb += kGroups) {      // uniform
+        const int slot = sb + grp;
+        const int row = slot >> gshift;
+        const uint32_t part = uint32_t(slot) & gmask;      // the entries of the row this group takes: part, part + step, ...
+        uint32_t n = 0, o = 0;
+        if (slot < n_slots) { n = VNX_GVD_ABL == 3 ? 0u : cnt[row]; o = offs[row]; }
+        float4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+        uint32_t i = part;
+        for (; i + step < n; i += 2 * step) {        // two taps in flight
+          const uint32_t s0 = l_slot[o + i], s1 = l_slot[o + i + step];
+          const float w0 = l_wt[o + i], w1 = l_wt[o + i + step];
+          const float4_t x0 = g4[s0 * 8], x1 = g4[s1 * 8];
+          a0 += w0 * x0;
+          a1 += w1 * x1;
         }
-        if constexpr (KS == 1) {
-          float4_t a1 = {0.f, 0.f, 0.f, 0.f};
-          uint32_t j = i[0];
-          for (; j + step < n[0]; j += 2 * step) {        // two taps in flight
-            const uint32_t s0 = l_slot[o[0] + j], s1 = l_slot[o[0] + j + step];
-            const float w0 = l_wt[o[0] + j], w1 = l_wt[o[0] + j + step];
-            const float4_t x0 = g4[s0 * 8], x1 = g4[s1 * 8];
-            acc[0] += w0 * x0;
-            a1 += w1 * x1;
-          }
-          if (j < n[0]) a1 += l_wt[o[0] + j] * g4[uint32_t(l_slot[o[0] + j]) * 8];
-          acc[0] += a1;
-        } else {
-          // KS rows side by side, one tap of each per step (fine levels have one or two taps per row: the rows, not the taps
-          // of a row, are what can be in flight together)
-          bool more = true;
-          while (more) {
-            more = false;
+        if (i < n) a1 += l_wt[o + i] * g4[uint32_t(l_slot[o + i]) * 8];
+        a0 += a1;
+        // (two ROWS side by side, one tap of each per step -- fine levels have one or two taps per row -- measured slower:
+        //  grad_value kernel 16.2 vs 13.5 us at the T = 5 decoder call; the merged loop runs to the longer of the two rows)
+        // a row spread over 1 << gshift groups (adjacent groups of one wave): their partial sums meet in the first
 #pragma unroll
-            for (int k = 0; k < KS; ++k)
-              if (i[k] < n[k]) {
-                acc[k] += l_wt[o[k] + i[k]] * g4[uint32_t(l_slot[o[k] + i[k]]) * 8];
-                i[k] += step;
-                more = true;
-              }
+        for (int sh = 0; sh < 3; ++sh)
+          if (sh < gshift) {
+            a0.x += __shfl_xor(a0.x, 8 << sh, 64); a0.y += __shfl_xor(a0.y, 8 << sh, 64);
+            a0.z += __shfl_xor(a0.z, 8 << sh, 64); a0.w += __shfl_xor(a0.w, 8 << sh, 64);
           }
-        }
-#pragma unroll
-        for (int k = 0; k < KS; ++k) {
-          float4_t a0 = acc[k];
-          // a row spread over 1 << gshift groups (adjacent groups of one wave): their partial sums meet in the first
-#pragma unroll
-          for (int sh = 0; sh < 3; ++sh)
-            if (sh < gshift) {
-              a0.x += __shfl_xor(a0.x, 8 << sh, 64); a0.y += __shfl_xor(a0.y, 8 << sh, 64);
-              a0.z += __shfl_xor(a0.z, 8 << sh, 64); a0.w += __shfl_xor(a0.w, 8 << sh, 64);
-            }
-          if (VNX_GVD_ABL == 4) continue;
-          if ((uint32_t(slot[k]) & gmask) == 0u && slot[k] < n_slots) {
-            TV* p = out + __umul24(uint32_t(row[k]), q_stride) + ch4 * 4;
-            // several passes: the later ones add onto what the first stored (this lane wrote it: program order).  Non-temporal
-            // stores in every case: written with plain stores the 26 MB of rows of a T = 5 call stay dirty in L2 until the
-            // end-of-kernel write-back, which then takes 10 us (kernel 18.0 us; 7.8 without any store; 14.8 with `nt`) -- and a
-            // branch that stores the same value plain on one side and `nt` on the other is merged by the compiler into the
-            // plain form.
-            if (pass > 0) a0 += load4<TV>(p);
-            if constexpr (sizeof(TV) == 4 && VNX_GVD_STORE_POLICY != 0) {
-              float* fp = reinterpret_cast<float*>(p);
-#if VNX_GVD_STORE_POLICY == 1
-              *reinterpret_cast<float4_t*>(fp) = a0;
-#elif VNX_GVD_STORE_POLICY == 2
-              asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(fp), "v"(a0) : "memory");
-#elif VNX_GVD_STORE_POLICY == 3
-              asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(fp), "v"(a0) : "memory");
-#elif VNX_GVD_STORE_POLICY == 4
-              asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(fp), "v"(a0) : "memory");
-#elif VNX_GVD_STORE_POLICY == 5
-              asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(fp), "v"(a0) : "memory");
-#endif
-            } else {
-              store4<TV>(p, a0);
-            }
-          }
+        if (VNX_GVD_ABL == 4) continue;
+        if (part == 0u && slot < n_slots) {
+          TV* p = out + __umul24(uint32_t(row), q_stride) + ch4 * 4;
+          // several passes: the later ones add onto what the first stored (this lane wrote it: program order).  Non-temporal
+          // stores in every case: written with plain stores the 26 MB of rows of a T = 5 call stay dirty in L2 until the
+          // end-of-kernel write-back, which then takes 10 us (kernel 18.0 us; 7.8 without any store; 14.8 with `nt`) -- and a
+          // branch that stores the same value plain on one side and `nt` on the other is merged by the compiler into the
+          // plain form.  Other cache policies of the store (sc1 nt, sc0 sc1 nt: 13.3-13.4 us against 13.5; sc1, sc0 sc1
+          // without nt: 14.4-14.5): within noise or worse, `nt` stays.
+          if (pass > 0) a0 += load4<TV>(p);
+          store4<TV>(p, a0);
         }
       }
     }
     if (pass + 1 < n_pass) __syncthreads();       // the staged rows and the lists are rewritten next
   }
+  VNX_GVD_STAMP(7);
   stamp_end(stamps);
 }
 
 }  // namespace rec
+
+#ifdef VNX_DEV_VARIANTS      // include/vnext_hip_dev.h: the phase stamps a -DVNX_GVD_STAMPS build leaves (zeros otherwise)
+extern "C" int vnx_debug_read_gvd_stamps(unsigned long long* host, int n) {
+#ifdef VNX_GVD_STAMPS
+  return int(hipMemcpyFromSymbol(host, HIP_SYMBOL(rec::g_gvd_stamps), sizeof(unsigned long long) * size_t(n)));
+#else
+  for (int i = 0; i < n; ++i) host[i] = 0;
+  return 0;
+#endif
+}
+#endif
 
 // Workgroups per (batch, head): the host knows S, not the level shapes.  A level of n pixels has
 // max(ceil(n / ROWS), min(ut, n)) units (gvd_level_split): ceil(n / ROWS) + 1 bounds it for ut <= 2, and
