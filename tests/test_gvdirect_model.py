@@ -85,11 +85,11 @@ def model_grad_value(value_shape, shapes, lsi, loc, attn, grad_out, rng):
                         for row, rk, slot, wt in ranked:
                             assert lst[offs[row] + rk] is None
                             lst[offs[row] + rk] = (slot, wt)
-                        # the walk: slot = row * groups-per-row + part, 64 slots per round; parts meet, part 0 stores
+                        # the walk: slot = row * groups-per-row + part, 128 slots per round (4-lane groups); parts meet, part 0 stores
                         n_slots = rows << gshift
-                        for sb in range(0, n_slots, 64):
+                        for sb in range(0, n_slots, 128):
                             partial = {}
-                            for grp in range(64):
+                            for grp in range(128):
                                 slot = sb + grp
                                 if slot >= n_slots:
                                     continue
@@ -102,7 +102,7 @@ def model_grad_value(value_shape, shapes, lsi, loc, attn, grad_out, rng):
                                     i += step
                                 partial.setdefault(row, []).append(acc)
                             for row, parts in partial.items():
-                                assert len(parts) == step      # the groups of a row are adjacent: one round, one wave
+                                assert len(parts) == step      # the groups of a row are adjacent: one round, one wave (16 groups)
                                 stored[row] = sum(parts) + (stored[row] if pass_ > 0 else 0)
                     gv[b, lsi[l] + r0: lsi[l] + r1, m] = stored
     assert not np.isnan(gv).any(), "a row without an owner"

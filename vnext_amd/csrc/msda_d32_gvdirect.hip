@@ -332,50 +332,75 @@ msda_bwd_gv_direct_kernel(const int64_t* __restrict__ shapes, const int64_t* __r
     if (pass == 0) VNX_GVD_STAMP(6);
     if (tid == 0) alloc[0] = 0;
 
-    // ---- 8-lane groups walk the rows: slot = row * groups-per-row + part; a row's segment summed in registers, stored at once ----
+    // ---- lane groups walk the rows: slot = row * groups-per-row + part; a row's segment summed in registers, stored at once.
+    //      A group is kLpr = 4 lanes, each with 32 bytes of the row (bytes [16 j, 16 j + 16) and [64 + 16 j, ...): every load and
+    //      store instruction still moves whole 64-byte half rows): the walk is bound by the vector instructions of its PER-ROW
+    //      work (a fine level has 1.25 taps per row), which all lanes of a group execute alike -- with 8 lanes x 16 bytes the
+    //      kernel issued 999 vector instructions per wave, 450 of them here (profiles/r05_backward_pmc.csv); 4 lanes halve the
+    //      row iterations of a wave: grad_value kernel 13.8 -> 13.4 us at the T = 5 decoder call, 25.4 -> 23.8 at B = 10,
+    //      33.7 -> 32.5 at 720p (walk + store 4.5 -> 3.4 us per workgroup by the phase stamps). ----
     {
+      constexpr int kLpr = 4;                            // lanes per row, two 16-B pieces each
+      constexpr int kPieces = 8 / kLpr;
+      constexpr int kGrp = kThreads / kLpr;              // groups per workgroup = slots per round
       const int ta = opaque(tid);
-      const int grp = ta >> 3, ch4 = ta & 7;
+      const int grp = ta / kLpr, cl = ta % kLpr;
       const uint32_t step = gmask + 1u;
-      const float4_t* g4 = grows + ch4;
+      const float4_t* g4 = grows + cl;
       const int n_slots = rows << gshift;
-      for (int sb = 0; sb < n_slots; sb += kGroups) {      // uniform
+      for (int sb = 0; sb < n_slots; sb += kGrp) {      // uniform
         const int slot = sb + grp;
         const int row = slot >> gshift;
         const uint32_t part = uint32_t(slot) & gmask;      // the entries of the row this group takes: part, part + step, ...
         uint32_t n = 0, o = 0;
         if (slot < n_slots) { n = VNX_GVD_ABL == 3 ? 0u : cnt[row]; o = offs[row]; }
-        float4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+        float4_t a0[kPieces], a1[kPieces];
+#pragma unroll
+        for (int h = 0; h < kPieces; ++h) a0[h] = a1[h] = float4_t{0.f, 0.f, 0.f, 0.f};
         uint32_t i = part;
         for (; i + step < n; i += 2 * step) {        // two taps in flight
           const uint32_t s0 = l_slot[o + i], s1 = l_slot[o + i + step];
           const float w0 = l_wt[o + i], w1 = l_wt[o + i + step];
-          const float4_t x0 = g4[s0 * 8], x1 = g4[s1 * 8];
-          a0 += w0 * x0;
-          a1 += w1 * x1;
+#pragma unroll
+          for (int h = 0; h < kPieces; ++h) {
+            a0[h] += w0 * g4[s0 * 8 + h * kLpr];
+            a1[h] += w1 * g4[s1 * 8 + h * kLpr];
+          }
         }
-        if (i < n) a1 += l_wt[o + i] * g4[uint32_t(l_slot[o + i]) * 8];
-        a0 += a1;
-        // (two ROWS side by side, one tap of each per step -- fine levels have one or two taps per row -- measured slower:
-        //  grad_value kernel 16.2 vs 13.5 us at the T = 5 decoder call; the merged loop runs to the longer of the two rows)
+        if (i < n) {
+          const uint32_t s0 = l_slot[o + i];
+          const float w0 = l_wt[o + i];
+#pragma unroll
+          for (int h = 0; h < kPieces; ++h) a1[h] += w0 * g4[s0 * 8 + h * kLpr];
+        }
+#pragma unroll
+        for (int h = 0; h < kPieces; ++h) a0[h] += a1[h];
+        // (two ROWS side by side, one tap of each per step -- measured slower: grad_value kernel 16.2 vs 13.5 us at the T = 5
+        //  decoder call; the merged loop runs to the longer of the two rows)
         // a row spread over 1 << gshift groups (adjacent groups of one wave): their partial sums meet in the first
 #pragma unroll
         for (int sh = 0; sh < 3; ++sh)
           if (sh < gshift) {
-            a0.x += __shfl_xor(a0.x, 8 << sh, 64); a0.y += __shfl_xor(a0.y, 8 << sh, 64);
-            a0.z += __shfl_xor(a0.z, 8 << sh, 64); a0.w += __shfl_xor(a0.w, 8 << sh, 64);
+#pragma unroll
+            for (int h = 0; h < kPieces; ++h) {
+              a0[h].x += __shfl_xor(a0[h].x, kLpr << sh, 64); a0[h].y += __shfl_xor(a0[h].y, kLpr << sh, 64);
+              a0[h].z += __shfl_xor(a0[h].z, kLpr << sh, 64); a0[h].w += __shfl_xor(a0[h].w, kLpr << sh, 64);
+            }
           }
         if (VNX_GVD_ABL == 4) continue;
         if (part == 0u && slot < n_slots) {
-          TV* p = out + __umul24(uint32_t(row), q_stride) + ch4 * 4;
+          TV* p = out + __umul24(uint32_t(row), q_stride) + cl * 4;
           // several passes: the later ones add onto what the first stored (this lane wrote it: program order).  Non-temporal
           // stores in every case: written with plain stores the 26 MB of rows of a T = 5 call stay dirty in L2 until the
           // end-of-kernel write-back, which then takes 10 us (kernel 18.0 us; 7.8 without any store; 14.8 with `nt`) -- and a
           // branch that stores the same value plain on one side and `nt` on the other is merged by the compiler into the
           // plain form.  Other cache policies of the store (sc1 nt, sc0 sc1 nt: 13.3-13.4 us against 13.5; sc1, sc0 sc1
           // without nt: 14.4-14.5): within noise or worse, `nt` stays.
-          if (pass > 0) a0 += load4<TV>(p);
-          store4<TV>(p, a0);
+#pragma unroll
+          for (int h = 0; h < kPieces; ++h) {
+            if (pass > 0) a0[h] += load4<TV>(p + h * kLpr * 4);
+            store4<TV>(p + h * kLpr * 4, a0[h]);
+          }
         }
       }
     }
