@@ -71,15 +71,6 @@ constexpr size_t kGvdLdsBytes = size_t(kGvdQc) * 128 + size_t(kGvdCap) * 6 + siz
 static_assert(kGvdLdsBytes * VNX_GVD_UNITS_PER_CU <= 160 * 1024, "the units that share a CU must fit its LDS");
 static_assert(kGvdCap < 65536 && kGvdQc < 65536, "tap ranks and query slots fit 16 bits");
 
-// A barrier that orders LDS only.  __syncthreads() is a workgroup-scope fence over ALL memory: on gfx9 (one counter for
-// vector loads and stores) it waits for every outstanding global load -- here the 38 KB of grad_out rows a workgroup has in
-// flight while it decodes and sorts.  The fences below name the local address space, so only lgkmcnt is waited for.
-__device__ __forceinline__ void lds_barrier() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
-
 template <typename TV, typename TL, int P_T>
 __global__ void __launch_bounds__(kThreads, VNX_GVD_UNITS_PER_CU * kWaves / 4)
 msda_bwd_gv_direct_kernel(const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,

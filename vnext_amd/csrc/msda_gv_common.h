@@ -119,6 +119,15 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
   return uint32_t(x);
 }
 
+// A barrier that orders LDS only.  __syncthreads() is a workgroup-scope fence over ALL memory: on gfx9 (one counter for
+// vector loads and stores) it waits for every outstanding global load -- here the 38 KB of grad_out rows a workgroup has in
+// flight while it decodes and sorts.  The fences below name the local address space, so only lgkmcnt is waited for.
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 constexpr int kWaves = 8;                   // 512 threads, one sample per thread per chunk
 constexpr int kThreads = 64 * kWaves;
 constexpr int kGroups = kThreads / 8;       // 8-lane groups
