@@ -1055,7 +1055,7 @@ def main():
             n_regions = DL.vnx_debug_stamp_regions(kinds, offs, nblk, max_regions)
             DL.vnx_debug_arm_stamps(None, 0)
         khz = L.vnx_debug_wall_clock_khz()
-        span = {1: [], 2: [], 3: [], "warm": []}
+        span = {1: [], 2: [], 3: [], 4: [], "warm": []}
         if khz > 0 and 0 < n_regions <= max_regions:
             for _ in range(10):
                 stamps.zero_()
@@ -1088,9 +1088,9 @@ def main():
             line["roofline"]["warm_us_per_launch"] = us_fwd_warm
             line["roofline"]["warm_frac"] = bytes_fwd / us_fwd_warm / 1e3 / HBM_PEAK_GBS
             line["roofline"]["warm_note"] = "one input set replayed: value and locations stay in L2 / Infinity Cache; not an HBM fraction"
-        line["roofline_bwd"] = roof(bytes_bwd, us_bwd, None,
-                                    "msda_bwd_gv_direct_kernel (grad_value from the op's inputs) + msda_bwd_d32_kernel "
-                                    "(grad_loc, grad_attn), one ms_deform_attn_backward call")
+        line["roofline_bwd"] = roof(bytes_bwd, us_bwd, k_us[4],
+                                    "msda_bwd_pair_kernel: one launch per ms_deform_attn_backward call, its workgroups either "
+                                    "grad_value units (from the op's inputs) or eight grad_loc / grad_attn waves")
         if k_us[2]:
             line["roofline_bwd"]["us_grad_loc_kernel_span"] = k_us[2]
         if k_us[3]:
@@ -1115,7 +1115,8 @@ def main():
         pmc = latest_profile("bench_pmc_hbm.json")
         if pmc is not None and (B, Lq, res, a.dist) == (5, 300, "360p", "U"):
             for key, names in (("roofline", ["msda_fwd_d32_kernel"]),
-                               ("roofline_bwd", ["msda_bwd_d32_kernel", "msda_bwd_gv_rec_kernel", "msda_bwd_gv_sel_kernel", "msda_bwd_gv_direct_kernel"])):
+                               ("roofline_bwd", ["msda_bwd_pair_kernel", "msda_bwd_d32_kernel", "msda_bwd_gv_rec_kernel", "msda_bwd_gv_sel_kernel",
+                                                 "msda_bwd_gv_direct_kernel"])):
                 vals = [v.get("hbm_bytes_per_launch_corrected") for k, v in pmc["data"].items() if any(n in k for n in names)]
                 if vals and all(v is not None for v in vals):
                     line[key]["traffic"] = sum(vals)

@@ -31,7 +31,7 @@ int vnx_get_kernel_variant(void);
  * MSDA kernel takes a region of 2 x gridDim 64-bit words and each workgroup leaves {its start, its last wave's end} there in
  * constant-rate wall-clock ticks (vnx_debug_wall_clock_khz, vnext_hip_debug.h).  buf: n_words zero-filled 64-bit words;
  * nullptr disarms.  vnx_debug_stamp_regions -> number of regions handed out since arming; per region the kernel kind
- * (1 forward, 2 grad_loc / grad_attn, 3 grad_value), word offset, workgroups.
+ * (1 forward, 2 grad_loc / grad_attn, 3 grad_value, 4 the paired backward kernel), word offset, workgroups.
  */
 void vnx_debug_arm_stamps(void* buf, long long n_words);
 int vnx_debug_stamp_regions(int* kinds, long long* offsets, long long* blocks, int n);

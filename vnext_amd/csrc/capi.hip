@@ -77,6 +77,10 @@ int msda_backward_gvrec_d32(int vdt, const int64_t*, const int64_t*, const void*
 int msda_split_levels_convert(int vdt, const int64_t*, const int64_t*, const float* image, void* grad_value, MsdaDims, bool tiles,
                               hipStream_t);
 bool msda_d32_gvdirect_supported(int vdt, int ldt, const MsdaDims& d);
+bool msda_backward_pair_supported(int vdt, int ldt, const MsdaDims& d);
+int msda_backward_pair_d32(int vdt, const void* value, const int64_t*, const int64_t*, const void* loc, const void* attn,
+                           const void* grad_out, void* grad_value, void* grad_loc, void* grad_attn, MsdaDims, int order,
+                           hipStream_t);
 int msda_backward_gvdirect_d32(int vdt, int ldt, const int64_t*, const int64_t*, const void* loc, const void* attn,
                                const void* grad_out, void* grad_value, MsdaDims, bool compact, hipStream_t);
 
@@ -311,6 +315,9 @@ static bool use_tiles(int vdt, int ldt, const MsdaDims& d, int variant) {
 // Calls below 1 024 queries (the decoders'): grad_value by the self-decoding kernel (msda_d32_gvdirect.hip) -- no records, no
 // tags, no workspace, and no dependence on the grad_loc kernel, so the two run concurrently (side_lane below).  The
 // development build keeps the record-fed kernels reachable for A/B runs (variant 430 and the variants that name one).
+#ifndef VNX_PAIR_ORDER
+#define VNX_PAIR_ORDER 1      // role order of the paired backward kernel's workgroup groups (msda_d32.hip): the grad_loc groups first
+#endif
 static bool use_direct(int vdt, int ldt, const MsdaDims& d, int variant) {
   if (variant == 430 || variant == 408 || variant == 412 || variant == 420 || variant == 425) return false;
   if (use_tiles(vdt, ldt, d, variant)) return false;
@@ -418,6 +425,26 @@ int vnx_msda_backward(int value_dtype, int loc_dtype, const void* value,
       // not honoured on gfx9 parts (hip_ext.h says so; measured 23.70 vs 23.93 us eager, no overlap in the kernel trace).)
       const bool only_gl = variant >= 100 && variant < 200;
       const bool only_gv = variant == 442;
+      // Both halves as ONE launch where the paired kernel is built for the call (msda_d32.hip: msda_bwd_pair_kernel; fp32,
+      // L*P == 16, the one-wave grad_loc configuration -- the decoders' calls): the grad_value units first, the grad_loc work in the
+      // remaining workgroups, sharing the GPU without a second queue.  Development build: 444 = the two launches instead,
+      // 445 / 446 / 447 = the paired kernel with the grad_value groups first / the grad_loc groups first / alternating.
+      if (!only_gl && !only_gv && !(flags & VNX_MSDA_FORK) && variant != 441 && variant != 444 &&
+          msda_backward_pair_supported(value_dtype, loc_dtype, d) && (!sixteen || (flags & VNX_MSDA_LEVELS_PACKED))) {
+        const int order = variant == 445 ? 0 : variant == 446 ? 1 : variant == 447 ? 2 : VNX_PAIR_ORDER;
+        st = msda_backward_pair_d32(value_dtype, value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output, grad_value,
+                                    grad_sampling_loc, grad_attn_weight, d, order, stream);
+        if (st != VNX_OK) return st;
+        if (!(flags & VNX_MSDA_LEVELS_PACKED)) {      // the general path, every kernel of which does nothing when the levels ARE packed
+          st = zero_if_not_packed(spatial_shapes, level_start_index, num_levels, spatial_size, grad_value,
+                                  n_value * size_t(elem_size(value_dtype)), stream);
+          if (st != VNX_OK) return st;
+          st = msda_backward_generic(value_dtype, loc_dtype, value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
+                                     grad_output, grad_value, grad_sampling_loc, grad_attn_weight, d, /*only_if_not_packed=*/1, stream);
+          if (st != VNX_OK) return st;
+        }
+        return VNX_OK;
+      }
       SideLane* lane = (((flags & VNX_MSDA_FORK) || variant == 441) && !only_gl && !only_gv) ? side_lane() : nullptr;
       if (lane) {
         if (hipEventRecord(lane->fork, stream) != hipSuccess || hipStreamWaitEvent(lane->side, lane->fork, 0) != hipSuccess) {

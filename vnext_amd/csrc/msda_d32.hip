@@ -23,6 +23,7 @@
 //    are QPW queries x (8/QPW) sample groups x 8 channel lanes; sample groups
 //    are summed with cross-lane exchanges at the end.
 #include "vnx_common.h"
+#include "msda_d32_gvdirect_body.h"
 
 namespace vnx {
 
@@ -818,15 +819,19 @@ __device__ __forceinline__ void store_loc(TL* p, float v) { *p = from_acc<TL>(v)
 //      cuh:376-394, become 9 DPP adds).
 // grad_value accumulates in fp32 (`gv`: grad_value itself for fp32, the workspace
 // image for 16-bit values), laid out [B,S,M,32] fp32.
+// The kernel's body as a device function of the workgroup's index `vblock`, the wave's index inside it `wave` and the
+// workgroup's LDS: msda_bwd_d32_kernel below is this and nothing else; msda_bwd_pair_kernel runs the one-wave-per-workgroup
+// configuration in every WAVE of its grad_loc workgroups (vblock = that wave's own workgroup index, wave = 0, its own LDS slice).
 template <typename TV, typename TL, int QPW, int WPB, int LP_T, bool ATOMICS, bool FUSED = false, int LPR = 8>
-__global__ void VNX_K1_BOUNDS(64 * WPB)
-msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ shapes,
-                    const int64_t* __restrict__ lsi, const TL* __restrict__ loc,
-                    const TL* __restrict__ attn, const TV* __restrict__ grad_out,
-                    float* __restrict__ gv, TL* __restrict__ grad_loc, TL* __restrict__ grad_attn,
-                    MsdaDims d, int tiles_per_batch, uint4_t* __restrict__ sample_records,
-                    uint32_t* __restrict__ sample_units, uint32_t* __restrict__ tile_summary, int units_min,
-                    unsigned long long* stamps, FusedArgs fa) {
+__device__ __forceinline__ void
+msda_bwd_d32_body(const TV* __restrict__ value, const int64_t* __restrict__ shapes,
+                  const int64_t* __restrict__ lsi, const TL* __restrict__ loc,
+                  const TL* __restrict__ attn, const TV* __restrict__ grad_out,
+                  float* __restrict__ gv, TL* __restrict__ grad_loc, TL* __restrict__ grad_attn,
+                  const MsdaDims& d, int tiles_per_batch, uint4_t* __restrict__ sample_records,
+                  uint32_t* __restrict__ sample_units, uint32_t* __restrict__ tile_summary, int units_min,
+                  unsigned long long* stamps, const FusedArgs& fa, const uint32_t vblock, const int wave,
+                  unsigned char* __restrict__ smem) {
   static_assert(!FUSED || (LP_T == 16 && !ATOMICS), "the fused prologue is built for L*P == 16, record-fed grad_value");
   static_assert(LPR == 8 || (LPR == 4 && LP_T == 16 && !ATOMICS), "4 lanes per row: L*P == 16, owner-computes grad_value");
   stamp_begin(stamps);
@@ -834,15 +839,13 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
   constexpr int PG = (64 / LPR) / QPW;
   constexpr int kRowBytes = D * int(sizeof(TV));
   constexpr int kLaneBytes = kRowBytes / LPR;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int LP = LP_T > 0 ? LP_T : d.L * d.P;
   const int p_shift = __builtin_ctz(uint32_t(d.P) | 0x10000u);      // log2(P) when P is a power of two (L * P == 16)
   const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int tile = blockIdx.x / d.M;
+  const int tile = vblock / d.M;
   const int b = tile / tiles_per_batch;
-  const int m = (blockIdx.x % d.M + b) % d.M;      // head <-> XCD map rotates with the batch element (see the forward)
+  const int m = (vblock % d.M + b) % d.M;      // head <-> XCD map rotates with the batch element (see the forward)
   const int q0 = (tile - b * tiles_per_batch) * (QPW * WPB) + wave * QPW;
 
   // per-wave LDS: tap offsets, geometry, results
@@ -1287,6 +1290,22 @@ msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
   stamp_end(stamps);
 }
 
+template <typename TV, typename TL, int QPW, int WPB, int LP_T, bool ATOMICS, bool FUSED = false, int LPR = 8>
+__global__ void VNX_K1_BOUNDS(64 * WPB)
+msda_bwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ shapes,
+                    const int64_t* __restrict__ lsi, const TL* __restrict__ loc,
+                    const TL* __restrict__ attn, const TV* __restrict__ grad_out,
+                    float* __restrict__ gv, TL* __restrict__ grad_loc, TL* __restrict__ grad_attn,
+                    MsdaDims d, int tiles_per_batch, uint4_t* __restrict__ sample_records,
+                    uint32_t* __restrict__ sample_units, uint32_t* __restrict__ tile_summary, int units_min,
+                    unsigned long long* stamps, FusedArgs fa) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  msda_bwd_d32_body<TV, TL, QPW, WPB, LP_T, ATOMICS, FUSED, LPR>(value, shapes, lsi, loc, attn, grad_out, gv, grad_loc, grad_attn, d,
+                                                                 tiles_per_batch, sample_records, sample_units, tile_summary,
+                                                                 units_min, stamps, fa, blockIdx.x,
+                                                                 __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)), smem);
+}
+
 template <typename TV, typename TL, int QPW, int WPB>
 static int launch_bwd_cfg(const void* value, const int64_t* shapes, const int64_t* lsi,
                           const void* loc, const void* attn, const void* grad_out, void* gv,
@@ -1346,6 +1365,113 @@ static int launch_bwd(const void* value, const int64_t* shapes, const int64_t* l
 #undef VNX_CASE
   set_error("msda_backward: no kernel for qpw=%d wpb=%d", c.qpw, c.wpb);
   return VNX_ERR_UNSUPPORTED;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The backward of a call below 1 024 queries as ONE launch (round 5).  Its two halves -- grad_value by the self-decoding
+// kernel (msda_d32_gvdirect_body.h), grad_loc / grad_attn by the per-query gather kernel above -- read the same inputs and
+// write disjoint outputs, so they can share the GPU; but two kernels on one stream run strictly one after the other, a fork
+// onto a second stream costs more than it gains on this runtime and hipExtAnyOrderLaunch is not honoured on gfx9 (DESIGN.md
+// section 3.3e).  Here some workgroups of the grid are grad_value units and the others run the grad_loc kernel's one-wave
+// configuration in each of their eight waves: wave w of grad_loc workgroup (g, x) takes the virtual workgroup (8 g + w) M + x
+// -- the same head class x for all eight, so the head <-> XCD map of both kernels is kept.  Registers and LDS are the
+// maximum of the two roles: two workgroups per CU either way.
+constexpr int kPairWaves = 8;
+template <int QPW> constexpr int kPairGlWaveLds = 3 * QPW * 17 * 16 + 128;      // the one-wave configuration's LDS (L*P == 16)
+
+template <typename TV, typename TL, int QPW, int LPR>
+__global__ void __launch_bounds__(64 * kPairWaves, 2 * kPairWaves / 4)
+msda_bwd_pair_kernel(const TV* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
+                     const TL* __restrict__ loc, const TL* __restrict__ attn, const TV* __restrict__ grad_out,
+                     TV* __restrict__ grad_value, TL* __restrict__ grad_loc, TL* __restrict__ grad_attn, MsdaDims d,
+                     int tiles_per_batch, int ut, uint32_t gv_groups, uint32_t gl_groups, uint32_t gl_blocks, int order,
+                     unsigned long long* stamps) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  stamp_begin(stamps);
+  // Roles by GROUPS of M consecutive workgroups (one per head class / XCD).  order 1 (what the library uses): all grad_loc
+  // groups first -- their waves are bound by the latency of two cold gather rounds, so they start at once and the grad_value
+  // units fill the CUs as they drain; 0: the grad_value groups first; 2: alternating while both last.  Measured (kbench, cold,
+  // backward alone / fwd+bwd step; two launches 22.7 / 28.8 us): order 1 21.4 / 26.8, order 0 24.1 / 26.6, order 2 24.8 / 31.4
+  // at the T = 5 decoder call; B = 10 39.5 / 49.7 -> 36.2 / 47.5 (0: 40.5 / 46.9, 2: 45.4 / 55.7); 720p 41.5 -> 35.7 (0: 40.7, 2: 38.2).
+  const uint32_t M = uint32_t(d.M), G = blockIdx.x / M, x = blockIdx.x - G * M;
+  bool is_gv;
+  uint32_t g;      // the group's index within its role
+  if (order == 0) { is_gv = G < gv_groups; g = is_gv ? G : G - gv_groups; }
+  else if (order == 1) { is_gv = G >= gl_groups; g = is_gv ? G - gl_groups : G; }
+  else {
+    const uint32_t n_min = gv_groups < gl_groups ? gv_groups : gl_groups;
+    if (G < 2 * n_min) { is_gv = (G & 1u) == 0u; g = G >> 1; }
+    else { is_gv = gv_groups > gl_groups; g = G - n_min; }
+  }
+  if (is_gv) {      // uniform over the workgroup
+    rec::msda_bwd_gv_direct_body<TV, TL, 4>(shapes, lsi, loc, attn, grad_out, grad_value, d, ut, 0, nullptr, g * M + x, smem);
+    stamp_end(stamps);
+    return;
+  }
+  const uint32_t w = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)));
+  const uint32_t vb = (g * kPairWaves + w) * M + x;
+  if (vb < gl_blocks)      // uniform over the wave; the body has no workgroup barrier in this configuration
+    msda_bwd_d32_body<TV, TL, QPW, 1, 16, false, false, LPR>(value, shapes, lsi, loc, attn, grad_out, nullptr, grad_loc, grad_attn, d,
+                                                            tiles_per_batch, nullptr, nullptr, nullptr, 0, nullptr, FusedArgs{}, vb, 0,
+                                                            smem + w * kPairGlWaveLds<QPW>);
+  stamp_end(stamps);
+}
+
+int msda_gvdirect_units_bound(const MsdaDims& d);
+
+// -> true when the call is one the paired kernel is built for (what the decoders of both models present: fp32 locations, fp32
+// or 16-bit values, L*P == 16 with 4 points, the one-wave configuration of the grad_loc kernel)
+bool msda_backward_pair_supported(int vdt, int ldt, const MsdaDims& d) {
+  if (ldt != VNX_F32 || (vdt != VNX_F32 && vdt != VNX_BF16 && vdt != VNX_F16)) return false;
+  if (d.P != 4 || d.L * d.P != 16 || d.Lq >= 1024) return false;
+  const FwdCfg c = pick_fwd_cfg(d, 0);
+  return c.qpw == 4 && c.wpb == 1;
+}
+
+template <typename TV>
+static int launch_pair(const void* value, const int64_t* shapes, const int64_t* lsi, const void* loc, const void* attn,
+                       const void* grad_out, void* grad_value, void* grad_loc, void* grad_attn, const MsdaDims& d, int order,
+                       hipStream_t stream) {
+  constexpr int QPW = 4;
+  constexpr int kLpr = sizeof(TV) == 2 ? 4 : 8;      // 16-bit rows as 4 lanes x 16 B (as the stand-alone launcher)
+  const int tiles_per_batch = (d.Lq + QPW - 1) / QPW;
+  const int64_t gl_blocks = int64_t(d.B) * tiles_per_batch * d.M;
+  const int ut = gvd_units_min(d.S, d.L, d.B * d.M);
+  const int64_t gv_blocks = ((int64_t(d.B) * msda_gvdirect_units_bound(d) + 1) & ~int64_t(1)) * d.M;
+  const int64_t gl_groups = (gl_blocks + int64_t(kPairWaves) * d.M - 1) / (int64_t(kPairWaves) * d.M);      // of M workgroups each
+  const int64_t blocks = gv_blocks + gl_groups * d.M;
+  if (blocks >= (int64_t(1) << 31)) {
+    set_error("msda_backward: %lld workgroups exceed the grid limit", (long long)blocks);
+    return VNX_ERR_UNSUPPORTED;
+  }
+  constexpr size_t kLds = rec::kGvdLdsBytes > size_t(kPairWaves) * kPairGlWaveLds<QPW> ? rec::kGvdLdsBytes
+                                                                                           : size_t(kPairWaves) * kPairGlWaveLds<QPW>;
+  static thread_local int raised_on = -1;      // more than 64 KiB of LDS per workgroup: the limit is raised once per device
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (kLds > 64 * 1024 && raised_on != dev) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&msda_bwd_pair_kernel<TV, float, QPW, kLpr>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, int(kLds)) != hipSuccess)
+      return check_launch("msda_bwd_pair (LDS limit)");
+    raised_on = dev;
+  }
+  hipLaunchKernelGGL((msda_bwd_pair_kernel<TV, float, QPW, kLpr>), dim3(uint32_t(blocks)), dim3(64 * kPairWaves), kLds, stream,
+                     (const TV*)value, shapes, lsi, (const float*)loc, (const float*)attn, (const TV*)grad_out,
+                     (TV*)grad_value, (float*)grad_loc, (float*)grad_attn, d, tiles_per_batch, ut, uint32_t(gv_blocks / d.M),
+                     uint32_t(gl_groups), uint32_t(gl_blocks), order, take_stamp_region(kStampGradPair, blocks));
+  return check_launch("msda_bwd_pair");
+}
+
+int msda_backward_pair_d32(int vdt, const void* value, const int64_t* shapes, const int64_t* lsi, const void* loc, const void* attn,
+                           const void* grad_out, void* grad_value, void* grad_loc, void* grad_attn, MsdaDims d, int order,
+                           hipStream_t stream) {
+#define VNX_ARGS value, shapes, lsi, loc, attn, grad_out, grad_value, grad_loc, grad_attn, d, order, stream
+  if (vdt == VNX_F32) return launch_pair<float>(VNX_ARGS);
+  if (vdt == VNX_BF16) return launch_pair<bf16_t>(VNX_ARGS);
+  if (vdt == VNX_F16) return launch_pair<f16_t>(VNX_ARGS);
+#undef VNX_ARGS
+  set_error("msda_backward_pair_d32: unsupported value dtype %d", vdt);
+  return VNX_ERR_INVALID_ARGUMENT;
 }
 
 // queries per workgroup of the grad_loc kernel = per tile word of the tile mode (the launcher's own choice)

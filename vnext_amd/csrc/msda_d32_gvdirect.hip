@@ -27,378 +27,18 @@
 // A pass stages at most VNX_GVD_QC queries; calls with more run several passes, the later ones adding onto the rows the
 // first stored (same owner, same lanes: no atomics).  Levels must be packed (checked on the device; capi.hip).
 // Reference semantics: ms_deform_im2col_cuda.cuh:87-159 (the scatter this replaces), :253-298 (index decode).
-#include "msda_gv_common.h"
+#include "msda_d32_gvdirect_body.h"
 
 namespace vnx {
 namespace rec {
-
-#ifndef VNX_GVD_UNITS_PER_CU
-#define VNX_GVD_UNITS_PER_CU 2
-#endif
-#ifndef VNX_GVD_DMA
-#define VNX_GVD_DMA 0             // A/B: fp32 grad_out rows -> LDS by buffer_load ... lds (0: through registers, see request_rows)
-#endif
-#ifndef VNX_GVD_AUX
-#define VNX_GVD_AUX 0             // cache policy of the location / weight loads (2 = nt)
-#endif
-// Timing ablations (A/B builds of the development library only; wrong grad_value by construction): 1 = return after the
-// level table, 2 = no taps (loads, decode and barriers only), 3 = rows stored without their sums, 4 = no store
-#ifndef VNX_GVD_ABL
-#define VNX_GVD_ABL 0
-#endif
-#ifndef VNX_GVD_FULL_BARRIERS
-#define VNX_GVD_FULL_BARRIERS 0   // A/B: __syncthreads() (waits for the rows in flight) where the kernel has LDS-only barriers
-#endif
-
-
-// Development aid (-DVNX_GVD_STAMPS, development library only): per-workgroup phase timestamps in constant-rate wall-clock
-// ticks, 8 per workgroup -- 0 start, 1 level table read, 2 loads issued, 3 decoded + ranked (the loads have arrived),
-// 4 first barrier, 5 offsets + second barrier, 6 scattered + rows staged + third barrier, 7 rows walked and stored.
-#ifdef VNX_GVD_STAMPS
-__device__ unsigned long long g_gvd_stamps[4096 * 8];
-#define VNX_GVD_STAMP(k) do { if (tid == 0 && blockIdx.x < 4096) g_gvd_stamps[blockIdx.x * 8 + (k)] = (unsigned long long)wall_clock64(); } while (0)
-#else
-#define VNX_GVD_STAMP(k) do { } while (0)
-#endif
-
-constexpr int kGvdQc = VNX_GVD_QC;
-constexpr int kGvdRows = VNX_GVD_ROWS;
-constexpr int kGvdSamples = kGvdQc * 4;                                 // samples of a level per pass, at most
-constexpr int kGvdSpt = (kGvdSamples + kThreads - 1) / kThreads;        // ... per thread
-constexpr int kGvdCap = 4 * kGvdSamples;                                // taps per pass, at most: the sorted list holds them all
-constexpr int kGvdRowPieces = (kGvdQc * 8 + kThreads - 1) / kThreads;   // 16-B pieces of staged rows per thread and pass
-constexpr size_t kGvdLdsBytes = size_t(kGvdQc) * 128 + size_t(kGvdCap) * 6 + size_t(kGvdRows) * 12 + 16 + 4 * kLevelsMax * 4;
-static_assert(kGvdLdsBytes * VNX_GVD_UNITS_PER_CU <= 160 * 1024, "the units that share a CU must fit its LDS");
-static_assert(kGvdCap < 65536 && kGvdQc < 65536, "tap ranks and query slots fit 16 bits");
 
 template <typename TV, typename TL, int P_T>
 __global__ void __launch_bounds__(kThreads, VNX_GVD_UNITS_PER_CU * kWaves / 4)
 msda_bwd_gv_direct_kernel(const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
                           const TL* __restrict__ loc, const TL* __restrict__ attn, const TV* __restrict__ grad_out,
                           TV* __restrict__ grad_value, MsdaDims d, int ut, int compact, unsigned long long* stamps) {
-  stamp_begin(stamps);
-  constexpr int D = 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float4_t* grows = reinterpret_cast<float4_t*>(smem);                       // [qc][8] grad_out rows of this head
-  float* l_wt = reinterpret_cast<float*>(grows + kGvdQc * 8);                // [cap] tap weights, sorted by row
-  uint32_t* cnt2 = reinterpret_cast<uint32_t*>(l_wt + kGvdCap);              // [2][rows] taps per row (double-buffered over passes)
-  uint32_t* offs = cnt2 + 2 * kGvdRows;                                      // [rows] first tap of the row
-  uint32_t* alloc = offs + kGvdRows;                                         // [4]
-  int* meta = reinterpret_cast<int*>(alloc + 4);                             // [4*L]
-  uint16_t* l_slot = reinterpret_cast<uint16_t*>(meta + 4 * kLevelsMax);     // [cap] tap query slots, same order
-
-  const int P = P_T > 0 ? P_T : d.P;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // units are numbered from the last (coarsest) level back; head <-> XCD map rotating with the batch element: as in
-  // msda_d32_gvrec.hip / msda_gv_common.h
-  int rest, b, m;
-  if (kGvPair16 && sizeof(TV) == 2 && (d.M & 1) == 0) gv_decode_block<true>(blockIdx.x, d.M, d.B, rest, b, m);
-  else gv_decode_block<false>(blockIdx.x, d.M, d.B, rest, b, m);
-  const int unit = rest / d.B;
-  VNX_GVD_STAMP(0);
-
-  // ---- the grad_out rows of this head, all queries of a pass: 16 B per thread and step, into registers, written to LDS just
-  //      before the walk.  They are REQUESTED behind the pass's samples and stay in flight across the decode, the ranking and
-  //      the two LDS-only barriers of the sort (lds_barrier).  The first forms of the round requested them first -- by LDS-DMA,
-  //      before the level table -- and lost 1.3 us to three things the phase stamps showed: a wave's loads return in order,
-  //      so nothing requested after the rows could be used before they had landed; __syncthreads() waits for every load in
-  //      flight; and with an LDS-DMA pending the compiler makes every LDS access wait for it (it cannot tell the DMA's
-  //      target from the access).  VNX_GVD_DMA = 1 keeps the DMA form for A/B runs. -----------------------------
-  const TV* go_head = grad_out + (int64_t(b) * d.Lq * d.M + m) * D;
-  const uint32_t q_stride = uint32_t(d.M) * uint32_t(D);
-  constexpr uint32_t kOutOfRange = 0x80000000u;          // byte ranges stay below 2^31 (msda_d32_gvdirect_supported)
-  const __amdgpu_buffer_rsrc_t go_src = uniform_rsrc(go_head, uint32_t(d.Lq) * q_stride * uint32_t(sizeof(TV)));
-  int qc = kGvdSamples / P;          // queries per pass: what the staged rows and the sample slots of the threads hold
-  qc = qc < kGvdQc ? qc : kGvdQc;
-  constexpr bool kDma = VNX_GVD_DMA != 0 && sizeof(TV) == 4;
-  float4_t pg[kDma ? 1 : kGvdRowPieces];
-  auto request_rows = [&](int q_lo) {
-    if constexpr (kDma) {
-      // a wave instruction moves 8 rows (64 lanes x 16 B) from global memory to 1 KiB of consecutive LDS; lanes past the
-      // last query are masked off (an out-of-range offset would still WRITE its zeros)
-#pragma unroll
-      for (int i = 0; i < kGvdRowPieces; ++i) {
-        const int row_w = i * (kThreads / 8) + wave * 8;                  // first row of this wave's instruction
-        if (row_w < qc && q_lo + row_w < d.Lq) {                          // uniform over the wave
-          const int ql = row_w + (lane >> 3);
-          if (ql < qc && q_lo + ql < d.Lq) {
-            const uint32_t off = (__umul24(uint32_t(q_lo + ql), q_stride) + uint32_t(lane & 7) * 4u) * 4u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(go_src, (__attribute__((address_space(3))) void*)(grows + row_w * 8), 16,
-                                                     int(off), 0, 0, 0);
-          }
-        }
-      }
-    } else {
-      const int tg = opaque(tid);
-#pragma unroll
-      for (int i = 0; i < kGvdRowPieces; ++i) {
-        const int g = i * kThreads + tg, ql = g >> 3;
-        const bool ok = ql < qc && q_lo + ql < d.Lq;
-        const uint32_t off = ok ? (__umul24(uint32_t(q_lo + ql), q_stride) + uint32_t(g & 7) * 4u) * uint32_t(sizeof(TV)) : kOutOfRange;
-        pg[i] = load4_buf<TV>(go_src, off);
-      }
-    }
-  };
-  int lvl = -1, r0 = 0, r1 = 0, Hl = 0, Wl = 0, start = 0, gshift = 0;
-  bool packed = true;
-  if (tid < d.L) {      // level table: lane l works out level l's unit split once
-    const int H = int(shapes[2 * tid]), W = int(shapes[2 * tid + 1]), first = int(lsi[tid]);     // (one round trip: both requested
-    const GvdSplit sp = gvd_level_split(H * W, ut, d.Lq, P);                                     //  before the divisions below)
-    meta[4 * tid] = H; meta[4 * tid + 1] = W; meta[4 * tid + 2] = first;
-    meta[4 * tid + 3] = sp.units | (sp.rpu << 18) | (sp.gshift << 29);      // units < 2^18 (S < 2^27), rpu <= 2047, gshift <= 3
-  }
-  for (int i = tid; i < 2 * kGvdRows; i += kThreads) cnt2[i] = 0;
-  if (tid == 0) alloc[0] = 0;
-  lds_barrier();
-  {
-    int running = 0;
-    int u = unit;
-    for (int l = 0; l < d.L; ++l) {
-      packed = packed && (meta[4 * l + 2] == running);
-      running += meta[4 * l] * meta[4 * l + 1];
-    }
-    for (int l = d.L - 1; l >= 0; --l) {
-      const int H = meta[4 * l], W = meta[4 * l + 1], st = meta[4 * l + 2];
-      const uint32_t ur = uint32_t(meta[4 * l + 3]);
-      const int n = H * W, units = int(ur & 0x3ffffu), rpu = int((ur >> 18) & 0x7ffu);
-      if (lvl < 0) {
-        if (u < units) {
-          lvl = l; Hl = H; Wl = W; start = st; gshift = int(ur >> 29);
-          r0 = u * rpu;
-          r1 = r0 + rpu < n ? r0 + rpu : n;
-        } else {
-          u -= units;
-        }
-      }
-    }
-    packed = packed && (running == d.S);
-  }
-  if (!packed || lvl < 0) {        // uniform over the workgroup (unpacked levels: the general path does the call, capi.hip)
-    if constexpr (kDma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the rows in flight land in LDS this workgroup still owns
-    return;
-  }
-  // uniform over the workgroup, but it came through LDS: scalarise (SGPRs instead of VGPRs, see opaque()).
-  // (Tried: every lane reading the level sizes through the scalar cache and working the unit out in registers, no LDS -- the
-  //  phase stamps showed why it buys nothing, 2.6 vs 2.3 us: the first barrier of the kernel waits for the row DMA requested
-  //  above either way; what this phase costs is those 38 KB arriving, not the table.)
-  lvl = __builtin_amdgcn_readfirstlane(lvl); r0 = __builtin_amdgcn_readfirstlane(r0); r1 = __builtin_amdgcn_readfirstlane(r1);
-  Hl = __builtin_amdgcn_readfirstlane(Hl); Wl = __builtin_amdgcn_readfirstlane(Wl); start = __builtin_amdgcn_readfirstlane(start);
-  gshift = __builtin_amdgcn_readfirstlane(gshift);
-  if (VNX_GVD_ABL == 1) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
-  const int rows = r1 - r0;
-  VNX_GVD_STAMP(1);
-
-  const int LP = d.L * P;
-  // sample (q, head m, level lvl, point k) of this batch element: element  q * (M * LP) + k  from s_base on in the op's own
-  // layout; compact (the fused backward: its grad_loc kernel leaves the decoded locations and softmax weights laid out
-  // [batch][head][level][query][point], msda_d32.hip): q * P + k -- consecutive bytes
-  const int64_t s_base = compact ? ((int64_t(b) * d.M + m) * d.L + lvl) * int64_t(d.Lq) * P
-                                 : (int64_t(b) * d.Lq * d.M + m) * LP + lvl * P;
-  const TL* attn_bm = attn + s_base;
-  const TL* loc_bm = loc + 2 * s_base;
-  const uint32_t s_stride = compact ? uint32_t(P) : uint32_t(d.M) * uint32_t(LP);
-  const uint32_t n_samp = uint32_t(d.Lq) * s_stride;      // from s_base on, at most
-  const __amdgpu_buffer_rsrc_t loc_src = uniform_rsrc(loc_bm, n_samp * 2u * uint32_t(sizeof(TL)));
-  const __amdgpu_buffer_rsrc_t attn_src = uniform_rsrc(attn_bm, n_samp * uint32_t(sizeof(TL)));
-  const float Hf = float(Hl), Wf = float(Wl);
-  const int dr[4] = {0, 1, Wl, Wl + 1};
-  TV* out = grad_value + ((int64_t(b) * d.S + start + r0) * d.M + m) * D;
-
-  const int n_pass = (d.Lq + qc - 1) / qc;
-  const uint32_t gmask = (1u << gshift) - 1u;
-
-  for (int pass = 0; pass < n_pass; ++pass) {
-    uint32_t* cnt = cnt2 + (pass & 1) * kGvdRows;
-    uint32_t* cnt_next = cnt2 + ((pass + 1) & 1) * kGvdRows;
-    const int q_lo = pass * qc;
-    // ---- this pass's samples: up to kGvdSpt per thread, slot j * 512 + tid -> (query slot, point) -------------------
-    float sx[kGvdSpt], sy[kGvdSpt], sa[kGvdSpt];
-    uint32_t svalid = 0;               // bit j: slot j holds a sample
-    {
-      const int tq = opaque(tid);
-#pragma unroll
-      for (int j = 0; j < kGvdSpt; ++j) {
-        const uint32_t s = uint32_t(j * kThreads + tq);
-        const uint32_t ql = P_T == 4 ? (s >> 2) : s / uint32_t(P);
-        const uint32_t k = s - ql * uint32_t(P);
-        const bool valid = int(ql) < qc && q_lo + int(ql) < d.Lq;
-        svalid |= uint32_t(valid) << j;
-        const uint32_t si = valid ? __umul24(uint32_t(q_lo) + ql, s_stride) + k : kOutOfRange;
-        if constexpr (sizeof(TL) == 4) {
-          const uint2_t xy = __builtin_bit_cast(uint2_t, __builtin_amdgcn_raw_buffer_load_b64(loc_src, int(si * 8u), 0, VNX_GVD_AUX));
-          sx[j] = __uint_as_float(xy.x); sy[j] = __uint_as_float(xy.y);
-          sa[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(attn_src, int(si * 4u), 0, VNX_GVD_AUX));
-        } else {
-          const uint32_t xy = __builtin_amdgcn_raw_buffer_load_b32(loc_src, int(si * 4u), 0, VNX_GVD_AUX);
-          const uint32_t a16 = __builtin_amdgcn_raw_buffer_load_b16(attn_src, int(si * 2u), 0, VNX_GVD_AUX);
-          sx[j] = to_acc(__builtin_bit_cast(TL, uint16_t(xy & 0xffffu))); sy[j] = to_acc(__builtin_bit_cast(TL, uint16_t(xy >> 16)));
-          sa[j] = to_acc(__builtin_bit_cast(TL, uint16_t(a16)));
-        }
-      }
-    }
-    request_rows(q_lo);      // behind the samples: a wave's loads return in order, and the samples are needed first
-    if (pass == 0) VNX_GVD_STAMP(2);
-
-    // ---- decode (cuh:285-288, 38-45), rank every tap inside its row ------------------------------------------------------
-    uint32_t mask = 0;                 // 4 bits per sample: which corners land in [r0, r1)
-    int row00[kGvdSpt];
-    uint32_t rank[kGvdSpt][2];         // two 16-bit ranks per word
-#pragma unroll
-    for (int j = 0; j < kGvdSpt; ++j) {
-      row00[j] = 0; rank[j][0] = rank[j][1] = 0u;
-      float lh = 0.f, lw = 0.f;
-      uint32_t mj = 0;
-      if (svalid & (1u << j)) {
-        const float h = sy[j] * Hf - 0.5f, w = sx[j] * Wf - 0.5f;                 // cuh:285-286
-        if (h > -1.f && w > -1.f && h < Hf && w < Wf) {                            // cuh:288
-          const float hf = floorf(h), wf = floorf(w);
-          const int h0 = int(hf), w0 = int(wf);
-          lh = h - hf; lw = w - wf;
-          const bool top = h0 >= 0, bot = h0 + 1 <= Hl - 1, lef = w0 >= 0, rig = w0 + 1 <= Wl - 1;
-          const int p00 = h0 * Wl + w0;
-          mj = (uint32_t(top && lef && p00 >= r0 && p00 < r1)) |
-               (uint32_t(top && rig && p00 + 1 >= r0 && p00 + 1 < r1) << 1) |
-               (uint32_t(bot && lef && p00 + Wl >= r0 && p00 + Wl < r1) << 2) |
-               (uint32_t(bot && rig && p00 + Wl + 1 >= r0 && p00 + Wl + 1 < r1) << 3);
-          row00[j] = p00 - r0;
-        }
-      }
-      sy[j] = lh; sx[j] = lw;          // (sx, sy) now hold the fractions; sa the attention weight
-      if (VNX_GVD_ABL == 2) mj = (lh + lw == 12345.f) ? mj : 0u;
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-        if (mj & (1u << t)) {
-          const uint32_t r = __hip_atomic_fetch_add(cnt + row00[j] + dr[t], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          rank[j][t >> 1] |= r << ((t & 1) * 16);
-        }
-      mask |= mj << (4 * j);
-    }
-    if (pass == 0) VNX_GVD_STAMP(3);
-    if (VNX_GVD_FULL_BARRIERS) __syncthreads(); else lds_barrier();      // (the rows stay in flight)
-    if (pass == 0) VNX_GVD_STAMP(4);
-
-    // ---- row counts -> segment offsets: DPP wave scan + one LDS allocation per wave and 512 rows ------------------------------
-    for (int rb = 0; rb < rows; rb += kThreads) {      // uniform
-      const int r = rb + tid;
-      const uint32_t my_cnt = r < rows ? cnt[r] : 0u;
-      const uint32_t incl = wave_inclusive_scan(my_cnt);
-      const uint32_t wave_total = uint32_t(__builtin_amdgcn_readlane(int(incl), 63));
-      uint32_t base = 0;
-      if (lane == 0 && wave_total != 0)
-        base = __hip_atomic_fetch_add(alloc, wave_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      base = uint32_t(__builtin_amdgcn_readfirstlane(int(base)));
-      if (r < rows) { offs[r] = base + incl - my_cnt; cnt_next[r] = 0; }
-    }
-    if (VNX_GVD_FULL_BARRIERS) __syncthreads(); else lds_barrier();
-    if (pass == 0) VNX_GVD_STAMP(5);
-
-    // ---- scatter {query slot, weight} into the rows' segments --------------------------------------------------------------
-#pragma unroll
-    for (int j = 0; j < kGvdSpt; ++j) {
-      const uint32_t mj = (mask >> (4 * j)) & 0xfu;
-      if (mj) {
-        const float lh = sy[j], lw = sx[j], a = sa[j], hh = 1.f - lh, hw = 1.f - lw;
-        const float wt[4] = {a * (hh * hw), a * (hh * lw), a * (lh * hw), a * (lh * lw)};     // cuh:115-152
-        const uint32_t sj = uint32_t(j * kThreads + opaque(tid));
-        const uint32_t slot = P_T == 4 ? (sj >> 2) : sj / uint32_t(P);       // the query slot of sample j (as in the loads)
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-          if (mj & (1u << t)) {
-            const uint32_t pos = offs[row00[j] + dr[t]] + ((rank[j][t >> 1] >> ((t & 1) * 16)) & 0xffffu);
-            l_slot[pos] = uint16_t(slot);
-            l_wt[pos] = wt[t];
-          }
-      }
-    }
-    if constexpr (kDma) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-      const int tg = opaque(tid);
-#pragma unroll
-      for (int i = 0; i < kGvdRowPieces; ++i)
-        if (((i * kThreads + tg) >> 3) < kGvdQc) grows[i * kThreads + tg] = pg[i];
-    }
-    __syncthreads();
-    if (pass == 0) VNX_GVD_STAMP(6);
-    if (tid == 0) alloc[0] = 0;
-
-    // ---- lane groups walk the rows: slot = row * groups-per-row + part; a row's segment summed in registers, stored at once.
-    //      A group is kLpr = 4 lanes, each with 32 bytes of the row (bytes [16 j, 16 j + 16) and [64 + 16 j, ...): every load and
-    //      store instruction still moves whole 64-byte half rows): the walk is bound by the vector instructions of its PER-ROW
-    //      work (a fine level has 1.25 taps per row), which all lanes of a group execute alike -- with 8 lanes x 16 bytes the
-    //      kernel issued 999 vector instructions per wave, 450 of them here (profiles/r05_backward_pmc.csv); 4 lanes halve the
-    //      row iterations of a wave: grad_value kernel 13.8 -> 13.4 us at the T = 5 decoder call, 25.4 -> 23.8 at B = 10,
-    //      33.7 -> 32.5 at 720p (walk + store 4.5 -> 3.4 us per workgroup by the phase stamps). ----
-    {
-      constexpr int kLpr = 4;                            // lanes per row, two 16-B pieces each
-      constexpr int kPieces = 8 / kLpr;
-      constexpr int kGrp = kThreads / kLpr;              // groups per workgroup = slots per round
-      const int ta = opaque(tid);
-      const int grp = ta / kLpr, cl = ta % kLpr;
-      const uint32_t step = gmask + 1u;
-      const float4_t* g4 = grows + cl;
-      const int n_slots = rows << gshift;
-      for (int sb = 0; sb < n_slots; sb += kGrp) {      // uniform
-        const int slot = sb + grp;
-        const int row = slot >> gshift;
-        const uint32_t part = uint32_t(slot) & gmask;      // the entries of the row this group takes: part, part + step, ...
-        uint32_t n = 0, o = 0;
-        if (slot < n_slots) { n = VNX_GVD_ABL == 3 ? 0u : cnt[row]; o = offs[row]; }
-        float4_t a0[kPieces], a1[kPieces];
-#pragma unroll
-        for (int h = 0; h < kPieces; ++h) a0[h] = a1[h] = float4_t{0.f, 0.f, 0.f, 0.f};
-        uint32_t i = part;
-        for (; i + step < n; i += 2 * step) {        // two taps in flight
-          const uint32_t s0 = l_slot[o + i], s1 = l_slot[o + i + step];
-          const float w0 = l_wt[o + i], w1 = l_wt[o + i + step];
-#pragma unroll
-          for (int h = 0; h < kPieces; ++h) {
-            a0[h] += w0 * g4[s0 * 8 + h * kLpr];
-            a1[h] += w1 * g4[s1 * 8 + h * kLpr];
-          }
-        }
-        if (i < n) {
-          const uint32_t s0 = l_slot[o + i];
-          const float w0 = l_wt[o + i];
-#pragma unroll
-          for (int h = 0; h < kPieces; ++h) a1[h] += w0 * g4[s0 * 8 + h * kLpr];
-        }
-#pragma unroll
-        for (int h = 0; h < kPieces; ++h) a0[h] += a1[h];
-        // (two ROWS side by side, one tap of each per step -- measured slower: grad_value kernel 16.2 vs 13.5 us at the T = 5
-        //  decoder call; the merged loop runs to the longer of the two rows)
-        // a row spread over 1 << gshift groups (adjacent groups of one wave): their partial sums meet in the first
-#pragma unroll
-        for (int sh = 0; sh < 3; ++sh)
-          if (sh < gshift) {
-#pragma unroll
-            for (int h = 0; h < kPieces; ++h) {
-              a0[h].x += __shfl_xor(a0[h].x, kLpr << sh, 64); a0[h].y += __shfl_xor(a0[h].y, kLpr << sh, 64);
-              a0[h].z += __shfl_xor(a0[h].z, kLpr << sh, 64); a0[h].w += __shfl_xor(a0[h].w, kLpr << sh, 64);
-            }
-          }
-        if (VNX_GVD_ABL == 4) continue;
-        if (part == 0u && slot < n_slots) {
-          TV* p = out + __umul24(uint32_t(row), q_stride) + cl * 4;
-          // several passes: the later ones add onto what the first stored (this lane wrote it: program order).  Non-temporal
-          // stores in every case: written with plain stores the 26 MB of rows of a T = 5 call stay dirty in L2 until the
-          // end-of-kernel write-back, which then takes 10 us (kernel 18.0 us; 7.8 without any store; 14.8 with `nt`) -- and a
-          // branch that stores the same value plain on one side and `nt` on the other is merged by the compiler into the
-          // plain form.  Other cache policies of the store (sc1 nt, sc0 sc1 nt: 13.3-13.4 us against 13.5; sc1, sc0 sc1
-          // without nt: 14.4-14.5): within noise or worse, `nt` stays.
-#pragma unroll
-          for (int h = 0; h < kPieces; ++h) {
-            if (pass > 0) a0[h] += load4<TV>(p + h * kLpr * 4);
-            store4<TV>(p + h * kLpr * 4, a0[h]);
-          }
-        }
-      }
-    }
-    if (pass + 1 < n_pass) __syncthreads();       // the staged rows and the lists are rewritten next
-  }
-  VNX_GVD_STAMP(7);
-  stamp_end(stamps);
+  msda_bwd_gv_direct_body<TV, TL, P_T>(shapes, lsi, loc, attn, grad_out, grad_value, d, ut, compact, stamps, blockIdx.x, smem);
 }
 
 }  // namespace rec

@@ -73,7 +73,7 @@ int check_launch(const char* what);
 // duration on the device, without the inter-kernel gap that event timing around back-to-back
 // launches includes.  Per-workgroup slots: no same-address atomics across workgroups.
 // nullptr (the normal case) = no stamps.
-enum StampKernel { kStampFwd = 1, kStampGradLoc = 2, kStampGradValue = 3 };
+enum StampKernel { kStampFwd = 1, kStampGradLoc = 2, kStampGradValue = 3, kStampGradPair = 4 };
 unsigned long long* take_stamp_region(int kernel, long long blocks);
 __device__ __forceinline__ void stamp_begin(unsigned long long* s) {
   if (s && threadIdx.x == 0) s[2 * size_t(blockIdx.x)] = (unsigned long long)wall_clock64();
