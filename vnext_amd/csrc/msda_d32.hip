@@ -1393,6 +1393,7 @@ msda_bwd_pair_kernel(const TV* __restrict__ value, const int64_t* __restrict__ s
   // units fill the CUs as they drain; 0: the grad_value groups first; 2: alternating while both last.  Measured (kbench, cold,
   // backward alone / fwd+bwd step; two launches 22.7 / 28.8 us): order 1 21.4 / 26.8, order 0 24.1 / 26.6, order 2 24.8 / 31.4
   // at the T = 5 decoder call; B = 10 39.5 / 49.7 -> 36.2 / 47.5 (0: 40.5 / 46.9, 2: 45.4 / 55.7); 720p 41.5 -> 35.7 (0: 40.7, 2: 38.2).
+  // (Also measured and dropped: the units of the coarse levels -- the longest -- in front of the grad_loc groups, 21.9 / 29.4.)
   const uint32_t M = uint32_t(d.M), G = blockIdx.x / M, x = blockIdx.x - G * M;
   bool is_gv;
   uint32_t g;      // the group's index within its role
@@ -1446,9 +1447,9 @@ static int launch_pair(const void* value, const int64_t* shapes, const int64_t* 
   }
   constexpr size_t kLds = rec::kGvdLdsBytes > size_t(kPairWaves) * kPairGlWaveLds<QPW> ? rec::kGvdLdsBytes
                                                                                            : size_t(kPairWaves) * kPairGlWaveLds<QPW>;
-  static thread_local int raised_on = -1;      // more than 64 KiB of LDS per workgroup: the limit is raised once per device
   int dev = 0;
   (void)hipGetDevice(&dev);
+  static thread_local int raised_on = -1;      // more than 64 KiB of LDS per workgroup: the limit is raised once per device
   if (kLds > 64 * 1024 && raised_on != dev) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&msda_bwd_pair_kernel<TV, float, QPW, kLpr>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, int(kLds)) != hipSuccess)

@@ -11,10 +11,11 @@
 //   * the locations and weights of its level's samples of every query -- 32 + 16 bytes per (query, head, level): 14 KB for
 //     the 300 queries of a decoder call -- straight from `sampling_loc` / `attn_weight`, and decodes them (cuh:253-298);
 //   * the grad_out rows of its head of every query (128 B each: 38 KB), streamed into LDS by `buffer_load ... lds`
-//     (no register round trip) while the decode runs;
+//     (no register round trip) while the decode runs -- the first form; now through registers, requested behind the samples
+//     (msda_d32_gvdirect_body.h says why);
 // counting-sorts ALL taps that land in its rows by destination row (integer LDS atomics for ranks, DPP scan; the list
-// holds the worst case, every sample on the unit's rows), and then 8-lane groups WALK the rows: a group sums one row's
-// segment in four registers and stores the row at once -- no rows kept in registers, no second barrier-separated chunk,
+// holds the worst case, every sample on the unit's rows), and then 4-lane groups WALK the rows: a group sums one row's
+// segment in eight registers and stores the row at once -- no rows kept in registers, no second barrier-separated chunk,
 // nothing between the sort and the last store but LDS reads and 16-B stores.  No records, no tags, no workspace, no
 // dependence on the grad_loc kernel.
 // What bounds the form is what the units FETCH: each of them reads its level's samples (strided: 32 of every 1 024 bytes of
