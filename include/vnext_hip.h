@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define VNX_ABI_VERSION 12
+#define VNX_ABI_VERSION 13
 
 /* element types */
 enum {
@@ -360,6 +360,27 @@ int vnx_bias_relu_dropout_forward(int dtype, void* h, const void* bias, const un
                                   const unsigned long long* seed_device, void* hip_stream);
 int vnx_bias_relu_dropout_backward(int dtype, const void* grad, const void* y, const unsigned char* row_zero, void* grad_h,
                                    void* grad_bias, void* partial, long long rows, int channels, float p, void* hip_stream);
+
+/*
+ * Self-attention over the object queries of a decoder layer (ABI 13) -- what `nn.MultiheadAttention(256, 8, dropout)` does
+ * between its input and output projections (projects/SeqFormer/seqformer/models/deformable_transformer.py:286-323 and the
+ * `_box` twin; IDOL's decoder layer the same), for ALL heads in one launch forward and one backward:
+ *   out[b, i, h] = sum_j dropout(softmax_j((q_i + bq) . (k_j + bk) / sqrt(head_dim)))_ij (v_j + bv)
+ * qkv: fp32 [batch * queries][row_stride], a row = q | k | v (channels = heads * head_dim each) of one query as the
+ * in-projection GEMMs left them, WITHOUT bias; in_proj_bias [3 * channels] (may be null) is added here.  head_dim must be 32.
+ * out [batch, queries, channels] fp32; lse [batch * heads * queries] fp32 (the log-sum-exp of a row's scaled scores: all the
+ * backward needs to recompute the probabilities, which are never stored).  Dropout on the probabilities as in
+ * vnx_add_dropout_layernorm_* (hash of (seed, element), seed_device for captured graphs; p = 0: none).
+ * Backward: grad_qkv [batch * queries][grad_row_stride], the same row layout (gradients of the rows BEFORE the bias; the
+ * bias gradient is their column sum), every element written.  No workspace, no atomics, fixed summation order.
+ */
+int vnx_query_self_attention_forward(int dtype, const void* qkv, const void* in_proj_bias, void* out, void* lse, int batch,
+                                     int queries, int heads, int head_dim, int row_stride, float p, unsigned long long seed,
+                                     const unsigned long long* seed_device, void* hip_stream);
+int vnx_query_self_attention_backward(int dtype, const void* qkv, const void* in_proj_bias, const void* out, const void* lse,
+                                      const void* grad_out, void* grad_qkv, int batch, int queries, int heads, int head_dim,
+                                      int row_stride, int grad_row_stride, float p, unsigned long long seed,
+                                      const unsigned long long* seed_device, void* hip_stream);
 
 /* (The kernel-variant override of rounds 1-3 -- a process-wide A/B knob -- is no longer part of this library: it lives in
  *  the development build only, include/vnext_hip_dev.h.  Every call here selects its kernels from its own arguments.) */

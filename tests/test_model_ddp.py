@@ -93,6 +93,40 @@ def test_training_branch_returns_the_reference_loss_names_and_reaches_every_para
         undo()
 
 
+def test_box_predictions_of_the_refinement_loop_are_the_detectors_box_head():
+    """The decoder's refinement loop and the detector's box head evaluate the same expression with the same modules and
+    references (deformable_transformer.py:366-380 / deformable_detr.py:195-213); `_heads` takes the loop's result.  Values
+    and the gradient of every parameter must equal the head's own recomputation."""
+    undo = _cpu_stand_ins()
+    try:
+        torch.manual_seed(2)
+        cfg = {"MODEL.DEVICE": "cpu", **TINY, "MODEL.SeqFormer.DEC_LAYERS": 3}
+        model = build_model(get_seqformer_cfg(**cfg)).train()
+        clips = T.synthetic_clips(2, 2, 64, 96, "cpu", seed=7, num_instances=2)
+
+        def run(reuse):
+            model.zero_grad()
+            x, mask = model._preprocess(clips)
+            srcs, masks, poss = model._features(x, mask)
+            d = model.detr.detr
+            hs, hs_box, _, init_ref, inter_refs, inter_boxes, _, _ = d.transformer(srcs, masks, poss, d.query_embed.weight)
+            assert inter_boxes is not None and inter_boxes.requires_grad and not inter_refs.requires_grad
+            assert torch.equal(inter_boxes.detach(), inter_refs)
+            logits, boxes = model._heads(hs, hs_box, init_ref, inter_refs, inter_boxes if reuse else None)
+            g = torch.Generator().manual_seed(3)
+            ((boxes * torch.randn(boxes.shape, generator=g)).sum() + (logits * torch.randn(logits.shape, generator=g)).sum()).backward()
+            return boxes.detach(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+
+        boxes_a, grads_a = run(True)
+        boxes_b, grads_b = run(False)
+        torch.testing.assert_close(boxes_a, boxes_b, rtol=0, atol=1e-6)
+        assert set(grads_a) == set(grads_b) and any("bbox_embed" in n for n in grads_a)
+        for n in grads_a:
+            torch.testing.assert_close(grads_a[n], grads_b[n], rtol=0, atol=2e-5 * float(grads_b[n].abs().max()) + 1e-7, msg=n)
+    finally:
+        undo()
+
+
 def _ddp_worker(rank, world, port, out):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),

@@ -41,18 +41,25 @@ def census(fn, title):
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
         fn()
         torch.cuda.synchronize()
     ops = collections.defaultdict(lambda: [0, 0.0])
+    shaped = collections.defaultdict(lambda: [0, 0.0])
     for ev in prof.events():
         ks = getattr(ev, "kernels", None) or []
         if ks and ev.device_type == torch.autograd.DeviceType.CPU:
             ops[ev.name][0] += len(ks); ops[ev.name][1] += sum(k.duration for k in ks)
+            key = (ev.name, str([list(x) for x in (ev.input_shapes or []) if x])[:90])
+            shaped[key][0] += len(ks); shaped[key][1] += sum(k.duration for k in ks)
     n = sum(v[0] for v in ops.values()); t = sum(v[1] for v in ops.values())
     print("=== %s: %d launches, %.2f ms of kernels" % (title, n, t / 1e3))
     for name, (c, us) in sorted(ops.items(), key=lambda kv: -kv[1][0])[:28]:
         print("%5d %9.1f us  %s" % (c, us, name[:80]))
+    if os.environ.get("VNX_CENSUS_SHAPES"):
+        print("--- by (operator, input shapes)")
+        for (name, shp), (c, us) in sorted(shaped.items(), key=lambda kv: -kv[1][0])[:int(os.environ["VNX_CENSUS_SHAPES"])]:
+            print("%5d %9.1f us  %-28s %s" % (c, us, name[:28], shp))
 
 
 census(step, "encoder + decoder, forward + backward")

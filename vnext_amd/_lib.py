@@ -16,7 +16,7 @@ DEV_LIB_PATH = os.path.join(_HERE, "lib", "libvnext_hip_dev.so")
 
 VNX_F32, VNX_F64, VNX_BF16, VNX_F16 = 0, 1, 2, 3
 VNX_OK = 0
-ABI_VERSION = 12
+ABI_VERSION = 13
 MSDA_LEVELS_PACKED = 1
 MSDA_FORK = 2              # vnx_msda_backward: grad_value kernel on the library's side stream (include/vnext_hip.h)
 
@@ -47,6 +47,9 @@ SIGNATURES = {
     "vnx_add_dropout_layernorm_forward": (_i, [_i] + [_vp] * 8 + [_ll, _i, ctypes.c_float, ctypes.c_float, ctypes.c_ulonglong, _vp, _vp]),
     "vnx_add_dropout_layernorm_backward": (_i, [_i] + [_vp] * 10 + [_ll, _i, ctypes.c_float, ctypes.c_ulonglong, _vp, _vp]),
     "vnx_bias_relu_dropout_partial_bytes": (_sz, [_i]),
+    "vnx_query_self_attention_forward": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, ctypes.c_float, ctypes.c_ulonglong, _vp, _vp]),
+    "vnx_query_self_attention_backward": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, ctypes.c_float,
+                                               ctypes.c_ulonglong, _vp, _vp]),
     "vnx_bias_relu_dropout_forward": (_i, [_i, _vp, _vp, _vp, _ll, _i, _i, ctypes.c_float, ctypes.c_ulonglong, _vp, _vp]),
     "vnx_bias_relu_dropout_backward": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, ctypes.c_float, _vp]),
 }

@@ -20,6 +20,7 @@ from torch.nn.init import constant_, normal_, xavier_uniform_
 
 from ..ops.fused_ffn import ffn_block
 from ..ops.fused_norm import add_dropout_norm
+from ..ops.self_attention import query_self_attention_block
 from ..ops.modules import MSDeformAttnIDOL
 from .seqformer_transformer import DeformableTransformerEncoder as _ClipEncoder
 from .seqformer_transformer import _get_activation_fn, _get_clones
@@ -30,6 +31,7 @@ class DeformableTransformerEncoderLayer(nn.Module):
     def __init__(self, d_model=256, d_ffn=1024, dropout=0.1, activation="relu", n_levels=4, n_heads=8, n_points=4):
         super().__init__()
         self.self_attn = MSDeformAttnIDOL(d_model, n_levels, n_heads, n_points)
+        self.self_attn.defer_output_bias = True      # added in norm1's pass (forward below)
         self.dropout1 = nn.Dropout(dropout)
         self.norm1 = nn.LayerNorm(d_model)
         self.linear1 = nn.Linear(d_model, d_ffn)
@@ -42,7 +44,7 @@ class DeformableTransformerEncoderLayer(nn.Module):
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None):
         q = src if pos is None else src + pos
         src2 = self.self_attn(q, reference_points, src, spatial_shapes, level_start_index, padding_mask)[0]
-        src = add_dropout_norm(src, src2, self.dropout1, self.norm1)
+        src = add_dropout_norm(src, src2, self.dropout1, self.norm1, r_bias=self.self_attn.output_proj.bias)
         # norm2(src + dropout3(linear2(dropout2(activation(linear1(src)))))) -- vnext_amd/ops/fused_ffn.py
         return ffn_block(src, self.linear1, self.activation, self.dropout2, self.linear2, self.dropout3, self.norm2)
 
@@ -68,6 +70,7 @@ class DeformableTransformerDecoderLayer(nn.Module):
     def __init__(self, d_model=256, d_ffn=1024, dropout=0.1, activation="relu", n_levels=4, n_heads=8, n_points=4):
         super().__init__()
         self.cross_attn = MSDeformAttnIDOL(d_model, n_levels, n_heads, n_points)
+        self.cross_attn.defer_output_bias = True     # added in norm1's pass (forward below)
         self.dropout1 = nn.Dropout(dropout)
         self.norm1 = nn.LayerNorm(d_model)
         self.self_attn = nn.MultiheadAttention(d_model, n_heads, dropout=dropout)
@@ -82,12 +85,11 @@ class DeformableTransformerDecoderLayer(nn.Module):
 
     def forward(self, tgt, query_pos, reference_points, src, src_spatial_shapes, level_start_index,
                 src_padding_mask=None):
-        q = k = tgt if query_pos is None else tgt + query_pos
-        tgt2 = self.self_attn(q.transpose(0, 1), k.transpose(0, 1), tgt.transpose(0, 1))[0].transpose(0, 1)
-        tgt = add_dropout_norm(tgt, tgt2, self.dropout2, self.norm2)
+        # norm2(tgt + dropout2(self_attn(tgt + pos, tgt + pos, tgt))): vnext_amd/ops/self_attention.py
+        tgt = query_self_attention_block(tgt, query_pos, self.self_attn, self.dropout2, self.norm2)
         tgt2, loc, w = self.cross_attn(tgt if query_pos is None else tgt + query_pos, reference_points, src,
                                        src_spatial_shapes, level_start_index, src_padding_mask)
-        tgt = add_dropout_norm(tgt, tgt2, self.dropout1, self.norm1)
+        tgt = add_dropout_norm(tgt, tgt2, self.dropout1, self.norm1, r_bias=self.cross_attn.output_proj.bias)
         return ffn_block(tgt, self.linear1, self.activation, self.dropout3, self.linear2, self.dropout4, self.norm3), loc, w
 
 

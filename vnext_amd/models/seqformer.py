@@ -323,8 +323,8 @@ class _TrainTrunk(nn.Module):
         mask[:, :h, :w] = False
         srcs, masks, poss = o._features(x, mask)
         d = self.detr.detr
-        hs, hs_box, memory, init_ref, inter_refs, _, _, _ = d.transformer(srcs, masks, poss, d.query_embed.weight)
-        logits, boxes = o._heads(hs, hs_box, init_ref, inter_refs)
+        hs, hs_box, memory, init_ref, inter_refs, inter_boxes, _, _ = d.transformer(srcs, masks, poss, d.query_embed.weight)
+        logits, boxes = o._heads(hs, hs_box, init_ref, inter_refs, inter_boxes)
         return (hs, logits, boxes, inverse_sigmoid(init_ref), inverse_sigmoid(inter_refs),
                 o._mask_features(srcs, memory))
 
@@ -399,8 +399,13 @@ class SeqFormer(nn.Module):
         fold = lambda t: t.reshape(N, T, *t.shape[1:])  # noqa: E731
         return [fold(s) for s in srcs], [fold(mk) for mk in masks], [fold(p) for p in poss]
 
-    def _heads(self, hs, hs_box, init_reference, inter_references):
+    def _heads(self, hs, hs_box, init_reference, inter_references, inter_boxes=None):
+        """Class logits [Ld, N, Q, K] and boxes [Ld, N, T, Q, 4] of every decoder layer (deformable_detr.py:195-213).
+        inter_boxes: the box predictions the decoder's refinement loop already made with these same box heads and
+        references (seqformer_transformer.py) -- then only the class heads run here."""
         d = self.detr.detr
+        if inter_boxes is not None and d.transformer.decoder.bbox_embed is d.bbox_embed:
+            return torch.stack([d.class_embed[lvl](h) for lvl, h in enumerate(hs.unbind(0))]), inter_boxes
         classes, coords = [], []
         for lvl, (h, h_box) in enumerate(zip(hs.unbind(0), hs_box.unbind(0))):   # unbind: ONE stack in the backward
             reference = init_reference if lvl == 0 else inter_references[lvl - 1]
@@ -417,9 +422,9 @@ class SeqFormer(nn.Module):
     def _run(self, batched_inputs, want_refs=False):
         x, mask = self._preprocess(batched_inputs)
         srcs, masks, poss = self._features(x, mask)
-        hs, hs_box, memory, init_ref, inter_refs, _, _, _ = self.detr.detr.transformer(
+        hs, hs_box, memory, init_ref, inter_refs, inter_boxes, _, _ = self.detr.detr.transformer(
             srcs, masks, poss, self.detr.detr.query_embed.weight)
-        logits, boxes = self._heads(hs, hs_box, init_ref, inter_refs)
+        logits, boxes = self._heads(hs, hs_box, init_ref, inter_refs, inter_boxes)
         if want_refs:  # the (pre-sigmoid) reference each decoder layer refined, [N, T, Q, 2 or 4]
             refs = [inverse_sigmoid(init_ref if l == 0 else inter_refs[l - 1]) for l in range(hs.shape[0])]
             return x, srcs, hs, memory, logits, boxes, refs

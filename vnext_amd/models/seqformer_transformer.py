@@ -8,7 +8,9 @@ differently onto the machine:
   * every MSDeformAttn call folds the frame axis into the op batch (one launch per layer,
     vnext_amd/ops/modules/ms_deform_attn.py);
   * the decoder's per-frame box-query self-attention, a Python loop over frames in the reference
-    (:291-297), runs as one batched nn.MultiheadAttention call over N*T sequences.
+    (:291-297), runs as one batched call over N*T sequences -- and every self-attention sub-layer as
+    `query_self_attention_block` (vnext_amd/ops/self_attention.py: one attention launch for all heads, the output
+    projection's bias folded into the LayerNorm pass; the module stays an nn.MultiheadAttention).
 """
 from __future__ import annotations
 
@@ -22,7 +24,8 @@ from torch.nn.init import constant_, normal_, xavier_uniform_
 from ..ops.fused_ffn import ffn_block
 from ..ops.fused_norm import add_dropout_norm
 from ..ops.modules import MSDeformAttnSeqFormer
-from .transformer_common import ReferenceScaler, flatten_levels, inverse_sigmoid, refine_reference  # noqa: F401  (inverse_sigmoid: re-exported)
+from ..ops.self_attention import query_self_attention_block
+from .transformer_common import ReferenceScaler, flatten_levels, inverse_sigmoid, refined_boxes  # noqa: F401  (inverse_sigmoid: re-exported)
 
 
 
@@ -45,6 +48,7 @@ class DeformableTransformerEncoderLayer(nn.Module):
                  n_points=4):
         super().__init__()
         self.self_attn = MSDeformAttnSeqFormer(d_model, n_levels, n_heads, n_points, 'encode')
+        self.self_attn.defer_output_bias = True      # added in norm1's pass (forward below)
         self.dropout1 = nn.Dropout(dropout)
         self.norm1 = nn.LayerNorm(d_model)
         self.linear1 = nn.Linear(d_model, d_ffn)
@@ -65,7 +69,7 @@ class DeformableTransformerEncoderLayer(nn.Module):
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None):
         src2 = self.self_attn(self.with_pos_embed(src, pos), None, reference_points, src, spatial_shapes,
                               level_start_index, padding_mask)
-        src = add_dropout_norm(src, src2, self.dropout1, self.norm1)
+        src = add_dropout_norm(src, src2, self.dropout1, self.norm1, r_bias=self.self_attn.output_proj.bias)
         return self.forward_ffn(src)
 
 
@@ -105,6 +109,7 @@ class DeformableTransformerDecoderLayer(nn.Module):
                  n_points=4):
         super().__init__()
         self.cross_attn = MSDeformAttnSeqFormer(d_model, n_levels, n_heads, n_points, 'decode')
+        self.cross_attn.defer_output_bias = True     # both output projections: added in norm1's / norm1_box's pass (forward below)
         self.dropout1 = nn.Dropout(dropout)
         self.norm1 = nn.LayerNorm(d_model)
         self.dropout1_box = nn.Dropout(dropout)
@@ -142,39 +147,33 @@ class DeformableTransformerDecoderLayer(nn.Module):
 
     def forward(self, tgt, tgt_box, query_pos, reference_points, src, src_spatial_shapes, level_start_index,
                 src_padding_mask=None):
-        # self attention of the mask & class queries
-        q1 = k1 = self.with_pos_embed(tgt, query_pos)
-        tgt2 = self.self_attn(q1.transpose(0, 1), k1.transpose(0, 1), tgt.transpose(0, 1))[0].transpose(0, 1)
-        tgt = add_dropout_norm(tgt, tgt2, self.dropout2, self.norm2)
+        # self attention of the mask & class queries: norm2(tgt + dropout2(self_attn(tgt + pos, tgt + pos, tgt)))
+        tgt = query_self_attention_block(tgt, query_pos, self.self_attn, self.dropout2, self.norm2)
 
         if tgt_box.dim() == 3:  # first layer: box queries still shared by the frames [N, Q, C]
-            q_box = k_box = self.with_pos_embed(tgt_box, query_pos)
-            tgt2_box = self.self_attn_box(q_box.transpose(0, 1), k_box.transpose(0, 1),
-                                          tgt_box.transpose(0, 1))[0].transpose(0, 1)
-            tgt_box = add_dropout_norm(tgt_box, tgt2_box, self.dropout2_box, self.norm2_box)
+            tgt_box = query_self_attention_block(tgt_box, query_pos, self.self_attn_box, self.dropout2_box, self.norm2_box)
             box_query = self.with_pos_embed(tgt_box, query_pos)
-        else:  # [N, T, Q, C]: every frame attends over its own box queries -- one batched call
+        else:  # [N, T, Q, C]: every frame attends over its own box queries -- one batched call, pos shared by a clip's frames
             N, nf, num_q, C = tgt_box.shape
-            flat = tgt_box.reshape(N * nf, num_q, C)
-            pos = None if query_pos is None else query_pos.unsqueeze(1).expand(N, nf, num_q, C).reshape(N * nf, num_q, C)
-            q_box = k_box = self.with_pos_embed(flat, pos)
-            t2 = self.self_attn_box(q_box.transpose(0, 1), k_box.transpose(0, 1), flat.transpose(0, 1))[0].transpose(0, 1)
-            tgt_box = add_dropout_norm(flat, t2, self.dropout2_box, self.norm2_box).view(N, nf, num_q, C)
+            tgt_box = query_self_attention_block(tgt_box.reshape(N * nf, num_q, C), query_pos, self.self_attn_box,
+                                                 self.dropout2_box, self.norm2_box).view(N, nf, num_q, C)
             box_query = tgt_box if query_pos is None else tgt_box + query_pos.unsqueeze(1)
 
         tgt2, tgt2_box, sampling_locations, attention_weights = self.cross_attn(
             self.with_pos_embed(tgt, query_pos), box_query, reference_points, src, src_spatial_shapes,
             level_start_index, src_padding_mask)
 
+        # (the cross attention returned both projections without their biases: defer_output_bias)
         if tgt_box.dim() == 3:      # first layer: the shared box queries broadcast over the frames
-            tgt_box = self.norm1_box(tgt_box.unsqueeze(1) + self.dropout1_box(tgt2_box))
+            tgt_box = self.norm1_box(tgt_box.unsqueeze(1) + self.dropout1_box(tgt2_box + self.cross_attn.output_proj_box.bias))
         else:
-            tgt_box = add_dropout_norm(tgt_box, tgt2_box, self.dropout1_box, self.norm1_box)
+            tgt_box = add_dropout_norm(tgt_box, tgt2_box, self.dropout1_box, self.norm1_box,
+                                       r_bias=self.cross_attn.output_proj_box.bias)
         tgt_box = self.forward_ffn_box(tgt_box)
 
         time_weight = F.softmax(self.time_attention_weights(tgt_box), 1)   # softmax over the frames
-        tgt2 = (tgt2 * time_weight).sum(1)
-        tgt = add_dropout_norm(tgt, tgt2, self.dropout1, self.norm1)
+        tgt2 = (tgt2 * time_weight).sum(1)      # the weights of a query sum to one: output_proj's bias passes through unchanged
+        tgt = add_dropout_norm(tgt, tgt2, self.dropout1, self.norm1, r_bias=self.cross_attn.output_proj.bias)
         return self.forward_ffn(tgt), tgt_box, sampling_locations, attention_weights
 
 
@@ -190,22 +189,27 @@ class DeformableTransformerDecoder(nn.Module):
     def forward(self, tgt, reference_points, src, src_spatial_shapes, src_level_start_index, src_valid_ratios,
                 query_pos=None, src_padding_mask=None):
         """tgt [N, Q, C] (both query streams start from it), reference_points [N, T, Q, 2] ->
-        stacked per-layer (mask/class queries [Ld, N, Q, C], box queries [Ld, N, T, Q, C], references [Ld, N, T, Q, 4], None),
-        or the last layer's (queries, references) without `return_intermediate`."""
+        stacked per-layer (mask/class queries [Ld, N, Q, C], box queries [Ld, N, T, Q, C], references [Ld, N, T, Q, 4], the
+        layers' box predictions [Ld, N, T, Q, 4] | None), or the last layer's (queries, references) without
+        `return_intermediate`.  The box predictions are the refined references BEFORE they are detached: the detector's box
+        head evaluates exactly this expression again for its loss (reference: deformable_detr.py:195-213) -- here it takes
+        them from this loop instead (six box MLPs, logits and sigmoids less per step)."""
         scaled = ReferenceScaler(src_valid_ratios, extra_axes=2)       # [N, 1, 1, L, 2|4] against [N, T, Q, 1, 2|4]
         queries, box_queries = tgt, tgt
-        kept = ([], [], [])
+        kept = ([], [], [], [])
         for lid, layer in enumerate(self.layers):
             queries, box_queries, _, _ = layer(queries, box_queries, query_pos, scaled(reference_points), src,
                                                src_spatial_shapes, src_level_start_index, src_padding_mask)
+            boxes = None
             if self.bbox_embed is not None:
-                reference_points = refine_reference(self.bbox_embed[lid](box_queries), reference_points)
+                boxes = refined_boxes(self.bbox_embed[lid](box_queries), reference_points)
+                reference_points = boxes.detach()
             if self.return_intermediate:
-                for store, item in zip(kept, (queries, box_queries, reference_points)):
+                for store, item in zip(kept, (queries, box_queries, reference_points, boxes)):
                     store.append(item)
         if not self.return_intermediate:
             return queries, reference_points
-        return tuple(torch.stack(store) for store in kept) + (None,)
+        return tuple(torch.stack(store) for store in kept[:3]) + (torch.stack(kept[3]) if self.bbox_embed is not None else None,)
 
 
 class DeformableTransformer(nn.Module):
@@ -249,7 +253,8 @@ class DeformableTransformer(nn.Module):
 
     def forward(self, srcs, masks, pos_embeds, query_embed=None):
         """srcs / pos_embeds per level [N, T, C, H_l, W_l], masks [N, T, H_l, W_l], query_embed [Q, 2C] ->
-        (hs, hs_box, memory [N, T, S, C], initial references [N, T, Q, 2], per-layer references, None, None, valid_ratios)."""
+        (hs, hs_box, memory [N, T, S, C], initial references [N, T, Q, 2], per-layer references, per-layer box predictions
+        (with their graph; None without a box head on the decoder), None, valid_ratios)."""
         assert query_embed is not None
         memory_in, padding, pos, shapes_t, start_t, sizes = flatten_levels(srcs, masks, pos_embeds, self.level_embed)
         valid_ratios = torch.stack([self.get_valid_ratio(m[:, 0]) for m in masks], 1)      # of the clip's first frame
@@ -260,6 +265,6 @@ class DeformableTransformer(nn.Module):
         tgt = query_embed[:, channels:].unsqueeze(0).expand(clips, -1, -1)
         # one learned reference point per query, the same in every frame of the clip to begin with
         init_reference = self.reference_points(query_pos).sigmoid().unsqueeze(1).repeat(1, frames, 1, 1)
-        hs, hs_box, inter_references, inter_samples = self.decoder(tgt, init_reference, memory, shapes_t, start_t,
-                                                                   valid_ratios, query_pos, padding)
-        return hs, hs_box, memory, init_reference, inter_references, inter_samples, None, valid_ratios
+        hs, hs_box, inter_references, inter_boxes = self.decoder(tgt, init_reference, memory, shapes_t, start_t,
+                                                                 valid_ratios, query_pos, padding)
+        return hs, hs_box, memory, init_reference, inter_references, inter_boxes, None, valid_ratios

@@ -53,11 +53,18 @@ class ReferenceScaler:
         return reference_points.unsqueeze(-2) * scale
 
 
-def refine_reference(delta, reference_points):
+def refined_boxes(delta, reference_points):
     """Iterative box refinement: the layer's box head predicts an offset in logit space.  Boxes: all four components move;
-    points: the centre moves, the predicted size is taken as it is.  Returned detached, as the reference feeds it on."""
+    points: the centre moves, the predicted size is taken as it is.  -> the refined boxes WITH their graph: they are also
+    the layer's box prediction (the reference's detector computes the same expression a second time for its loss,
+    deformable_detr.py:195-213: `bbox_embed[lvl](hs_box[lvl]) + inverse_sigmoid(reference)`, sigmoid)."""
     if reference_points.shape[-1] == 4:
         moved = delta + inverse_sigmoid(reference_points)
     else:
         moved = torch.cat([delta[..., :2] + inverse_sigmoid(reference_points), delta[..., 2:]], -1)
-    return moved.sigmoid().detach()
+    return moved.sigmoid()
+
+
+def refine_reference(delta, reference_points):
+    """`refined_boxes`, detached: what the reference feeds on to the next layer."""
+    return refined_boxes(delta, reference_points).detach()

@@ -53,6 +53,13 @@ class _MSDeformAttnBase(nn.Module):
         self.attention_weights = nn.Linear(d_model, n_heads * n_levels * n_points)
         self.value_proj = nn.Linear(d_model, d_model)
         self.output_proj = nn.Linear(d_model, d_model)
+        # set by a transformer layer that adds the output projections' biases itself, in the pass that follows
+        # (`add_dropout_norm(..., r_bias=...)`: the bias gradient then falls out of the LayerNorm backward instead of a
+        # reduction launch per projection): the module then returns `output_proj` / `output_proj_box` WITHOUT bias
+        self.defer_output_bias = False
+
+    def _project_output(self, x, proj):
+        return F.linear(x, proj.weight) if self.defer_output_bias else proj(x)
 
     def _reset_parameters(self):
         # reference :62-75 (IDOL) / :65-80 (SeqFormer): zero offset weights, bias = the head's unit
@@ -148,13 +155,13 @@ class MSDeformAttnIDOL(_MSDeformAttnBase):
             output = self._try_fused(value, offsets, logits, reference_points, input_spatial_shapes,
                                      input_level_start_index)
             if output is not None:
-                return self.output_proj(output), None, None
+                return self._project_output(output, self.output_proj), None, None
         sampling_offsets, attention_weights = self._offsets_and_weights(query)
         sampling_locations = self._locations(reference_points, sampling_offsets, input_spatial_shapes)
         output = MSDeformAttnFunction.apply(value, input_spatial_shapes, input_level_start_index,
                                             sampling_locations.contiguous(), attention_weights,
                                             self.im2col_step)
-        return self.output_proj(output), sampling_locations, attention_weights
+        return self._project_output(output, self.output_proj), sampling_locations, attention_weights
 
 
 class MSDeformAttnSeqFormer(_MSDeformAttnBase):
@@ -204,13 +211,13 @@ class MSDeformAttnSeqFormer(_MSDeformAttnBase):
                                       input_spatial_shapes, input_level_start_index)
             self.return_samples = keep
             if sampled is not None:
-                return self.output_proj(sampled.view(N, nf, Len_q, -1))
+                return self._project_output(sampled.view(N, nf, Len_q, -1), self.output_proj)
         sampling_offsets, attention_weights = self._offsets_and_weights(query)  # [N,nf,Lq,M,L,P(,2)]
         # the encoder's reference points are shared by the frames: [N, Lq, L, 2] (SeqFormer :107-112)
         locations = self._locations(reference_points[:, None], sampling_offsets, input_spatial_shapes)
         sampled = self._apply_folded(value, locations, attention_weights, input_spatial_shapes,
                                      input_level_start_index)
-        return self.output_proj(sampled)
+        return self._project_output(sampled, self.output_proj)
 
     def decode_forward(self, query, query_box, reference_points, input_flatten, input_spatial_shapes,
                        input_level_start_index, input_padding_mask=None):
@@ -226,7 +233,7 @@ class MSDeformAttnSeqFormer(_MSDeformAttnBase):
                                       input_spatial_shapes, input_level_start_index)
             if sampled is not None:
                 sampled = sampled.view(N, nf, sampled.shape[1], -1)
-                return self.output_proj(sampled), self.output_proj_box(sampled), None, None
+                return self._project_output(sampled, self.output_proj), self._project_output(sampled, self.output_proj_box), None, None
         sampling_offsets, attention_weights = self._offsets_and_weights(query_box)
         if query_box.dim() == 3:
             # first decoder layer: one set of offsets / weights per query, shared by the frames
@@ -238,7 +245,7 @@ class MSDeformAttnSeqFormer(_MSDeformAttnBase):
             locations = self._locations(reference_points, sampling_offsets, input_spatial_shapes)
             weights = attention_weights
         sampled = self._apply_folded(value, locations, weights, input_spatial_shapes, input_level_start_index)
-        output = self.output_proj(sampled)
-        output_box = self.output_proj_box(sampled)
+        output = self._project_output(sampled, self.output_proj)
+        output_box = self._project_output(sampled, self.output_proj_box)
         # the reference returns the LAST frame's locations (the loop variable, :171,217)
         return output, output_box, locations[:, -1], attention_weights
