@@ -382,6 +382,28 @@ int vnx_query_self_attention_backward(int dtype, const void* qkv, const void* in
                                       int row_stride, int grad_row_stride, float p, unsigned long long seed,
                                       const unsigned long long* seed_device, void* hip_stream);
 
+/*
+ * Two element-wise chains of a decoder layer, one launch forward and one backward each (ABI 13; fp32):
+ *  - iterative box refinement (projects/SeqFormer/seqformer/models/deformable_transformer.py:366-380; IDOL :350-365):
+ *      out[r] = sigmoid(delta[r] + inverse_sigmoid(reference[r]))        reference rows of 4 components, or
+ *      out[r] = sigmoid((delta[r][:2] + inverse_sigmoid(reference[r]), delta[r][2:]))     of 2 (the first layer),
+ *    inverse_sigmoid(x) = log(max(clamp(x, 0, 1), eps) / max(1 - clamp(x, 0, 1), eps))  (util/misc.py:493-497).
+ *    delta, out [rows, 4]; reference [rows, ref_components].  Backward: grad_delta [rows, 4] and, unless null, grad_reference
+ *    [rows, ref_components] (the clamps differentiated as autograd does: the gradient passes where min <= x <= max).
+ *  - SeqFormer's temporal weighting of an instance query's frame-level context (:305-312):
+ *      weights = softmax(logits, over the frames);  out[n, q, :] = sum_t weights[n, t, q] x[n, t, q, :]
+ *    x [clips, frames, queries, channels] (channels a multiple of 4, frames <= 16), logits and weights [clips, frames,
+ *    queries], out [clips, queries, channels].  Backward: grad_x (shape of x) and grad_logits from grad_out, x and the weights.
+ */
+int vnx_refine_boxes_forward(int dtype, const void* delta, const void* reference, void* out, long long rows, int ref_components,
+                             float eps, void* hip_stream);
+int vnx_refine_boxes_backward(int dtype, const void* grad_out, const void* out, const void* reference, void* grad_delta,
+                              void* grad_reference, long long rows, int ref_components, float eps, void* hip_stream);
+int vnx_time_weighted_sum_forward(int dtype, const void* x, const void* logits, void* out, void* weights, int clips, int frames,
+                                  int queries, int channels, void* hip_stream);
+int vnx_time_weighted_sum_backward(int dtype, const void* grad_out, const void* x, const void* weights, void* grad_x,
+                                   void* grad_logits, int clips, int frames, int queries, int channels, void* hip_stream);
+
 /* (The kernel-variant override of rounds 1-3 -- a process-wide A/B knob -- is no longer part of this library: it lives in
  *  the development build only, include/vnext_hip_dev.h.  Every call here selects its kernels from its own arguments.) */
 

@@ -47,6 +47,10 @@ SIGNATURES = {
     "vnx_add_dropout_layernorm_forward": (_i, [_i] + [_vp] * 8 + [_ll, _i, ctypes.c_float, ctypes.c_float, ctypes.c_ulonglong, _vp, _vp]),
     "vnx_add_dropout_layernorm_backward": (_i, [_i] + [_vp] * 10 + [_ll, _i, ctypes.c_float, ctypes.c_ulonglong, _vp, _vp]),
     "vnx_bias_relu_dropout_partial_bytes": (_sz, [_i]),
+    "vnx_refine_boxes_forward": (_i, [_i, _vp, _vp, _vp, _ll, _i, ctypes.c_float, _vp]),
+    "vnx_refine_boxes_backward": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _ll, _i, ctypes.c_float, _vp]),
+    "vnx_time_weighted_sum_forward": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "vnx_time_weighted_sum_backward": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "vnx_query_self_attention_forward": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, ctypes.c_float, ctypes.c_ulonglong, _vp, _vp]),
     "vnx_query_self_attention_backward": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, ctypes.c_float,
                                                ctypes.c_ulonglong, _vp, _vp]),

@@ -23,6 +23,7 @@ from torch.nn.init import constant_, normal_, xavier_uniform_
 
 from ..ops.fused_ffn import ffn_block
 from ..ops.fused_norm import add_dropout_norm
+from ..ops.decoder_glue import time_weighted_sum
 from ..ops.modules import MSDeformAttnSeqFormer
 from ..ops.self_attention import query_self_attention_block
 from .transformer_common import ReferenceScaler, flatten_levels, inverse_sigmoid, refined_boxes  # noqa: F401  (inverse_sigmoid: re-exported)
@@ -159,9 +160,10 @@ class DeformableTransformerDecoderLayer(nn.Module):
                                                  self.dropout2_box, self.norm2_box).view(N, nf, num_q, C)
             box_query = tgt_box if query_pos is None else tgt_box + query_pos.unsqueeze(1)
 
+        # (the decoder's cross attention samples around the BOX queries only; its `query` argument is read for nothing --
+        #  ms_deform_attn.py decode_forward, reference :120-217 -- so the reference's `with_pos_embed(tgt, query_pos)` is not evaluated)
         tgt2, tgt2_box, sampling_locations, attention_weights = self.cross_attn(
-            self.with_pos_embed(tgt, query_pos), box_query, reference_points, src, src_spatial_shapes,
-            level_start_index, src_padding_mask)
+            tgt, box_query, reference_points, src, src_spatial_shapes, level_start_index, src_padding_mask)
 
         # (the cross attention returned both projections without their biases: defer_output_bias)
         if tgt_box.dim() == 3:      # first layer: the shared box queries broadcast over the frames
@@ -171,8 +173,9 @@ class DeformableTransformerDecoderLayer(nn.Module):
                                        r_bias=self.cross_attn.output_proj_box.bias)
         tgt_box = self.forward_ffn_box(tgt_box)
 
-        time_weight = F.softmax(self.time_attention_weights(tgt_box), 1)   # softmax over the frames
-        tgt2 = (tgt2 * time_weight).sum(1)      # the weights of a query sum to one: output_proj's bias passes through unchanged
+        # tgt2 = (tgt2 * softmax(time_attention_weights(tgt_box), over the frames)).sum(frames): one launch (ops/decoder_glue.py).
+        # The weights of a query sum to one: output_proj's bias passes through unchanged.
+        tgt2 = time_weighted_sum(tgt2, self.time_attention_weights(tgt_box))
         tgt = add_dropout_norm(tgt, tgt2, self.dropout1, self.norm1, r_bias=self.cross_attn.output_proj.bias)
         return self.forward_ffn(tgt), tgt_box, sampling_locations, attention_weights
 
@@ -261,8 +264,9 @@ class DeformableTransformer(nn.Module):
         memory = self.encoder(memory_in, shapes_t, start_t, valid_ratios, pos, padding, spatial_shapes_list=sizes)
 
         clips, frames, channels = memory.shape[0], memory.shape[1], memory.shape[-1]
-        query_pos = query_embed[:, :channels].unsqueeze(0).expand(clips, -1, -1)
-        tgt = query_embed[:, channels:].unsqueeze(0).expand(clips, -1, -1)
+        # (materialised once: every layer's kernels want dense rows, and an expanded view would be copied per use)
+        query_pos = query_embed[:, :channels].unsqueeze(0).expand(clips, -1, -1).contiguous()
+        tgt = query_embed[:, channels:].unsqueeze(0).expand(clips, -1, -1).contiguous()
         # one learned reference point per query, the same in every frame of the clip to begin with
         init_reference = self.reference_points(query_pos).sigmoid().unsqueeze(1).repeat(1, frames, 1, 1)
         hs, hs_box, inter_references, inter_boxes = self.decoder(tgt, init_reference, memory, shapes_t, start_t,

@@ -7,13 +7,8 @@ from __future__ import annotations
 
 import torch
 
+from ..ops.decoder_glue import inverse_sigmoid, refined_boxes  # noqa: F401  (re-exported: the models import them from here)
 from ..ops.functions import level_tensors
-
-
-def inverse_sigmoid(x, eps=1e-5):
-    """logit with both sides clamped away from 0 (projects/SeqFormer/seqformer/util/misc.py:493-497)"""
-    x = x.clamp(min=0, max=1)
-    return torch.log(x.clamp(min=eps) / (1 - x).clamp(min=eps))
 
 
 def flatten_levels(srcs, masks, pos_embeds, level_embed):
@@ -51,18 +46,6 @@ class ReferenceScaler:
     def __call__(self, reference_points):
         scale = self.xywh if reference_points.shape[-1] == 4 else self.xy
         return reference_points.unsqueeze(-2) * scale
-
-
-def refined_boxes(delta, reference_points):
-    """Iterative box refinement: the layer's box head predicts an offset in logit space.  Boxes: all four components move;
-    points: the centre moves, the predicted size is taken as it is.  -> the refined boxes WITH their graph: they are also
-    the layer's box prediction (the reference's detector computes the same expression a second time for its loss,
-    deformable_detr.py:195-213: `bbox_embed[lvl](hs_box[lvl]) + inverse_sigmoid(reference)`, sigmoid)."""
-    if reference_points.shape[-1] == 4:
-        moved = delta + inverse_sigmoid(reference_points)
-    else:
-        moved = torch.cat([delta[..., :2] + inverse_sigmoid(reference_points), delta[..., 2:]], -1)
-    return moved.sigmoid()
 
 
 def refine_reference(delta, reference_points):
