@@ -193,7 +193,11 @@ def test_config_c1_single_480x640_frame_on_cpu_with_the_oracle_op(monkeypatch):
                                         "MODEL.IDOL.NUM_OBJECT_QUERIES": 20, "MODEL.IDOL.DROPOUT": 0.0})).eval()
     with torch.no_grad():
         x, mask = model._preprocess([torch.rand(3, 480, 640) * 255])
-        srcs, hs, memory, refs, inter_refs = model._encode_decode(x, mask)
+        srcs, hs, memory, refs, inter_refs, loop_boxes = model._encode_decode(x, mask)
+        # the box head of the detector = the refinement loop's own prediction (idol_transformer.py)
+        _, own = model._box_heads(hs, refs, [0])
+    torch.testing.assert_close(loop_boxes[[0]], own, rtol=0, atol=1e-6)
+    assert torch.equal(loop_boxes, inter_refs)
     assert [tuple(s.shape[-2:]) for s in srcs] == [(60, 80), (30, 40), (15, 20), (8, 10)]
     assert tuple(memory.shape) == (1, 6380, 256) and tuple(hs.shape) == (1, 1, 20, 256)
     assert torch.isfinite(memory).all() and torch.isfinite(hs).all()

@@ -124,7 +124,8 @@ class IDOL(nn.Module):
         return x, mask
 
     def _encode_decode(self, x, mask):
-        """-> srcs, hs [Ld, N, Q, C], memory [N, S, C], per-layer pre-sigmoid references"""
+        """-> srcs, hs [Ld, N, Q, C], memory [N, S, C], per-layer pre-sigmoid references, the refined references, and the box
+        predictions of the decoder's refinement loop (what _box_heads would compute again; None if it used other heads)"""
         d = self.detr.detr
         feats = d.backbone(x)
         srcs = [d.input_proj[l](f) for l, f in enumerate(feats)]
@@ -132,12 +133,20 @@ class IDOL(nn.Module):
             srcs.append(d.input_proj[l](feats[-1] if l == len(feats) else srcs[-1]))
         masks = [F.interpolate(mask[None].float(), size=s.shape[-2:]).to(torch.bool)[0] for s in srcs]
         poss = [sine_position(mk, s.shape[1] // 2).to(s.dtype) for s, mk in zip(srcs, masks)]
-        hs, memory, init_ref, inter_refs, _, _, _ = d.transformer(srcs, masks, poss, d.query_embed.weight)
+        hs, memory, init_ref, inter_refs, _, inter_boxes, _ = d.transformer(srcs, masks, poss, d.query_embed.weight)
         refs = [inverse_sigmoid(init_ref if l == 0 else inter_refs[l - 1]) for l in range(hs.shape[0])]
-        return srcs, hs, memory, refs, inter_refs
+        if d.transformer.decoder.bbox_embed is not d.bbox_embed:
+            inter_boxes = None        # the decoder's loop did not use the detector's box heads: they run in _box_heads
+        return srcs, hs, memory, refs, inter_refs, inter_boxes        # inter_boxes [Ld, N, Q, 4] with their graph | None
 
-    def _box_heads(self, hs, refs, layers):
+    def _box_heads(self, hs, refs, layers, loop_boxes=None):
+        """Class logits and boxes of the decoder layers `layers`.  loop_boxes [Ld, ...]: the box predictions the decoder's
+        refinement loop made with these box heads and references (idol_transformer.py) -- then only the class heads run."""
         d = self.detr.detr
+        if loop_boxes is not None:
+            layers = list(layers)      # (plain indexing: a list index would copy an index tensor to the device -- not under capture)
+            picked = loop_boxes if layers == list(range(loop_boxes.shape[0])) else torch.stack([loop_boxes[l] for l in layers])
+            return torch.stack([d.class_embed[l](hs[l]) for l in layers]), picked
         logits, boxes = [], []
         for l in layers:
             tmp = d.bbox_embed[l](hs[l])
@@ -188,9 +197,10 @@ class IDOL(nn.Module):
         frames = [f for video in batched_inputs for f in video["image"]]
         sizes = [tuple(f.shape[-2:]) for f in frames][0::2]
         x, mask = self._preprocess(frames)
-        srcs, hs, memory, refs, inter_refs = self._encode_decode(x, mask)
+        srcs, hs, memory, refs, inter_refs, inter_boxes = self._encode_decode(x, mask)
         Ld, bz = hs.shape[0], len(det_t)
-        logits, boxes = self._box_heads(hs[:, 0::2], [r[0::2] for r in refs], range(Ld))      # key frames
+        loop_boxes = None if inter_boxes is None else inter_boxes[:, 0::2]
+        logits, boxes = self._box_heads(hs[:, 0::2], [r[0::2] for r in refs], range(Ld), loop_boxes)      # key frames
         indices_list, matched = self.criterion.matcher.match_all_layers(logits, boxes, det_t)
         feats = self._mask_features([s[0::2] for s in srcs], memory[0::2])
         # the selected queries of every decoder layer on every key frame: one gather, one controller
@@ -252,9 +262,9 @@ class IDOL(nn.Module):
     def _chunk_trunk(self, x, mask):
         """Padded frames -> (logits [F,Q,K], boxes [F,Q,4], query states, pre-sigmoid reference of the
         last decoder layer, stride-8 mask features): the shape-static, sync-free part of inference."""
-        srcs, hs, memory, refs, _ = self._encode_decode(x, mask)
+        srcs, hs, memory, refs, _, inter_boxes = self._encode_decode(x, mask)
         last = hs.shape[0] - 1
-        logits, boxes = self._box_heads(hs, refs, [last])
+        logits, boxes = self._box_heads(hs, refs, [last], inter_boxes)
         return logits[0], boxes[0], hs[last], refs[last], self._mask_features(srcs, memory)
 
     def _chunk_trunk_graphed(self, stack):

@@ -24,7 +24,7 @@ from ..ops.self_attention import query_self_attention_block
 from ..ops.modules import MSDeformAttnIDOL
 from .seqformer_transformer import DeformableTransformerEncoder as _ClipEncoder
 from .seqformer_transformer import _get_activation_fn, _get_clones
-from .transformer_common import ReferenceScaler, flatten_levels, refine_reference
+from .transformer_common import ReferenceScaler, flatten_levels, refined_boxes
 
 
 class DeformableTransformerEncoderLayer(nn.Module):
@@ -106,11 +106,13 @@ class DeformableTransformerDecoder(nn.Module):
     def forward(self, tgt, reference_points, src, src_spatial_shapes, src_level_start_index, src_valid_ratios,
                 query_pos=None, src_padding_mask=None):
         """tgt [N, Q, C], reference_points [N, Q, 2] -> stacked per-layer (queries [Ld, N, Q, C], references [Ld, N, Q, 4],
-        kept sampling points [Ld, N, Q, 30, 2] | None), or the last layer's (queries, references)."""
+        kept sampling points [Ld, N, Q, 30, 2] | None, the layers' box predictions [Ld, N, Q, 4] | None), or the last layer's
+        (queries, references).  The box predictions are the refined references before they are detached: what the detector's
+        box head would compute again (projects/IDOL/idol/models/deformable_detr.py:214-232; see seqformer_transformer.py)."""
         scaled = ReferenceScaler(src_valid_ratios, extra_axes=1)       # [N, 1, L, 2|4] against [N, Q, 1, 2|4]
         unscale = src_valid_ratios[:, None, None, None, :, :]
         queries = tgt
-        kept, kept_refs, kept_samples = [], [], []
+        kept, kept_refs, kept_samples, kept_boxes = [], [], [], []
         for lid, layer in enumerate(self.layers):
             queries, loc, w = layer(queries, query_pos, scaled(reference_points), src, src_spatial_shapes,
                                     src_level_start_index, src_padding_mask)
@@ -119,13 +121,16 @@ class DeformableTransformerDecoder(nn.Module):
                 heaviest = w.flatten(2).topk(30, dim=2)[1]
                 kept_samples.append(torch.gather(flat, 2, heaviest.unsqueeze(-1).expand(-1, -1, -1, 2)))
             if self.bbox_embed is not None:
-                reference_points = refine_reference(self.bbox_embed[lid](queries), reference_points)
+                boxes = refined_boxes(self.bbox_embed[lid](queries), reference_points)
+                reference_points = boxes.detach()
+                kept_boxes.append(boxes)
             if self.return_intermediate:
                 kept.append(queries)
                 kept_refs.append(reference_points)
         if not self.return_intermediate:
             return queries, reference_points
-        return torch.stack(kept), torch.stack(kept_refs), (torch.stack(kept_samples) if kept_samples else None)
+        return (torch.stack(kept), torch.stack(kept_refs), (torch.stack(kept_samples) if kept_samples else None),
+                (torch.stack(kept_boxes) if kept_boxes else None))
 
 
 class DeformableTransformer(nn.Module):
@@ -175,7 +180,8 @@ class DeformableTransformer(nn.Module):
 
     def forward(self, srcs, masks, pos_embeds, query_embed=None):
         """srcs: per level [N, C, H_l, W_l]; -> (hs [Ld, N, Q, C], memory [N, S, C], init_reference
-        [N, Q, 2], inter_references [Ld, N, Q, 4], inter_samples | None, None, None)  (:135-198)"""
+        [N, Q, 2], inter_references [Ld, N, Q, 4], inter_samples | None, the layers' box predictions (with their graph) | None,
+        None)  (:135-198)"""
         assert query_embed is not None
         memory_in, padding, pos, shapes_t, start_t, sizes = flatten_levels(srcs, masks, pos_embeds, self.level_embed)
         valid_ratios = torch.stack([self.get_valid_ratio(m) for m in masks], 1)
@@ -184,6 +190,6 @@ class DeformableTransformer(nn.Module):
         query_pos = query_embed[:, :channels].unsqueeze(0).expand(images, -1, -1)
         tgt = query_embed[:, channels:].unsqueeze(0).expand(images, -1, -1)
         init_reference = self.reference_points(query_pos).sigmoid()
-        hs, inter_references, inter_samples = self.decoder(tgt, init_reference, memory, shapes_t, start_t, valid_ratios,
-                                                           query_pos, padding)
-        return hs, memory, init_reference, inter_references, inter_samples, None, None
+        hs, inter_references, inter_samples, inter_boxes = self.decoder(tgt, init_reference, memory, shapes_t, start_t,
+                                                                        valid_ratios, query_pos, padding)
+        return hs, memory, init_reference, inter_references, inter_samples, inter_boxes, None
