@@ -211,3 +211,55 @@ def test_bad_arguments_are_reported():
     st = lib.vnx_query_self_attention_forward(_lib.VNX_F32, None, None, o.data_ptr(), l.data_ptr(), 1, 4, 2, 32, 192, 0.0, 0,
                                               None, _lib.current_stream(t))
     assert st == 1
+
+
+@pytest.mark.gpu
+def test_captured_training_replays_draw_fresh_masks_and_backward_follows():
+    """As for the other fused dropout sites (tests/test_fused_norm.py): inside a `step_scope` a captured forward + backward of
+    the attention draws a fresh mask on every replay (a device-side step seed bumped by a captured add), and the backward of
+    a replay recomputes the mask of ITS forward.  Q = 32 with the mask-revealing weights of the read-back test above."""
+    from vnext_amd.ops.fused_norm import step_scope
+    B, Q, C, H, p = 2, 32, 64, 2, 0.25
+    probe = _mha(C, H, p=p, train=True, device=DEV)
+    with torch.no_grad():
+        probe.in_proj_weight.zero_()
+        probe.in_proj_bias.zero_()
+        for h in range(H):
+            probe.in_proj_weight[2 * C + h * 32:2 * C + (h + 1) * 32, :32] = torch.eye(32, device=DEV)
+        probe.out_proj.weight.copy_(torch.eye(C, device=DEV))
+        probe.out_proj.bias.zero_()
+    x0 = torch.zeros(B, Q, C, device=DEV)
+    x0[:, torch.arange(Q), torch.arange(Q)] = 1.0
+
+    class Site(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.mha = probe
+
+        def forward(self, xx):
+            with step_scope(xx.device):
+                return query_self_attention(xx, None, self.mha)
+
+    site = Site().train()
+    graphed = torch.cuda.make_graphed_callables(site, (x0.clone().requires_grad_(True),))
+    go = torch.randn(B, Q, C, device=DEV)
+    outs, grads = [], []
+    for _ in range(3):
+        xi = x0.clone().requires_grad_(True)
+        y = graphed(xi)
+        y.backward(go)
+        torch.cuda.synchronize()
+        outs.append(y.detach().clone())
+        grads.append(xi.grad.clone())
+    masks = [(o.view(B, Q, H, 32).permute(0, 2, 1, 3)[..., :Q] * Q * (1 - p)).round() for o in outs]
+    for m in masks:
+        assert set(m.unique().tolist()) <= {0.0, 1.0} and abs(1.0 - float(m.mean()) - p) < 0.05
+    assert not torch.equal(masks[0], masks[1]) and not torch.equal(masks[1], masks[2])
+    # the backward of replay i used mask i: with uniform probabilities and identity projections
+    #   out[b, i, h, :] = sum_j M_ij v_j / ((1 - p) Q),  v = x Wv^T  =>  grad_x = Wv^T-projected sum_i M_ij go_i / ((1 - p) Q)
+    for m, g in zip(masks, grads):
+        go_h = go.view(B, Q, H, 32).permute(0, 2, 1, 3)                                     # [B, H, Q(i), 32]
+        dv = (m.transpose(-1, -2) / ((1 - p) * Q)) @ go_h                                 # [B, H, Q(j), 32]
+        want = dv.sum(1)                                                                   # every head's Wv block reads x[:, :, :32]
+        torch.testing.assert_close(g[..., :32], want, rtol=0, atol=2e-6)
+        assert float(g[..., 32:].abs().max()) == 0.0
