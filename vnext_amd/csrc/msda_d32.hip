@@ -588,6 +588,209 @@ msda_fwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
   stamp_end(stamps);
 }
 
+// ---- forward of calls with MANY queries (the encoders'): the coarse levels staged whole in LDS --------------------------------
+// The gather kernel above is bound by what a CU's vector L1 delivers -- 64 B per clock; a sample is four 128-byte rows: 1.67 GB
+// at encoder-360p, 48.5 us at 2.1 GHz of a 55-us launch -- while the LDS, which delivers twice that, sits
+// idle.  The two LDS-staged forwards of rounds 2-3 (tools/experiments/msda_tile) staged data-dependent WINDOWS of every level and
+// paid for them in instructions (bounding boxes, far taps, window bookkeeping: 5.8-7.3 vector instructions per sample against
+// 4.9).  This kernel stages no window: every level of the pyramid receives the same number of taps, but the two coarsest
+// ones are 6 % of the pixels -- 300 rows of one head, 38 KB in fp32, at 360p -- so a workgroup copies them WHOLE into LDS
+// once and then walks many query tiles of its (batch, head): the taps of the staged levels are `ds_read_b128` at an offset the
+// decode computes exactly as it computes the global one (zero padding = one zero row), the taps of the fine levels are the
+// gathers of the kernel above.  No boxes, no far path, no per-tile staging, the same instruction count per sample -- and half
+// of the bytes leave the L1's queue for a pipe that was unused.
+// Which levels are staged is decided on the device (the host knows S, not the level sizes): the longest suffix of the packed
+// levels that fits kSlabRowsCap rows; none (unpacked levels, or a pyramid whose coarsest level is larger): every tap is a gather.
+// Workgroup = 8 waves, a wave = 8 queries x 8 lanes (one 8-lane set walks all 16 samples of its query: no cross-set sum);
+// LDS = slab + zero row + the waves' sample records: 76 KB, two workgroups per CU.  fp32 values, 4 levels x 4 points.
+constexpr int kSlabWaves = 8, kSlabQpw = 8, kSlabRowsCap = 320;
+constexpr int kSlabEnt = kSlabQpw * 17;                                             // records per wave: [8 queries][16 + 1]
+constexpr size_t kSlabRecBytes = size_t(kSlabWaves) * 2 * kSlabEnt * 16;            // offsets (uint4) + weights (float4)
+constexpr size_t kSlabLdsBytes = size_t(kSlabRowsCap + 1) * 128 + kSlabRecBytes + 64;
+
+template <typename TL, bool FUSED>
+__global__ void __launch_bounds__(64 * kSlabWaves, 2 * kSlabWaves / 4)      // two workgroups per CU: 4 waves per SIMD, <= 128 VGPRs
+msda_fwd_slab_kernel(const float* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
+                     const TL* __restrict__ loc, const TL* __restrict__ attn, float* __restrict__ out, MsdaDims d,
+                     int parts, unsigned long long* stamps, FusedArgs fa) {
+  stamp_begin(stamps);
+  constexpr int D = 32, LP = 16, kRowBytes = 128;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* slab = smem;                                                        // [rows + 1][128 B]
+  uint4_t* rec_base = reinterpret_cast<uint4_t*>(smem + size_t(kSlabRowsCap + 1) * kRowBytes);
+  int* s_lvl = reinterpret_cast<int*>(smem + size_t(kSlabRowsCap + 1) * kRowBytes + kSlabRecBytes);      // [4][4]: H, W, start, -
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int x = blockIdx.x % d.M, rest = blockIdx.x / d.M, b = rest % d.B, part = rest / d.B;
+  const int m = (x + b) % d.M;      // head <-> XCD map rotating with the batch element, as the gather kernel
+
+  // ---- the level table; which levels are staged ----
+  if (tid < 4) {
+    s_lvl[4 * tid] = int(shapes[2 * tid]); s_lvl[4 * tid + 1] = int(shapes[2 * tid + 1]); s_lvl[4 * tid + 2] = int(lsi[tid]);
+  }
+  __syncthreads();
+  int first_staged = 4, slab_first = d.S;      // levels [first_staged, 4) live in LDS, rows [slab_first, S) of the map
+  {
+    bool packed = true;
+    int running = 0;
+#pragma unroll
+    for (int l = 0; l < 4; ++l) { packed = packed && s_lvl[4 * l + 2] == running; running += s_lvl[4 * l] * s_lvl[4 * l + 1]; }
+    packed = packed && running == d.S;
+    if (packed) {
+#pragma unroll
+      for (int l = 3; l >= 0; --l)
+        if (d.S - s_lvl[4 * l + 2] <= kSlabRowsCap) { first_staged = l; slab_first = s_lvl[4 * l + 2]; }
+    }
+  }
+  first_staged = __builtin_amdgcn_readfirstlane(first_staged);
+  slab_first = __builtin_amdgcn_readfirstlane(slab_first);
+  const int n_slab = d.S - slab_first;
+  {
+    const float* src = value + ((int64_t(b) * d.S + slab_first) * d.M + m) * D;
+    for (int i = tid; i < n_slab * 8; i += 64 * kSlabWaves)
+      *reinterpret_cast<float4_t*>(slab + (i >> 3) * kRowBytes + (i & 7) * 16) =
+          *reinterpret_cast<const float4_t*>(src + int64_t(i >> 3) * d.M * D + (i & 7) * 4);
+    if (tid < 8) *reinterpret_cast<float4_t*>(slab + n_slab * kRowBytes + tid * 16) = float4_t{0.f, 0.f, 0.f, 0.f};
+  }
+  __syncthreads();
+  const uint32_t zero_row = uint32_t(n_slab) * kRowBytes;
+
+  uint4_t* s_off = rec_base + size_t(wave) * 2 * kSlabEnt;
+  float4_t* s_wt = reinterpret_cast<float4_t*>(s_off + kSlabEnt);
+  const int pixel_bytes = d.M * kRowBytes;
+  const float* head_base = value + (int64_t(b) * d.S * d.M + m) * D;
+  const __amdgpu_buffer_rsrc_t rsrc = uniform_rsrc(head_base, uint32_t((int64_t(d.S) * d.M - m) * kRowBytes));
+  const int ch = lane & 7, qi2 = lane >> 3;
+  const uint32_t lane_off = uint32_t(ch * 16);
+
+  const int n_tiles = (d.Lq + kSlabWaves * kSlabQpw - 1) / (kSlabWaves * kSlabQpw);
+  for (int t = part; t < n_tiles; t += parts) {
+    const int q0 = (t * kSlabWaves + wave) * kSlabQpw;
+    // ---- phase 1: one (query, sample) per lane and step (cuh:253-298) ----
+#pragma unroll
+    for (int e0 = 0; e0 < kSlabQpw * LP; e0 += 64) {
+      const int e = e0 + lane, qi = e >> 4, p = e & 15, l = p >> 2;
+      const int q = q0 + qi;
+      uint4_t o4 = {kTapOutside, kTapOutside, kTapOutside, kTapOutside};
+      float4_t w4 = {0.f, 0.f, 0.f, 0.f};
+      const bool staged = l >= first_staged;
+      if (staged) o4 = uint4_t{zero_row, zero_row, zero_row, zero_row};
+      const int64_t wi = ((int64_t(b) * d.Lq + q) * d.M + m) * LP + p;
+      const int H = s_lvl[4 * l], W = s_lvl[4 * l + 1], start = s_lvl[4 * l + 2];
+      float sx = 0.f, sy = 0.f, a = 0.f;
+      if constexpr (FUSED) {
+        float gx, gy;
+        fused_decode<TL>(loc, attn, fa, wi, b, q, l, q < d.Lq ? H : 1, q < d.Lq ? W : 1, d, q < d.Lq, sx, sy, a, gx, gy);
+      } else if (q < d.Lq) {
+        sx = to_acc(loc[2 * wi]); sy = to_acc(loc[2 * wi + 1]); a = to_acc(attn[wi]);
+      }
+      if (q < d.Lq) {
+        const float h = sy * float(H) - 0.5f, w = sx * float(W) - 0.5f;
+        if (h > -1.f && w > -1.f && h < float(H) && w < float(W)) {
+          const float hf = floorf(h), wf = floorf(w);
+          const int h0 = int(hf), w0 = int(wf);
+          const float lh = h - hf, lw = w - wf, hh = 1.f - lh, hw = 1.f - lw;
+          const bool top = h0 >= 0, bot = h0 + 1 <= H - 1, lef = w0 >= 0, rig = w0 + 1 <= W - 1;
+          // a pixel's row: byte offset into the head's rows of `value` (gathers) or into the slab (staged levels)
+          const uint32_t pb = staged ? uint32_t(kRowBytes) : uint32_t(pixel_bytes);
+          const uint32_t none = staged ? zero_row : kTapOutside;
+          const uint32_t o00 = uint32_t(__mul24((staged ? start - slab_first : start) + __mul24(h0, W) + w0, int(pb)));  // mod 2^32 on purpose
+          const uint32_t row_b = __umul24(uint32_t(W), pb);
+          o4.x = (top && lef) ? o00 : none;
+          o4.y = (top && rig) ? o00 + pb : none;
+          o4.z = (bot && lef) ? o00 + row_b : none;
+          o4.w = (bot && rig) ? o00 + row_b + pb : none;
+          w4.x = a * (hh * hw); w4.y = a * (hh * lw); w4.z = a * (lh * hw); w4.w = a * (lh * lw);
+        }
+      }
+      s_off[qi * 17 + p] = o4;
+      s_wt[qi * 17 + p] = w4;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- phase 2: an 8-lane set walks the 16 samples of its query, level by level: gathers or LDS reads ----
+    const uint4_t* g_off = s_off + qi2 * 17;
+    const float4_t* g_wt = s_wt + qi2 * 17;
+    float4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int l = 0; l < 4; ++l) {      // (not unrolled: one level's sixteen rows in registers at a time)
+      uint4_t o[4];
+      float4_t w[4];
+      float4_t v[4][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { o[j] = g_off[4 * l + j]; w[j] = g_wt[4 * l + j]; }
+      if (l < first_staged) {      // uniform
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[j][0] = load_tap<float>(rsrc, o[j].x + lane_off);
+          v[j][1] = load_tap<float>(rsrc, o[j].y + lane_off);
+          v[j][2] = load_tap<float>(rsrc, o[j].z + lane_off);
+          v[j][3] = load_tap<float>(rsrc, o[j].w + lane_off);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[j][0] = *reinterpret_cast<const float4_t*>(slab + o[j].x + lane_off);
+          v[j][1] = *reinterpret_cast<const float4_t*>(slab + o[j].y + lane_off);
+          v[j][2] = *reinterpret_cast<const float4_t*>(slab + o[j].z + lane_off);
+          v[j][3] = *reinterpret_cast<const float4_t*>(slab + o[j].w + lane_off);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc += w[j].x * v[j][0];
+        acc += w[j].y * v[j][1];
+        acc += w[j].z * v[j][2];
+        acc += w[j].w * v[j][3];
+      }
+    }
+    const int q = q0 + qi2;
+    if (q < d.Lq) store_row4<float>(out + ((int64_t(b) * d.Lq + q) * d.M + m) * D + ch * 4, acc);
+    __builtin_amdgcn_wave_barrier();      // this tile's records have been read: the next decode may overwrite them
+  }
+  stamp_end(stamps);
+}
+
+// the slab kernel takes a call when it is built for it (fp32 values, 4 levels x 4 points) and the call has enough queries per
+// (batch, head) for a workgroup's slab copy to pay (an encoder's; development build: variant 730 forces, 731 forbids)
+static bool use_slab_forward(int vdt, int ldt, const MsdaDims& d, int variant) {
+  if (vdt != VNX_F32 || (ldt != VNX_F32 && ldt != VNX_BF16 && ldt != VNX_F16) || d.L != 4 || d.P != 4 || d.D != 32) return false;
+  if (int64_t(d.S) * d.M * 128 >= (int64_t(1) << 31) || d.S >= (1 << 23)) return false;
+  if (variant == 731) return false;
+  return variant == 730 || d.Lq >= 2048;
+}
+
+template <typename TL>
+static int launch_fwd_slab(const void* value, const int64_t* shapes, const int64_t* lsi, const void* loc, const void* attn,
+                           void* out, const MsdaDims& d, const FusedArgs* fa, hipStream_t stream) {
+  const int n_tiles = (d.Lq + kSlabWaves * kSlabQpw - 1) / (kSlabWaves * kSlabQpw);
+  int parts = 512 / (d.B * d.M);      // one round of resident workgroups (two per CU) when the call allows it
+  parts = parts < 1 ? 1 : parts > n_tiles ? n_tiles : parts;
+  const int64_t blocks = int64_t(parts) * d.B * d.M;
+  static thread_local int raised_on[2] = {-1, -1};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const int which = fa != nullptr;
+  if (raised_on[which] != dev) {
+    const void* fn = fa ? reinterpret_cast<const void*>(&msda_fwd_slab_kernel<TL, true>)
+                        : reinterpret_cast<const void*>(&msda_fwd_slab_kernel<TL, false>);
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(kSlabLdsBytes)) != hipSuccess)
+      return check_launch("msda_fwd_slab (LDS limit)");
+    raised_on[which] = dev;
+  }
+  if (fa)
+    hipLaunchKernelGGL((msda_fwd_slab_kernel<TL, true>), dim3(uint32_t(blocks)), dim3(64 * kSlabWaves), kSlabLdsBytes, stream,
+                       (const float*)value, shapes, lsi, (const TL*)loc, (const TL*)attn, (float*)out, d, parts,
+                       take_stamp_region(kStampFwd, blocks), *fa);
+  else
+    hipLaunchKernelGGL((msda_fwd_slab_kernel<TL, false>), dim3(uint32_t(blocks)), dim3(64 * kSlabWaves), kSlabLdsBytes, stream,
+                       (const float*)value, shapes, lsi, (const TL*)loc, (const TL*)attn, (float*)out, d, parts,
+                       take_stamp_region(kStampFwd, blocks), FusedArgs{});
+  return check_launch("msda_fwd_slab");
+}
+
 struct FwdCfg { int qpw; int wpb; };
 
 static FwdCfg pick_fwd_cfg(const MsdaDims& d, int variant) {
@@ -697,6 +900,8 @@ bool msda_d32_fwd_supported(int vdt, int ldt, const MsdaDims& d) {
 int msda_forward_d32(int vdt, int ldt, const void* value, const int64_t* shapes,
                      const int64_t* lsi, const void* loc, const void* attn, void* out, MsdaDims d,
                      int variant, hipStream_t stream) {
+  if (use_slab_forward(vdt, ldt, d, variant) && ldt == VNX_F32)
+    return launch_fwd_slab<float>(value, shapes, lsi, loc, attn, out, d, nullptr, stream);
   if (vdt == VNX_F32) return launch_fwd<float, float>(value, shapes, lsi, loc, attn, out, d, variant, stream);
   if (vdt == VNX_BF16 && ldt == VNX_F32) return launch_fwd<bf16_t, float>(value, shapes, lsi, loc, attn, out, d, variant, stream);
   if (vdt == VNX_BF16 && ldt == VNX_BF16) return launch_fwd<bf16_t, bf16_t>(value, shapes, lsi, loc, attn, out, d, variant, stream);
@@ -1551,6 +1756,10 @@ static int fused_dispatch(bool backward, const void* value, const int64_t* shape
                           const void* raw_off, const void* raw_logit, const void* grad_out, void* out_or_grad_off,
                           void* grad_logit, const MsdaDims& d, void* records, void* tile_summary, const FusedArgs& fa,
                           hipStream_t stream) {
+  if constexpr (sizeof(TV) == 4 && sizeof(TL) == 4) {      // encoder calls: the coarse levels staged in LDS (msda_fwd_slab_kernel)
+    if (!backward && use_slab_forward(VNX_F32, VNX_F32, d, kernel_variant()))
+      return launch_fwd_slab<float>(value, shapes, lsi, raw_off, raw_logit, out_or_grad_off, d, &fa, stream);
+  }
   const FwdCfg c = pick_fwd_cfg(d, 0);
 #define VNX_CASE(Q, W)                                                                                   \
   if (c.qpw == Q && c.wpb == W)                                                                          \
