@@ -12,9 +12,9 @@ K=$GRAFT_REPO_ROOT/tools/kbench.bin
 cd /tmp && export TMPDIR=/tmp
 PMC_A="SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_SALU"
 PMC_B="SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"
-for c in "dec360 U" "enc360 M"; do
+for c in "dec360 U bwd" "enc360 M both"; do      # (encoder shape: the forward too -- msda_fwd_slab_kernel, round 5)
   set -- $c
-  ARGS="--shape $1 --dist $2 --op bwd --variants 0 --cold-only"
+  ARGS="--shape $1 --dist $2 --op $3 --variants 0 --cold-only"
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o kt_$1 -- $K $ARGS --inner 8 --reps 5 > $OUT/kt_$1.log 2>&1
   timeout 300 rocprofv3 --pmc $PMC_A --output-format csv -d $OUT -o pmcA_$1 -- $K $ARGS --inner 2 --reps 2 > /dev/null 2>&1
   timeout 300 rocprofv3 --pmc $PMC_B --output-format csv -d $OUT -o pmcB_$1 -- $K $ARGS --inner 2 --reps 2 > /dev/null 2>&1

@@ -8,7 +8,7 @@ import os
 import sys
 
 src, dst = sys.argv[1], sys.argv[2]
-KERNELS = ("msda_bwd_pair_kernel", "msda_bwd_d32_kernel", "msda_bwd_gv_direct_kernel", "msda_bwd_gv_sel_kernel", "msda_bwd_gv_tiles_kernel", "gv_split_finish_kernel", "dynamic_mask_head_bwd_kernel",
+KERNELS = ("msda_fwd_slab_kernel", "msda_bwd_slab_kernel", "msda_fwd_d32_kernel", "msda_bwd_pair_kernel", "msda_bwd_d32_kernel", "msda_bwd_gv_direct_kernel", "msda_bwd_gv_sel_kernel", "msda_bwd_gv_tiles_kernel", "gv_split_finish_kernel", "dynamic_mask_head_bwd_kernel",
            "dynamic_mask_head_runs_kernel", "zero3_kernel")
 SAMPLES = {"dec360": 128 * 5 * 300, "enc360": 128 * 5 * 5100}
 GHZ = 2.0          # the clock the derived shares assume (as in r03_forward_encoder360_pmc.csv)

@@ -710,6 +710,15 @@ msda_fwd_slab_kernel(const float* __restrict__ value, const int64_t* __restrict_
     __builtin_amdgcn_wave_barrier();
 
     // ---- phase 2: an 8-lane set walks the 16 samples of its query, level by level: gathers or LDS reads ----
+    // (Counters at encoder-360p, profiles/r05_backward_pmc.csv: 3.1 vector instructions per sample -- the gather kernel has 4.9 --
+    //  46 % of the issue slots, LDS 45 % busy with 17 % conflicts, 53 % of the wave cycles waiting.  Measured on top of this
+    //  form and dropped: the staged level's samples read and used while the gathered level's rows are in flight (44.9 against
+    //  42.6 us: the second path costs the first its registers), eight steps of two samples with the next step's rows requested
+    //  before this step's are used (spills), the rows of a sample's left / right taps ordered by row parity so that the two
+    //  sets the LDS serves together never meet in a bank (43.2: the conflicts are not what the kernel waits for); and the
+    //  gather kernel's lane map -- 4 queries per wave, the lower half of a wave gathering levels 0, 1 while the upper half reads
+    //  levels 2, 3 from LDS, 12 waves per workgroup, six per SIMD -- 61.6 us: each kind of load is issued with half of its
+    //  lanes masked.)
     const uint4_t* g_off = s_off + qi2 * 17;
     const float4_t* g_wt = s_wt + qi2 * 17;
     float4_t acc = {0.f, 0.f, 0.f, 0.f};
@@ -762,12 +771,23 @@ static bool use_slab_forward(int vdt, int ldt, const MsdaDims& d, int variant) {
   return variant == 730 || d.Lq >= 2048;
 }
 
+// Workgroups per (batch, head): whole ROUNDS of resident workgroups (two per CU = 512) -- a partly filled last round leaves
+// CUs idle for a whole workgroup's life (560 workgroups at encoder-360p: 54.6 us against 42.6 with 480) -- and as many rounds
+// (1, 2, 4, ...) as bring a workgroup to twelve tiles or fewer: every workgroup copies the slab once, but on the largest
+// calls shorter workgroups pack the launch's tail better (encoder-720p B = 5: one round = 25 tiles each 247 us, four rounds
+// 231-234; B = 2, 9.6 tiles each: 85 us with one round, 87 with two).
+static int slab_parts(const MsdaDims& d, int n_tiles) {
+  const int per_round = 512 / (d.B * d.M) > 0 ? 512 / (d.B * d.M) : 1;
+  int parts = per_round;
+  while (parts < n_tiles && (n_tiles + parts - 1) / parts > 12) parts *= 2;
+  return parts > n_tiles ? n_tiles : parts;
+}
+
 template <typename TL>
 static int launch_fwd_slab(const void* value, const int64_t* shapes, const int64_t* lsi, const void* loc, const void* attn,
                            void* out, const MsdaDims& d, const FusedArgs* fa, hipStream_t stream) {
   const int n_tiles = (d.Lq + kSlabWaves * kSlabQpw - 1) / (kSlabWaves * kSlabQpw);
-  int parts = 512 / (d.B * d.M);      // one round of resident workgroups (two per CU) when the call allows it
-  parts = parts < 1 ? 1 : parts > n_tiles ? n_tiles : parts;
+  const int parts = slab_parts(d, n_tiles);
   const int64_t blocks = int64_t(parts) * d.B * d.M;
   static thread_local int raised_on[2] = {-1, -1};
   int dev = 0;
