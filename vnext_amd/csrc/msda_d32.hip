@@ -664,8 +664,33 @@ msda_fwd_slab_kernel(const float* __restrict__ value, const int64_t* __restrict_
   const uint32_t lane_off = uint32_t(ch * 16);
 
   const int n_tiles = (d.Lq + kSlabWaves * kSlabQpw - 1) / (kSlabWaves * kSlabQpw);
+  // The locations and weights of a tile's two decode passes are REQUESTED one tile ahead (plain calls, fp32: six registers) --
+  // after the previous tile's decode, before its gathers -- so that a tile starts with its samples in hand instead of with a
+  // trip to memory: the kernel is bound by its waves' waits (four per SIMD), not by a pipe.  (asm: the compiler would sink the
+  // loads to their use; a wave's loads return in order, so the waits it generates for the gathers behind them stay valid.)
+  constexpr bool kAhead = !FUSED && sizeof(TL) == 4;
+  float2_t pre_xy[2] = {{0.f, 0.f}, {0.f, 0.f}};
+  float pre_a[2] = {0.f, 0.f};
+  auto request_samples = [&](int tile) {
+    if constexpr (kAhead) {
+      const int tq0 = (tile * kSlabWaves + wave) * kSlabQpw;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int e = 64 * k + lane, q = tq0 + (e >> 4);
+        const int qc = q < d.Lq ? q : d.Lq - 1;      // clamped: the loads are unconditional
+        const int64_t wi = ((int64_t(b) * d.Lq + qc) * d.M + m) * LP + (e & 15);
+        asm volatile("global_load_dwordx2 %0, %2, off\n\tglobal_load_dword %1, %3, off"
+                     : "=&v"(pre_xy[k]), "=&v"(pre_a[k])
+                     : "v"(reinterpret_cast<const float*>(loc) + 2 * wi), "v"(reinterpret_cast<const float*>(attn) + wi)
+                     : "memory");
+      }
+    }
+  };
+  if (part < n_tiles) request_samples(part);
   for (int t = part; t < n_tiles; t += parts) {
     const int q0 = (t * kSlabWaves + wave) * kSlabQpw;
+    if constexpr (kAhead)
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(pre_xy[0]), "+v"(pre_xy[1]), "+v"(pre_a[0]), "+v"(pre_a[1]) : : "memory");
     // ---- phase 1: one (query, sample) per lane and step (cuh:253-298) ----
 #pragma unroll
     for (int e0 = 0; e0 < kSlabQpw * LP; e0 += 64) {
@@ -681,6 +706,8 @@ msda_fwd_slab_kernel(const float* __restrict__ value, const int64_t* __restrict_
       if constexpr (FUSED) {
         float gx, gy;
         fused_decode<TL>(loc, attn, fa, wi, b, q, l, q < d.Lq ? H : 1, q < d.Lq ? W : 1, d, q < d.Lq, sx, sy, a, gx, gy);
+      } else if constexpr (kAhead) {
+        sx = pre_xy[e0 >> 6].x; sy = pre_xy[e0 >> 6].y; a = pre_a[e0 >> 6];
       } else if (q < d.Lq) {
         sx = to_acc(loc[2 * wi]); sy = to_acc(loc[2 * wi + 1]); a = to_acc(attn[wi]);
       }
@@ -708,6 +735,7 @@ msda_fwd_slab_kernel(const float* __restrict__ value, const int64_t* __restrict_
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    if (t + parts < n_tiles) request_samples(t + parts);      // uniform
 
     // ---- phase 2: an 8-lane set walks the 16 samples of its query, level by level: gathers or LDS reads ----
     // (Counters at encoder-360p, profiles/r05_backward_pmc.csv: 3.1 vector instructions per sample -- the gather kernel has 4.9 --
