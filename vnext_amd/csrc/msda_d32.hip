@@ -793,7 +793,7 @@ msda_fwd_slab_kernel(const float* __restrict__ value, const int64_t* __restrict_
 // the slab kernel takes a call when it is built for it (fp32 values, 4 levels x 4 points) and the call has enough queries per
 // (batch, head) for a workgroup's slab copy to pay (an encoder's; development build: variant 730 forces, 731 forbids)
 static bool use_slab_forward(int vdt, int ldt, const MsdaDims& d, int variant) {
-  if (vdt != VNX_F32 || (ldt != VNX_F32 && ldt != VNX_BF16 && ldt != VNX_F16) || d.L != 4 || d.P != 4 || d.D != 32) return false;
+  if (vdt != VNX_F32 || ldt != VNX_F32 || d.L != 4 || d.P != 4 || d.D != 32) return false;
   if (int64_t(d.S) * d.M * 128 >= (int64_t(1) << 31) || d.S >= (1 << 23)) return false;
   if (variant == 731) return false;
   return variant == 730 || d.Lq >= 2048;
@@ -948,7 +948,7 @@ bool msda_d32_fwd_supported(int vdt, int ldt, const MsdaDims& d) {
 int msda_forward_d32(int vdt, int ldt, const void* value, const int64_t* shapes,
                      const int64_t* lsi, const void* loc, const void* attn, void* out, MsdaDims d,
                      int variant, hipStream_t stream) {
-  if (use_slab_forward(vdt, ldt, d, variant) && ldt == VNX_F32)
+  if (use_slab_forward(vdt, ldt, d, variant))
     return launch_fwd_slab<float>(value, shapes, lsi, loc, attn, out, d, nullptr, stream);
   if (vdt == VNX_F32) return launch_fwd<float, float>(value, shapes, lsi, loc, attn, out, d, variant, stream);
   if (vdt == VNX_BF16 && ldt == VNX_F32) return launch_fwd<bf16_t, float>(value, shapes, lsi, loc, attn, out, d, variant, stream);
