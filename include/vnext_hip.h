@@ -95,9 +95,9 @@ enum {
    */
   VNX_MSDA_LEVELS_PACKED = 1,
   /*
-   * Fork the call: a backward call below 1 024 queries (32-channel heads) is two kernels neither of which reads what the
-   * other writes (grad_value; grad_sampling_loc + grad_attn_weight).  By default they run one after the other on
-   * `hip_stream`.  With this flag the grad_value kernel is launched on a side stream the library keeps per host thread
+   * Fork the call: a backward call below 1 024 queries (32-channel heads) is two halves neither of which reads what the
+   * other writes (grad_value; grad_sampling_loc + grad_attn_weight).  By default they are ONE launch whose workgroups take
+   * either role (fp32 locations, 4 levels x 4 points: the decoders' calls) or two launches one after the other on `hip_stream`.  With this flag the grad_value kernel is launched on a side stream the library keeps per host thread
    * and device (created on first use, never synchronised with the host), between an event recorded on `hip_stream` and an
    * event `hip_stream` then waits for: the two kernels share the GPU, `hip_stream` sees the call as one operation, a stream
    * capture records a fork and a join.  Measured on MI355X / ROCm 7.2: the pair then spans 24.3
