@@ -81,3 +81,61 @@ def test_forward_kernels_spill_nothing_and_nobody_uses_scratch(asm):
                 assert "runs_kernel" in name and "buffer_store_dwordx2" in line and line.rstrip().endswith(" nt"), (name, line)
     for m in re.finditer(r"\.private_segment_fixed_size:\s*(\d+)", text):
         assert int(m.group(1)) == 0
+
+
+# ---- the slab forward's samples requested one tile ahead (vnext_amd/csrc/msda_d32.hip: msda_fwd_slab_kernel) ------------------
+# The next tile's locations and weights are loaded by an asm statement and waited for, one tile later, by another: in between
+# (the whole gather phase, at 126 VGPRs) the compiler believes the destination registers hold values.  If it moved, copied or
+# spilled one of them there, the decode would read what the register held BEFORE the load landed.  Same class of hazard as the
+# mask head's scalar loads above; same kind of check.
+D32 = os.path.join(ROOT, "vnext_amd", "csrc", "msda_d32.hip")
+
+
+def vregs(token_text):
+    regs = set()
+    for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", token_text):
+        regs.update(range(int(a), int(b) + 1))
+    for a in re.findall(r"\bv(\d+)\b", token_text):
+        regs.add(int(a))
+    return regs
+
+
+def test_nothing_touches_the_slab_forwards_prefetched_samples_before_the_wait(tmp_path):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    out = tmp_path / "msda_d32.s"
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-I", os.path.dirname(D32), "-S",
+                           "--cuda-device-only", "-o", str(out), D32], stderr=subprocess.DEVNULL)
+    text = open(out).read()
+    m = re.search(r"^(_ZN3vnx20msda_fwd_slab_kernelIfLb0EEE\w*):[^\n]*\n(.*?)^\.Lfunc_end", text, re.S | re.M)
+    assert m, "the unfused slab kernel is gone?"
+    lines = [l.split(";")[0].strip() for l in m.group(2).splitlines()]
+    # hand-issued loads: the instructions between ;;#ASMSTART / ;;#ASMEND markers (the split above removed the markers'
+    # text, so find them in the raw body)
+    raw = m.group(2).splitlines()
+    in_asm, asm_loads, asm_waits = False, [], []
+    for i, l in enumerate(raw):
+        if "#ASMSTART" in l:
+            in_asm = True
+        elif "#ASMEND" in l:
+            in_asm = False
+        elif in_asm and "global_load_dword" in l:
+            asm_loads.append(i)
+        elif in_asm and "s_waitcnt vmcnt(0)" in l:
+            asm_waits.append(i)
+    assert len(asm_loads) == 8 and len(asm_waits) == 1, (asm_loads, asm_waits)      # 2 x 2 before the loop, 2 x 2 inside; one wait
+    wait = asm_waits[0]
+    dst = set()
+    for i in asm_loads:
+        dst |= vregs(lines[i].split(",")[0])
+    assert 4 <= len(dst) <= 6, dst
+    before, inside = [i for i in asm_loads if i < wait], [i for i in asm_loads if i > wait]
+    assert len(before) == 4 and len(inside) == 4
+    # forbidden zones: (last load before the loop, the wait) and (last load inside the loop, end of the kernel's loop body)
+    zones = list(range(before[-1] + 1, wait)) + list(range(inside[-1] + 1, len(lines)))
+    for i in zones:
+        ins = lines[i]
+        if not ins or ins.startswith(".") or ins.endswith(":") or ins.startswith("s_"):
+            continue
+        op, _, rest = ins.partition(" ")
+        assert not (vregs(rest) & dst), f"`{ins}` (line {i}) touches a prefetched sample register {sorted(dst)} before its wait"
