@@ -621,7 +621,14 @@ msda_fwd_slab_kernel(const float* __restrict__ value, const int64_t* __restrict_
   int* s_lvl = reinterpret_cast<int*>(smem + size_t(kSlabRowsCap + 1) * kRowBytes + kSlabRecBytes);      // [4][4]: H, W, start, -
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int x = blockIdx.x % d.M, rest = blockIdx.x / d.M, b = rest % d.B, part = rest / d.B;
+#ifndef VNX_SLAB_BATCH_MAJOR
+#define VNX_SLAB_BATCH_MAJOR 1
+#endif
+  // batch-major: the workgroups resident at one time (64 per XCD) belong to one or two batch elements, whose rows of the XCD's
+  // head then stay in its 4-MB L2 (2.5 MB per (batch, head) at 720p; with all five batch elements in flight the kernel fetched
+  // 929 MB for 100 MB of values -- PMC, profiles/r05_shapes_kernel_avg_us.json)
+  const int x = blockIdx.x % d.M, rest = blockIdx.x / d.M;
+  const int b = VNX_SLAB_BATCH_MAJOR ? rest / parts : rest % d.B, part = VNX_SLAB_BATCH_MAJOR ? rest % parts : rest / d.B;
   const int m = (x + b) % d.M;      // head <-> XCD map rotating with the batch element, as the gather kernel
 
   // ---- the level table; which levels are staged ----
