@@ -810,11 +810,15 @@ static bool use_slab_forward(int vdt, int ldt, const MsdaDims& d, int variant) {
 // CUs idle for a whole workgroup's life (560 workgroups at encoder-360p: 54.6 us against 42.6 with 480) -- and as many rounds
 // (1, 2, 4, ...) as bring a workgroup to twelve tiles or fewer: every workgroup copies the slab once, but on the largest
 // calls shorter workgroups pack the launch's tail better (encoder-720p B = 5: one round = 25 tiles each 247 us, four rounds
-// 231-234; B = 2, 9.6 tiles each: 85 us with one round, 87 with two).
+// 231-234; B = 2, 9.6 tiles each: 85 us with one round, 87 with two; encoder-360p at B = 10 -- two clips -- 13.3 tiles in one
+// round 88.5 us, 6.7 in two rounds 83.4, the gather kernel 110.9; VNX_SLAB_TILES_MAX 8 / 12 / 16 measured: 12).
 static int slab_parts(const MsdaDims& d, int n_tiles) {
   const int per_round = 512 / (d.B * d.M) > 0 ? 512 / (d.B * d.M) : 1;
   int parts = per_round;
-  while (parts < n_tiles && (n_tiles + parts - 1) / parts > 12) parts *= 2;
+#ifndef VNX_SLAB_TILES_MAX
+#define VNX_SLAB_TILES_MAX 12
+#endif
+  while (parts < n_tiles && (n_tiles + parts - 1) / parts > VNX_SLAB_TILES_MAX) parts *= 2;
   return parts > n_tiles ? n_tiles : parts;
 }
 
