@@ -1740,6 +1740,218 @@ int msda_backward_pair_d32(int vdt, const void* value, const int64_t* shapes, co
 }
 
 // queries per workgroup of the grad_loc kernel = per tile word of the tile mode (the launcher's own choice)
+// ---- grad_loc / grad_attn of calls with many queries, the coarse levels staged whole in LDS: the backward twin of
+// msda_fwd_slab_kernel (see there).  Same workgroup shape, slab and grid; a wave decodes 8 queries (two passes of 4 = two tile
+// boxes for the tile-fed grad_value kernel, msda_d32_gvtiles.hip), an 8-lane set then takes the four dots <grad_out row, tap
+// row> of each of its query's 16 samples -- rows of the staged levels from LDS, the others gathered -- and the decode's lane
+// of each sample combines them (cuh:123-158) and stores the gradients once, non-temporal.  The dots of a sample overwrite its
+// tap offsets in the wave's records (they are in registers by then), so the LDS budget is the forward's.
+__global__ void __launch_bounds__(64 * kSlabWaves, 2 * kSlabWaves / 4)
+msda_bwd_slab_kernel(const float* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
+                     const float* __restrict__ loc, const float* __restrict__ attn, const float* __restrict__ grad_out,
+                     float* __restrict__ grad_loc, float* __restrict__ grad_attn, uint32_t* __restrict__ tile_summary, MsdaDims d,
+                     int parts, unsigned long long* stamps) {
+  stamp_begin(stamps);
+  constexpr int D = 32, LP = 16, kRowBytes = 128;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* slab = smem;
+  uint4_t* rec_base = reinterpret_cast<uint4_t*>(smem + size_t(kSlabRowsCap + 1) * kRowBytes);
+  int* s_lvl = reinterpret_cast<int*>(smem + size_t(kSlabRowsCap + 1) * kRowBytes + kSlabRecBytes);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int x = blockIdx.x % d.M, rest = blockIdx.x / d.M, b = rest / parts, part = rest % parts;      // batch-major: see the forward
+  const int m = (x + b) % d.M;
+  if (tid < 4) {
+    s_lvl[4 * tid] = int(shapes[2 * tid]); s_lvl[4 * tid + 1] = int(shapes[2 * tid + 1]); s_lvl[4 * tid + 2] = int(lsi[tid]);
+  }
+  __syncthreads();
+  int first_staged = 4, slab_first = d.S;
+  {
+    bool packed = true;
+    int running = 0;
+#pragma unroll
+    for (int l = 0; l < 4; ++l) { packed = packed && s_lvl[4 * l + 2] == running; running += s_lvl[4 * l] * s_lvl[4 * l + 1]; }
+    packed = packed && running == d.S;
+    if (packed) {
+#pragma unroll
+      for (int l = 3; l >= 0; --l)
+        if (d.S - s_lvl[4 * l + 2] <= kSlabRowsCap) { first_staged = l; slab_first = s_lvl[4 * l + 2]; }
+    }
+  }
+  first_staged = __builtin_amdgcn_readfirstlane(first_staged);
+  slab_first = __builtin_amdgcn_readfirstlane(slab_first);
+  const int n_slab = d.S - slab_first;
+  {
+    const float* src = value + ((int64_t(b) * d.S + slab_first) * d.M + m) * D;
+    for (int i = tid; i < n_slab * 8; i += 64 * kSlabWaves)
+      *reinterpret_cast<float4_t*>(slab + (i >> 3) * kRowBytes + (i & 7) * 16) =
+          *reinterpret_cast<const float4_t*>(src + int64_t(i >> 3) * d.M * D + (i & 7) * 4);
+    if (tid < 8) *reinterpret_cast<float4_t*>(slab + n_slab * kRowBytes + tid * 16) = float4_t{0.f, 0.f, 0.f, 0.f};
+  }
+  __syncthreads();
+  const uint32_t zero_row = uint32_t(n_slab) * kRowBytes;
+
+  uint4_t* s_off = rec_base + size_t(wave) * 2 * kSlabEnt;            // tap offsets, then the four dots of the sample
+  float4_t* s_geo = reinterpret_cast<float4_t*>(s_off + kSlabEnt);    // lh, lw, attention weight
+  const int pixel_bytes = d.M * kRowBytes;
+  const float* head_base = value + (int64_t(b) * d.S * d.M + m) * D;
+  const __amdgpu_buffer_rsrc_t rsrc = uniform_rsrc(head_base, uint32_t((int64_t(d.S) * d.M - m) * kRowBytes));
+  const int ch = lane & 7, qi2 = lane >> 3;
+  const uint32_t lane_off = uint32_t(ch * 16);
+  uint2_t* tile_words = reinterpret_cast<uint2_t*>(tile_summary);      // [b][head][level][4-query tile]
+  const int wn = (d.Lq + 3) / 4;
+
+  const int n_tiles = (d.Lq + kSlabWaves * kSlabQpw - 1) / (kSlabWaves * kSlabQpw);
+  for (int t = part; t < n_tiles; t += parts) {
+    const int q0 = (t * kSlabWaves + wave) * kSlabQpw;
+    // ---- phase 1: decode; the bounding box of each 4-query tile's taps, per level ----
+#pragma unroll 1
+    for (int e0 = 0; e0 < kSlabQpw * LP; e0 += 64) {
+      const int e = e0 + lane, qi = e >> 4, p = e & 15, l = p >> 2;
+      const int q = q0 + qi;
+      const bool staged = l >= first_staged;
+      const uint32_t none = staged ? zero_row : kTapOutside;
+      uint4_t o4 = {none, none, none, none};
+      float4_t g4 = {0.f, 0.f, 0.f, 0.f};
+      uint32_t tile_kx = 0xffffffffu, tile_ky = 0xffffffffu;
+      if (q < d.Lq) {
+        const int64_t wi = ((int64_t(b) * d.Lq + q) * d.M + m) * LP + p;
+        const int H = s_lvl[4 * l], W = s_lvl[4 * l + 1], start = s_lvl[4 * l + 2];
+        const float sx = loc[2 * wi], sy = loc[2 * wi + 1], a = attn[wi];
+        const float h = sy * float(H) - 0.5f, w = sx * float(W) - 0.5f;
+        if (h > -1.f && w > -1.f && h < float(H) && w < float(W)) {
+          const float hf = floorf(h), wf = floorf(w);
+          const int h0 = int(hf), w0 = int(wf);
+          const bool top = h0 >= 0, bot = h0 + 1 <= H - 1, lef = w0 >= 0, rig = w0 + 1 <= W - 1;
+          const uint32_t pb = staged ? uint32_t(kRowBytes) : uint32_t(pixel_bytes);
+          const uint32_t o00 = uint32_t(__mul24((staged ? start - slab_first : start) + __mul24(h0, W) + w0, int(pb)));
+          const uint32_t row_b = __umul24(uint32_t(W), pb);
+          o4.x = (top && lef) ? o00 : none;
+          o4.y = (top && rig) ? o00 + pb : none;
+          o4.z = (bot && lef) ? o00 + row_b : none;
+          o4.w = (bot && rig) ? o00 + row_b + pb : none;
+          g4.x = h - hf; g4.y = w - wf; g4.z = a;
+          if (tile_summary != nullptr) {      // as msda_bwd_d32_body: coordinates saturate at 0xfffe
+            const uint32_t x_lo = min(uint32_t(lef ? w0 : w0 + 1), 0xfffeu), x_hi = min(uint32_t(rig ? w0 + 1 : w0), 0xfffeu);
+            const uint32_t y_lo = min(uint32_t(top ? h0 : h0 + 1), 0xfffeu), y_hi = min(uint32_t(bot ? h0 + 1 : h0), 0xfffeu);
+            tile_kx = x_lo | ((0xffffu - x_hi) << 16);
+            tile_ky = y_lo | ((0xffffu - y_hi) << 16);
+          }
+        }
+      }
+      s_off[qi * 17 + p] = o4;
+      s_geo[qi * 17 + p] = g4;
+      if (tile_summary != nullptr) {      // uniform.  Minimum over a level's 4 points (quad) and the pass's 4 queries (lane bits 4, 5)
+        tile_kx = pk_min_u16(tile_kx, uint32_t(__builtin_amdgcn_update_dpp(int(tile_kx), int(tile_kx), 0xB1, 0xF, 0xF, true)));
+        tile_ky = pk_min_u16(tile_ky, uint32_t(__builtin_amdgcn_update_dpp(int(tile_ky), int(tile_ky), 0xB1, 0xF, 0xF, true)));
+        tile_kx = pk_min_u16(tile_kx, uint32_t(__builtin_amdgcn_update_dpp(int(tile_kx), int(tile_kx), 0x4E, 0xF, 0xF, true)));
+        tile_ky = pk_min_u16(tile_ky, uint32_t(__builtin_amdgcn_update_dpp(int(tile_ky), int(tile_ky), 0x4E, 0xF, 0xF, true)));
+        tile_kx = pk_min_u16(tile_kx, uint32_t(__shfl_xor(int(tile_kx), 16, 64)));
+        tile_ky = pk_min_u16(tile_ky, uint32_t(__shfl_xor(int(tile_ky), 16, 64)));
+        tile_kx = pk_min_u16(tile_kx, uint32_t(__shfl_xor(int(tile_kx), 32, 64)));
+        tile_ky = pk_min_u16(tile_ky, uint32_t(__shfl_xor(int(tile_ky), 32, 64)));
+        const int wt = (q0 >> 2) + (e0 >> 6);      // this pass's 4-query tile
+        if ((lane & 3) == 0 && lane < 16 && wt < wn)
+          tile_words[((int64_t(b) * d.M + m) * 4 + (lane >> 2)) * wn + wt] = uint2_t{tile_kx, tile_ky};
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- phase 2: the four dots of every sample ----
+    {
+      uint4_t* g_off = s_off + qi2 * 17;
+      const int q = q0 + qi2;
+      float4_t top = {0.f, 0.f, 0.f, 0.f};
+      if (q < d.Lq) top = *reinterpret_cast<const float4_t*>(grad_out + ((int64_t(b) * d.Lq + q) * d.M + m) * D + ch * 4);
+      const float2_t t_lo = {top.x, top.y}, t_hi = {top.z, top.w};
+      auto dot = [&](const float4_t v) {
+        float2_t acc = t_lo * float2_t{v.x, v.y};
+        acc = t_hi * float2_t{v.z, v.w} + acc;
+        return acc.x + acc.y;
+      };
+#pragma unroll 1
+      for (int l = 0; l < 4; ++l) {
+        uint4_t o[4];
+        float4_t v[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = g_off[4 * l + j];
+        if (l < first_staged) {      // uniform
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            v[j][0] = load_tap<float>(rsrc, o[j].x + lane_off);
+            v[j][1] = load_tap<float>(rsrc, o[j].y + lane_off);
+            v[j][2] = load_tap<float>(rsrc, o[j].z + lane_off);
+            v[j][3] = load_tap<float>(rsrc, o[j].w + lane_off);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            v[j][0] = *reinterpret_cast<const float4_t*>(slab + o[j].x + lane_off);
+            v[j][1] = *reinterpret_cast<const float4_t*>(slab + o[j].y + lane_off);
+            v[j][2] = *reinterpret_cast<const float4_t*>(slab + o[j].z + lane_off);
+            v[j][3] = *reinterpret_cast<const float4_t*>(slab + o[j].w + lane_off);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float4_t dd = {dot(v[j][0]), dot(v[j][1]), dot(v[j][2]), dot(v[j][3])};
+          float t0, t1;
+          group8_sum4_split(dd, t0, t1);        // lanes 0..3 of the set: (d1, d2); lanes 4..7: (d3, d4)
+          if ((ch & 3) == 0) reinterpret_cast<float2_t*>(g_off + 4 * l + j)[ch >> 2] = float2_t{t0, t1};
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- phase 3: the decode's lane of a sample combines its four dots (cuh:123-158) ----
+#pragma unroll 1
+    for (int e0 = 0; e0 < kSlabQpw * LP; e0 += 64) {
+      const int e = e0 + lane, qi = e >> 4, p = e & 15, l = p >> 2;
+      const int q = q0 + qi;
+      if (q < d.Lq) {
+        const int64_t wi = ((int64_t(b) * d.Lq + q) * d.M + m) * LP + p;
+        const float4_t r = __builtin_bit_cast(float4_t, s_off[qi * 17 + p]);
+        const float4_t gq = s_geo[qi * 17 + p];
+        const float lh = gq.x, lw = gq.y, a = gq.z, hh = 1.f - lh, hw = 1.f - lw;
+        const float d1 = r.x, d2 = r.y, d3 = r.z, d4 = r.w;
+        const float gw = a * (hh * (d2 - d1) + lh * (d4 - d3));
+        const float gh = a * (hw * (d3 - d1) + lw * (d4 - d2));
+        const float ga = hh * (hw * d1 + lw * d2) + lh * (hw * d3 + lw * d4);
+        const float Hf = float(s_lvl[4 * l]), Wf = float(s_lvl[4 * l + 1]);
+        __builtin_nontemporal_store(float2_t{Wf * gw, Hf * gh}, reinterpret_cast<float2_t*>(grad_loc + 2 * wi));
+        __builtin_nontemporal_store(ga, grad_attn + wi);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  stamp_end(stamps);
+}
+
+static int launch_bwd_slab(const void* value, const int64_t* shapes, const int64_t* lsi, const void* loc, const void* attn,
+                           const void* grad_out, void* grad_loc, void* grad_attn, void* tile_summary, const MsdaDims& d,
+                           hipStream_t stream) {
+  const int n_tiles = (d.Lq + kSlabWaves * kSlabQpw - 1) / (kSlabWaves * kSlabQpw);
+  const int parts = slab_parts(d, n_tiles);
+  const int64_t blocks = int64_t(parts) * d.B * d.M;
+  static thread_local int raised_on = -1;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (raised_on != dev) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&msda_bwd_slab_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            int(kSlabLdsBytes)) != hipSuccess)
+      return check_launch("msda_bwd_slab (LDS limit)");
+    raised_on = dev;
+  }
+  hipLaunchKernelGGL(msda_bwd_slab_kernel, dim3(uint32_t(blocks)), dim3(64 * kSlabWaves), kSlabLdsBytes, stream,
+                     (const float*)value, shapes, lsi, (const float*)loc, (const float*)attn, (const float*)grad_out,
+                     (float*)grad_loc, (float*)grad_attn, (uint32_t*)tile_summary, d, parts,
+                     take_stamp_region(kStampGradLoc, blocks));
+  return check_launch("msda_bwd_slab");
+}
+
 int msda_bwd_tile_queries(const MsdaDims& d, int variant) {
   // the grad_loc launcher's variant decoding: < 100 as is, 100..199 (grad_loc only, timing) minus 100, others automatic
   const FwdCfg c = pick_fwd_cfg(d, variant < 100 ? variant : (variant < 200 ? variant - 100 : 0));
@@ -1758,6 +1970,16 @@ int msda_backward_d32(int vdt, int ldt, const void* value, const int64_t* shapes
                       int variant, void* records, void* tile_summary, float* tile_copy, hipStream_t stream) {
   // the 16-bit row limit of the sample records (h0+1, w0+1 packed into one word)
 #define VNX_ARGS value, shapes, lsi, loc, attn, grad_out, gv, grad_loc, grad_attn, d, variant, records, tile_summary, tile_copy, stream
+  // tile-fed calls (the encoders'), fp32: the coarse levels staged in LDS (msda_bwd_slab_kernel; its boxes are per 4 queries,
+  // as the automatic configuration's).  The launcher's variant decoding: 100..199 = grad_loc only (timing), others automatic.
+  // Development build: 730 forces, 731 / 733 forbid (733: this kernel only, the forward keeps its slab).
+  {
+    const int v = variant >= 100 && variant < 200 ? variant - 100 : (variant < 100 ? variant : 0);
+    const int kv = kernel_variant();
+    if (vdt == VNX_F32 && ldt == VNX_F32 && v == 0 && gv == nullptr && records == nullptr && tile_copy == nullptr &&
+        tile_summary != nullptr && kv != 733 && msda_bwd_tile_queries(d, 0) == 4 && use_slab_forward(vdt, ldt, d, kv))
+      return launch_bwd_slab(value, shapes, lsi, loc, attn, grad_out, grad_loc, grad_attn, tile_summary, d, stream);
+  }
   if (vdt == VNX_F32) return launch_bwd<float, float>(VNX_ARGS);
   if (vdt == VNX_BF16 && ldt == VNX_F32) return launch_bwd<bf16_t, float>(VNX_ARGS);
   if (vdt == VNX_BF16 && ldt == VNX_BF16) return launch_bwd<bf16_t, bf16_t>(VNX_ARGS);
