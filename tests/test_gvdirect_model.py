@@ -1,7 +1,8 @@
 """Host model of the self-decoding grad_value kernel (vnext_amd/csrc/msda_d32_gvdirect.hip): the unit split of every
 level (gvd_level_split, read through the debug ABI), the launcher's grid bound, and the kernel's index arithmetic --
-ranks inside a row, segment offsets allocated per wave in any order, groups walking the rows 64 slots at a time, a row
-spread over 1 << gshift adjacent groups, later passes adding onto the rows of the first -- replayed in numpy and held to the C oracle's
+ranks inside a row, segment offsets allocated per wave in any order, 2-lane groups walking the rows 256 slots at a time once per
+channel half (the first half's sums held until the second's are ready), a row spread over 1 << gshift adjacent groups, later
+passes adding onto the rows of the first -- replayed in numpy and held to the C oracle's
 grad_value.  No GPU: what is checked here is the scheme (a tap applied twice or never shows up as a wrong sum), the GPU
 tests (tests/test_msda_gvdirect.py) check the kernel.  Reference semantics: ms_deform_im2col_cuda.cuh:87-159,253-298."""
 import ctypes
@@ -13,7 +14,7 @@ import pytest
 from oracle import msda_oracle as O
 from vnext_amd import _lib
 
-QC, ROWS = 320, 640
+QC, ROWS = 304, 768      # VNX_GVD_QC, VNX_GVD_ROWS (vnx_common.h)
 
 
 def level_table(shapes, Lq, P, batch_heads=2):
@@ -85,25 +86,35 @@ def model_grad_value(value_shape, shapes, lsi, loc, attn, grad_out, rng):
                         for row, rk, slot, wt in ranked:
                             assert lst[offs[row] + rk] is None
                             lst[offs[row] + rk] = (slot, wt)
-                        # the walk: slot = row * groups-per-row + part, 128 slots per round (4-lane groups); parts meet, part 0 stores
+                        # the walk, once per channel half: slot = row * groups-per-row + part, 256 slots per round (2-lane
+                        # groups); parts meet, part 0 stores -- the first half's sums wait for the second's
                         n_slots = rows << gshift
-                        for sb in range(0, n_slots, 128):
-                            partial = {}
-                            for grp in range(128):
-                                slot = sb + grp
-                                if slot >= n_slots:
-                                    continue
-                                row, part = slot >> gshift, slot & gmask
-                                acc = np.zeros(D)
-                                i = part
-                                while i < cnt[row]:
-                                    sl, wt = lst[offs[row] + i]
-                                    acc += wt * go[b, qs[sl], m]
-                                    i += step
-                                partial.setdefault(row, []).append(acc)
-                            for row, parts in partial.items():
-                                assert len(parts) == step      # the groups of a row are adjacent: one round, one wave (16 groups)
-                                stored[row] = sum(parts) + (stored[row] if pass_ > 0 else 0)
+                        assert n_slots <= 3 * 256      # what a group's held sums cover (kIters)
+                        held = {}
+                        for cp in (0, 1):
+                            ch = slice(16 * cp, 16 * cp + 16)
+                            for sb in range(0, n_slots, 256):
+                                partial = {}
+                                for grp in range(256):
+                                    slot = sb + grp
+                                    if slot >= n_slots:
+                                        continue
+                                    row, part = slot >> gshift, slot & gmask
+                                    acc = np.zeros(16)
+                                    i = part
+                                    while i < cnt[row]:
+                                        sl, wt = lst[offs[row] + i]
+                                        acc += wt * go[b, qs[sl], m, ch]
+                                        i += step
+                                    partial.setdefault(row, []).append(acc)
+                                for row, parts in partial.items():
+                                    assert len(parts) == step      # the groups of a row are adjacent: one round, one wave (32 groups)
+                                    if cp == 0:
+                                        held[row] = sum(parts)
+                                    else:
+                                        both = np.concatenate((held.pop(row), sum(parts)))
+                                        stored[row] = both + (stored[row] if pass_ > 0 else 0)
+                        assert not held
                     gv[b, lsi[l] + r0: lsi[l] + r1, m] = stored
     assert not np.isnan(gv).any(), "a row without an owner"
     return gv
@@ -142,16 +153,17 @@ def test_scheme_reproduces_the_oracle(shapes, Lq, P, concentrate):
 
 
 def test_baseline_level_tables():
-    # T=5 decoder call at 360p (40 (batch, head) pairs: the grid fits one round, the two small levels are cut in two):
-    # 6 + 2 + 2 + 2 units; a row of the 60-pixel level (80 taps) on eight groups, of the 240-pixel level (20 taps) on two
+    # T=5 decoder call at 360p (units of up to 768 rows; 40 (batch, head) pairs: the stand-alone kernel's grid fits one round,
+    # the two small levels are cut in two): 5 + 2 + 2 + 2 units; a row of the 60-pixel level (80 taps) on eight groups, of the
+    # 240-pixel level (20 taps) on two
     used, bound, units, rpu, gs = level_table([(48, 80), (24, 40), (12, 20), (6, 10)], 300, 4, 40)
-    assert list(units) == [6, 2, 2, 2] and list(rpu) == [640, 480, 120, 30] and list(gs) == [0, 0, 1, 3]
-    assert used == 12 <= bound
+    assert list(units) == [5, 2, 2, 2] and list(rpu) == [768, 480, 120, 30] and list(gs) == [0, 0, 1, 3]
+    assert used == 11 <= bound
     # B = 10: two rounds of workgroups either way, one unit per small level
     used, bound, units, rpu, gs = level_table([(48, 80), (24, 40), (12, 20), (6, 10)], 300, 4, 80)
-    assert list(units) == [6, 2, 1, 1] and list(rpu) == [640, 480, 240, 60] and used == 10 <= bound
+    assert list(units) == [5, 2, 1, 1] and list(rpu) == [768, 480, 240, 60] and used == 9 <= bound
     used, bound, units, rpu, gs = level_table([(92, 160), (46, 80), (23, 40), (12, 20)], 300, 4, 40)
-    assert used <= bound and list(units)[0] == 23 and all(r <= ROWS for r in rpu)
+    assert used <= bound and list(units)[0] == 23 and all(r <= 640 for r in rpu)      # the 720p pyramid: units of up to 640 rows
 
 
 @pytest.mark.parametrize("seed", range(4))

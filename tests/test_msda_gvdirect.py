@@ -1,7 +1,7 @@
 """grad_value of calls below 1 024 queries (the decoders'): the self-decoding kernel of vnext_amd/csrc/msda_d32_gvdirect.hip,
 launched after the grad_loc kernel on the caller's stream or, with VNX_MSDA_FORK, beside it on the library's side stream
 (capi.hip: side_lane).  Everything through
-the C ABI against the fp64 C oracle: the BASELINE decoder shapes, ragged query counts incl. several passes (> 320
+the C ABI against the fp64 C oracle: the BASELINE decoder shapes, ragged query counts incl. several passes (> 304
 queries), levels of a handful of pixels (a row spread over several 8-lane groups), every sample on one spot (one row's
 segment is the whole list), other level / point counts, 16-bit values, unpacked levels (the general path must
 take over on the device), the fork under stream capture, on a non-default stream, from two host threads, and against
@@ -56,7 +56,7 @@ def test_baseline_decoder_shapes(shapes, B, Lq, dist):
     check(run(case, 0), oracle(case), case)
 
 
-@pytest.mark.parametrize("Lq", [1, 2, 7, 63, 64, 127, 319, 320, 321, 640, 700, 1023])
+@pytest.mark.parametrize("Lq", [1, 2, 7, 63, 64, 127, 303, 304, 305, 319, 320, 321, 608, 640, 700, 1023])
 def test_ragged_query_counts_and_several_passes(Lq):
     case = uniform_case([(24, 40), (12, 20), (6, 10), (3, 5)], 2, Lq, seed=Lq)
     check(run(case, 0), oracle(case), case)
@@ -82,6 +82,23 @@ def test_other_level_and_point_counts(L, P):
     shapes = [(30, 44), (15, 22), (8, 11), (4, 6), (2, 3)][:L]
     case = uniform_case(shapes, 2, 150, seed=10 * L + P, M=4, P=P)
     check(run(case, 0), oracle(case), case)
+
+
+@pytest.mark.parametrize("L,P", [(5, 4), (4, 8), (3, 2)])
+@pytest.mark.parametrize("vdt", [torch.float32, torch.bfloat16])
+def test_many_queries_with_other_level_and_point_counts(L, P, vdt):
+    """from 1 024 queries up a call the tile-fed kernel is not built for (L * P != 16 or P != 4) must NOT take the self-decoding
+    kernel (one pass per 304 queries, 16-bit rows rounded once per pass): the record-fed path accumulates in fp32 (capi.hip:
+    use_direct)"""
+    shapes = [(30, 44), (15, 22), (8, 11), (4, 6), (2, 3)][:L]
+    case = uniform_case(shapes, 2, 1500, seed=100 * L + P, M=4, P=P)
+    got = run(case, 0, vdt)
+    want = oracle(case, vdt)
+    if vdt == torch.float32:
+        check(got, want, case)
+    else:
+        np.testing.assert_allclose(got[0], want[0], rtol=0, atol=8e-3 * scale(want[0]))
+        np.testing.assert_allclose(got[2], want[2], rtol=0, atol=8e-3 * scale(want[2]))
 
 
 @pytest.mark.parametrize("vdt", [torch.bfloat16, torch.float16])

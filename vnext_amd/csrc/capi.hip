@@ -316,11 +316,15 @@ static bool use_tiles(int vdt, int ldt, const MsdaDims& d, int variant) {
 // tags, no workspace, and no dependence on the grad_loc kernel, so the two run concurrently (side_lane below).  The
 // development build keeps the record-fed kernels reachable for A/B runs (variant 430 and the variants that name one).
 #ifndef VNX_PAIR_ORDER
-#define VNX_PAIR_ORDER 1      // role order of the paired backward kernel's workgroup groups (msda_d32.hip): the grad_loc groups first
+#define VNX_PAIR_ORDER -1     // role order of the paired backward kernel's workgroup groups (msda_d32.hip): -1 = the launcher's choice
 #endif
 static bool use_direct(int vdt, int ldt, const MsdaDims& d, int variant) {
   if (variant == 430 || variant == 408 || variant == 412 || variant == 420 || variant == 425) return false;
   if (use_tiles(vdt, ldt, d, variant)) return false;
+  // built for calls below 1 024 queries: beyond, every unit would re-stage all grad_out rows of its head once per pass of
+  // VNX_GVD_QC queries, and 16-bit rows would be rounded once per pass -- such calls (L * P != 16 or P != 4 at encoder sizes) keep
+  // the record-fed path, which accumulates in fp32
+  if (d.Lq >= 1024) return false;
   return msda_d32_gvdirect_supported(vdt, ldt, d);
 }
 // RECORD-fed path with 16-bit values and enough queries for the query split of the coarse levels (gv_query_splits): the
@@ -772,11 +776,12 @@ extern "C" int vnx_debug_gvdirect_units(const int64_t* host_shapes, int levels, 
   if (!host_shapes || levels <= 0 || !units_used || !units_bound) return VNX_ERR_INVALID_ARGUMENT;
   int64_t S = 0;
   for (int l = 0; l < levels; ++l) S += host_shapes[2 * l] * host_shapes[2 * l + 1];
-  const int ut = gvd_units_min(int(S), levels, batch_heads);
+  const int rows = gvd_rows_max(int(S));
+  const int ut = gvd_units_min(int(S), levels, batch_heads, rows);
   int used = 0;
   for (int l = 0; l < levels; ++l) {
     const int H = int(host_shapes[2 * l]), W = int(host_shapes[2 * l + 1]);
-    const GvdSplit sp = gvd_level_split(H * W, ut, num_query, num_point);      // the kernel's level table
+    const GvdSplit sp = gvd_level_split(H * W, ut, num_query, num_point, rows);      // the kernel's level table
     used += sp.units;
     if (level_units) level_units[l] = sp.units;
     if (level_rows_per_unit) level_rows_per_unit[l] = sp.rpu;

@@ -256,6 +256,9 @@ __device__ __forceinline__ void fused_decode(const TL* __restrict__ raw_off, con
 #ifndef VNX_K1_BATCH
 #define VNX_K1_BATCH 4
 #endif
+#ifndef VNX_K1_BATCH_F32      // the 8-lanes-per-row fp32 path of the one-wave configuration (need not divide the samples of a group)
+#define VNX_K1_BATCH_F32 VNX_K1_BATCH
+#endif
 // tile boxes of the tile-fed grad_value path per WAVE (QPW = 4 queries on large calls) instead of per workgroup (16): a
 // tile's box is 4 + 12 pixels wide instead of 16 + 12, so fewer tiles meet a block (encoder backward, cold: 175.2 -> 169.1 us
 // at 360p, 654.8 -> 625.8 us at 720p B = 5), this kernel loses its LDS step, the grad_value kernel scans four times the
@@ -1086,7 +1089,7 @@ __device__ __forceinline__ void store_loc(TL* p, float v) { *p = from_acc<TL>(v)
 // The kernel's body as a device function of the workgroup's index `vblock`, the wave's index inside it `wave` and the
 // workgroup's LDS: msda_bwd_d32_kernel below is this and nothing else; msda_bwd_pair_kernel runs the one-wave-per-workgroup
 // configuration in every WAVE of its grad_loc workgroups (vblock = that wave's own workgroup index, wave = 0, its own LDS slice).
-template <typename TV, typename TL, int QPW, int WPB, int LP_T, bool ATOMICS, bool FUSED = false, int LPR = 8>
+template <typename TV, typename TL, int QPW, int WPB, int LP_T, bool ATOMICS, bool FUSED = false, int LPR = 8, int KB = 0>
 __device__ __forceinline__ void
 msda_bwd_d32_body(const TV* __restrict__ value, const int64_t* __restrict__ shapes,
                   const int64_t* __restrict__ lsi, const TL* __restrict__ loc,
@@ -1327,7 +1330,7 @@ msda_bwd_d32_body(const TV* __restrict__ value, const int64_t* __restrict__ shap
       return dot8f(lo, hi);
     };
     constexpr int kPer = LP_T / PG;
-    constexpr int kWant = k16 ? (WPB == 1 ? VNX_K1_BATCH : VNX_K1_BATCH_LARGE) : (WPB == 1 ? 2 : 1);   // fp32: 8 registers per tap
+    constexpr int kWant = KB > 0 ? KB : k16 ? (WPB == 1 ? VNX_K1_BATCH : VNX_K1_BATCH_LARGE) : (WPB == 1 ? 2 : 1);   // fp32: 8 registers per tap
     constexpr int kBatch = kPer < kWant ? kPer : kWant;
     static_assert(kPer % kBatch == 0, "whole batches");
     const uint32_t lane_off = uint32_t(ch * kLaneBytes);
@@ -1429,7 +1432,7 @@ msda_bwd_d32_body(const TV* __restrict__ value, const int64_t* __restrict__ shap
     // 2 for the large ones (4 waves per workgroup, rows > 4096), which are bound by how many waves fit:
     // encoder shape 106 vs 112 us.
     constexpr int kPer = LP_T / PG;
-    constexpr int kWant = WPB == 1 ? VNX_K1_BATCH : VNX_K1_BATCH_LARGE;
+    constexpr int kWant = KB > 0 ? KB : WPB == 1 ? VNX_K1_BATCH_F32 : VNX_K1_BATCH_LARGE;
     constexpr int kBatch = kPer < kWant ? kPer : kWant;
     // Round 2, late: this kernel is bound by vector-instruction issue on large calls (PMC, encoder 360p: 46.6 M wave
     // instructions x 4 clk / 1 024 SIMDs = 96 us = its duration), and most of them were the per-channel bilinear
@@ -1447,18 +1450,21 @@ msda_bwd_d32_body(const TV* __restrict__ value, const int64_t* __restrict__ shap
       return acc.x + acc.y;
     };
 #pragma unroll
-    for (int i0 = 0; i0 < kPer; i0 += kBatch) {
+    for (int i0 = 0; i0 < kPer; i0 += kBatch) {      // (kBatch need not divide kPer: the last batch is shorter)
       uint4_t o[kBatch];
       float4_t v[kBatch][4];
 #pragma unroll
-      for (int j = 0; j < kBatch; ++j) o[j] = g_off[i0 + j];
+      for (int j = 0; j < kBatch; ++j)
+        if (i0 + j < kPer) o[j] = g_off[i0 + j];
 #pragma unroll
-      for (int j = 0; j < kBatch; ++j) {
-        v[j][0] = tap(o[j].x); v[j][1] = tap(o[j].y); v[j][2] = tap(o[j].z); v[j][3] = tap(o[j].w);
-      }
+      for (int j = 0; j < kBatch; ++j)
+        if (i0 + j < kPer) {
+          v[j][0] = tap(o[j].x); v[j][1] = tap(o[j].y); v[j][2] = tap(o[j].z); v[j][3] = tap(o[j].w);
+        }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < kBatch; ++j) {
+        if (i0 + j >= kPer) continue;
         const float4_t dd = {dot(v[j][0]), dot(v[j][1]), dot(v[j][2]), dot(v[j][3])};
         if (VNX_K1_ABL & 4) {
           if (dd.x + dd.y + dd.z + dd.w == 12345.678f) g_res[i0 + j] = dd;
@@ -1641,14 +1647,23 @@ static int launch_bwd(const void* value, const int64_t* shapes, const int64_t* l
 // -- the same head class x for all eight, so the head <-> XCD map of both kernels is kept.  Registers and LDS are the
 // maximum of the two roles: two workgroups per CU either way.
 constexpr int kPairWaves = 8;
+// samples whose tap loads a grad_loc wave has in flight: three CUs' worth of workgroups need <= 80 VGPRs (the stand-alone kernel
+// takes 4 = 16 loads: 92 VGPRs; fp32 3 + 3 + 2: 76; 16-bit rows, 4 samples per group: 2 + 2)
+#ifndef VNX_PAIR_BATCH_F32
+#define VNX_PAIR_BATCH_F32 3
+#endif
+template <typename TV> constexpr int kPairBatch = sizeof(TV) == 2 ? 2 : VNX_PAIR_BATCH_F32;
 template <int QPW> constexpr int kPairGlWaveLds = 3 * QPW * 17 * 16 + 128;      // the one-wave configuration's LDS (L*P == 16)
 
 template <typename TV, typename TL, int QPW, int LPR>
-__global__ void __launch_bounds__(64 * kPairWaves, 2 * kPairWaves / 4)
+#ifndef VNX_PAIR_WGS_PER_CU
+#define VNX_PAIR_WGS_PER_CU 3
+#endif
+__global__ void __launch_bounds__(64 * kPairWaves, VNX_PAIR_WGS_PER_CU * kPairWaves / 4)
 msda_bwd_pair_kernel(const TV* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
                      const TL* __restrict__ loc, const TL* __restrict__ attn, const TV* __restrict__ grad_out,
                      TV* __restrict__ grad_value, TL* __restrict__ grad_loc, TL* __restrict__ grad_attn, MsdaDims d,
-                     int tiles_per_batch, int ut, uint32_t gv_groups, uint32_t gl_groups, uint32_t gl_blocks, int order,
+                     int tiles_per_batch, int ut, int rows_max, uint32_t gv_groups, uint32_t gl_groups, uint32_t gl_blocks, int order,
                      unsigned long long* stamps) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   stamp_begin(stamps);
@@ -1669,20 +1684,20 @@ msda_bwd_pair_kernel(const TV* __restrict__ value, const int64_t* __restrict__ s
     else { is_gv = gv_groups > gl_groups; g = G - n_min; }
   }
   if (is_gv) {      // uniform over the workgroup
-    rec::msda_bwd_gv_direct_body<TV, TL, 4>(shapes, lsi, loc, attn, grad_out, grad_value, d, ut, 0, nullptr, g * M + x, smem);
+    rec::msda_bwd_gv_direct_body<TV, TL, 4>(shapes, lsi, loc, attn, grad_out, grad_value, d, ut, rows_max, 0, nullptr, g * M + x, smem);
     stamp_end(stamps);
     return;
   }
   const uint32_t w = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)));
   const uint32_t vb = (g * kPairWaves + w) * M + x;
   if (vb < gl_blocks)      // uniform over the wave; the body has no workgroup barrier in this configuration
-    msda_bwd_d32_body<TV, TL, QPW, 1, 16, false, false, LPR>(value, shapes, lsi, loc, attn, grad_out, nullptr, grad_loc, grad_attn, d,
+    msda_bwd_d32_body<TV, TL, QPW, 1, 16, false, false, LPR, kPairBatch<TV>>(value, shapes, lsi, loc, attn, grad_out, nullptr, grad_loc, grad_attn, d,
                                                             tiles_per_batch, nullptr, nullptr, nullptr, 0, nullptr, FusedArgs{}, vb, 0,
                                                             smem + w * kPairGlWaveLds<QPW>);
   stamp_end(stamps);
 }
 
-int msda_gvdirect_units_bound(const MsdaDims& d);
+int msda_gvdirect_units_bound(const MsdaDims& d, int ut, int rows);
 
 // -> true when the call is one the paired kernel is built for (what the decoders of both models present: fp32 locations, fp32
 // or 16-bit values, L*P == 16 with 4 points, the one-wave configuration of the grad_loc kernel)
@@ -1696,14 +1711,20 @@ bool msda_backward_pair_supported(int vdt, int ldt, const MsdaDims& d) {
 template <typename TV>
 static int launch_pair(const void* value, const int64_t* shapes, const int64_t* lsi, const void* loc, const void* attn,
                        const void* grad_out, void* grad_value, void* grad_loc, void* grad_attn, const MsdaDims& d, int order,
-                       hipStream_t stream) {
+                       hipStream_t stream) {      // order: 0 / 1 / 2 as the kernel's, < 0 = chosen here
   constexpr int QPW = 4;
   constexpr int kLpr = sizeof(TV) == 2 ? 4 : 8;      // 16-bit rows as 4 lanes x 16 B (as the stand-alone launcher)
   const int tiles_per_batch = (d.Lq + QPW - 1) / QPW;
   const int64_t gl_blocks = int64_t(d.B) * tiles_per_batch * d.M;
-  const int ut = gvd_units_min(d.S, d.L, d.B * d.M);
-  const int64_t gv_blocks = ((int64_t(d.B) * msda_gvdirect_units_bound(d) + 1) & ~int64_t(1)) * d.M;
   const int64_t gl_groups = (gl_blocks + int64_t(kPairWaves) * d.M - 1) / (int64_t(kPairWaves) * d.M);      // of M workgroups each
+  const int rows = gvd_rows_max(d.S);
+  const int ut = gvd_units_min(d.S, d.L, d.B * d.M, rows, gl_groups * d.M);      // (the small levels are cut only if BOTH roles then fit one round)
+  const int64_t gv_blocks = ((int64_t(d.B) * msda_gvdirect_units_bound(d, ut, rows) + 1) & ~int64_t(1)) * d.M;
+  // Role order (see the kernel): with everything resident in ONE round of three workgroups per CU the grad_value groups go
+  // first -- their units are the longest workgroups (T = 5 call, 735 workgroups: 19.5 us against 20.7 with the grad_loc groups
+  // first); with more rounds the grad_loc groups (B = 10: 33.4 against 39.2 us).  order < 0: this choice.
+  if (order < 0)
+    order = int64_t(d.B) * d.M * gvd_units_estimate(d.S, d.L, rows) + gl_groups * d.M <= VNX_GVD_ONE_ROUND ? 0 : 1;
   const int64_t blocks = gv_blocks + gl_groups * d.M;
   if (blocks >= (int64_t(1) << 31)) {
     set_error("msda_backward: %lld workgroups exceed the grid limit", (long long)blocks);
@@ -1722,7 +1743,7 @@ static int launch_pair(const void* value, const int64_t* shapes, const int64_t* 
   }
   hipLaunchKernelGGL((msda_bwd_pair_kernel<TV, float, QPW, kLpr>), dim3(uint32_t(blocks)), dim3(64 * kPairWaves), kLds, stream,
                      (const TV*)value, shapes, lsi, (const float*)loc, (const float*)attn, (const TV*)grad_out,
-                     (TV*)grad_value, (float*)grad_loc, (float*)grad_attn, d, tiles_per_batch, ut, uint32_t(gv_blocks / d.M),
+                     (TV*)grad_value, (float*)grad_loc, (float*)grad_attn, d, tiles_per_batch, ut, rows, uint32_t(gv_blocks / d.M),
                      uint32_t(gl_groups), uint32_t(gl_blocks), order, take_stamp_region(kStampGradPair, blocks));
   return check_launch("msda_bwd_pair");
 }

@@ -37,9 +37,9 @@ template <typename TV, typename TL, int P_T>
 __global__ void __launch_bounds__(kThreads, VNX_GVD_UNITS_PER_CU * kWaves / 4)
 msda_bwd_gv_direct_kernel(const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
                           const TL* __restrict__ loc, const TL* __restrict__ attn, const TV* __restrict__ grad_out,
-                          TV* __restrict__ grad_value, MsdaDims d, int ut, int compact, unsigned long long* stamps) {
+                          TV* __restrict__ grad_value, MsdaDims d, int ut, int rows_max, int compact, unsigned long long* stamps) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  msda_bwd_gv_direct_body<TV, TL, P_T>(shapes, lsi, loc, attn, grad_out, grad_value, d, ut, compact, stamps, blockIdx.x, smem);
+  msda_bwd_gv_direct_body<TV, TL, P_T>(shapes, lsi, loc, attn, grad_out, grad_value, d, ut, rows_max, compact, stamps, blockIdx.x, smem);
 }
 
 }  // namespace rec
@@ -58,9 +58,10 @@ extern "C" int vnx_debug_read_gvd_stamps(unsigned long long* host, int n) {
 // Workgroups per (batch, head): the host knows S, not the level shapes.  A level of n pixels has
 // max(ceil(n / ROWS), min(ut, n)) units (gvd_level_split): ceil(n / ROWS) + 1 bounds it for ut <= 2, and
 // sum ceil(n_l / ROWS) <= S / ROWS + L.
-int msda_gvdirect_units_bound(const MsdaDims& d) {
-  const int ut = gvd_units_min(d.S, d.L, d.B * d.M);
-  return d.S / VNX_GVD_ROWS + d.L + (ut > 1 ? d.L : 0);
+int msda_gvdirect_units_bound(const MsdaDims& d, int ut, int rows) { return d.S / rows + d.L + (ut > 1 ? d.L : 0); }
+int msda_gvdirect_units_bound(const MsdaDims& d) {      // the stand-alone launcher's
+  const int rows = gvd_rows_max(d.S);
+  return msda_gvdirect_units_bound(d, gvd_units_min(d.S, d.L, d.B * d.M, rows), rows);
 }
 
 bool msda_d32_gvdirect_supported(int vdt, int ldt, const MsdaDims& d) {
@@ -71,15 +72,17 @@ bool msda_d32_gvdirect_supported(int vdt, int ldt, const MsdaDims& d) {
   // 24-bit stride multiplies; byte offsets into one batch element's locations and grad_out rows below 2^31 (buffer offsets)
   if (d.Lq >= (1 << 24) || d.M * 32 >= (1 << 24) || d.M * d.L * d.P >= (1 << 24)) return false;
   if (int64_t(d.Lq) * d.M * d.L * d.P * 8 >= (int64_t(1) << 31) || int64_t(d.Lq) * d.M * 32 * 4 >= (int64_t(1) << 31)) return false;
-  const int64_t blocks = (int64_t(d.B) * msda_gvdirect_units_bound(d) + 1) * d.M;
-  return blocks < (int64_t(1) << 31);
+  // (the grid of either launcher: at most 2 L more units per (batch, head) than S / rows + L with the smallest rows in use)
+  const int64_t blocks = (int64_t(d.B) * (d.S / VNX_GVD_ROWS_LARGE + 3 * d.L) + 1) * d.M;
+  return blocks < (int64_t(1) << 30);
 }
 
 template <typename TV, typename TL>
 static int launch_gvdirect(const int64_t* shapes, const int64_t* lsi, const void* loc, const void* attn, const void* grad_out,
                            void* grad_value, const MsdaDims& d, int compact, hipStream_t stream) {
-  const int ut = gvd_units_min(d.S, d.L, d.B * d.M);
-  const int64_t blocks = ((int64_t(d.B) * msda_gvdirect_units_bound(d) + 1) & ~int64_t(1)) * d.M;   // (unit, batch) pairs: even (gv_decode_block)
+  const int rows = gvd_rows_max(d.S);
+  const int ut = gvd_units_min(d.S, d.L, d.B * d.M, rows);
+  const int64_t blocks = ((int64_t(d.B) * msda_gvdirect_units_bound(d, ut, rows) + 1) & ~int64_t(1)) * d.M;   // (unit, batch) pairs: even (gv_decode_block)
   // more than 64 KiB of LDS per workgroup: the limit is raised once per kernel (and device: the attribute is per function)
 #define VNX_LAUNCH(PT)                                                                                                    \
   do {                                                                                                                    \
@@ -94,7 +97,7 @@ static int launch_gvdirect(const int64_t* shapes, const int64_t* lsi, const void
     }                                                                                                                     \
     hipLaunchKernelGGL((rec::msda_bwd_gv_direct_kernel<TV, TL, PT>), dim3(uint32_t(blocks)), dim3(rec::kThreads),        \
                        rec::kGvdLdsBytes, stream, shapes, lsi, (const TL*)loc, (const TL*)attn, (const TV*)grad_out,     \
-                       (TV*)grad_value, d, ut, compact, take_stamp_region(kStampGradValue, blocks));                     \
+                       (TV*)grad_value, d, ut, rows, compact, take_stamp_region(kStampGradValue, blocks));                     \
   } while (0)
   if (d.P == 4) VNX_LAUNCH(4); else VNX_LAUNCH(0);
 #undef VNX_LAUNCH

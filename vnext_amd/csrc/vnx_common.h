@@ -210,28 +210,46 @@ __host__ __device__ inline GvSplit gv_level_split(int n, int units_min, int rows
 // its size, so a row of a coarse level (80 taps at the 60-pixel level of a 300-query call) is spread over 1 << gshift
 // adjacent groups whose partial sums meet in registers; `ut` (gvd_units_min) cuts such a level in two when the grid has room.
 #ifndef VNX_GVD_QC
-#define VNX_GVD_QC 320            // queries staged per pass: 40 KiB of grad_out rows in LDS (all 300 of a decoder call)
+#define VNX_GVD_QC 304            // queries staged per pass (all 300 of a decoder call): 19 KiB of grad_out row halves in LDS
 #endif
 #ifndef VNX_GVD_ROWS
-#define VNX_GVD_ROWS 640
+#define VNX_GVD_ROWS 768          // rows of a unit at most (what the kernel's LDS holds); the launchers choose <= this per call (gvd_rows_max)
+#endif
+#ifndef VNX_GVD_ROWS_LARGE
+#define VNX_GVD_ROWS_LARGE 640    // ... for pyramids above VNX_GVD_SMALL_S pixels
+#endif
+#ifndef VNX_GVD_SMALL_S
+#define VNX_GVD_SMALL_S 8192
 #endif
 #ifndef VNX_GVD_ONE_ROUND
-#define VNX_GVD_ONE_ROUND 512     // workgroups resident at once: 2 per CU x 256 CUs
+#define VNX_GVD_ONE_ROUND 768     // workgroups resident at once: 3 per CU x 256 CUs
 #endif
 struct GvdSplit { int units, rpu, gshift; };
 // Units per level at least.  A level that fits one unit (the 240- and 60-pixel levels at 360p) receives as many taps as a
 // whole fine level, so its unit is the call's longest: when the grid has room for it in ONE round of resident workgroups such
 // a level is cut in two (T = 5 decoder call: 10 -> 12 units per (batch, head), 480 workgroups, kernel 14.8 -> 13.6 us; at
 // B = 10 the grid takes two rounds either way and the extra units cost 0.6 us: there 1).
-__host__ __device__ inline int gvd_units_min(int S, int L, int batch_heads) {
+// Rows per unit at most, chosen per call (round 6; measured with three workgroups per CU, paired backward, cold): 768 rows at
+// the 360p pyramid (S = 5 100: 9 units per (batch, head) instead of 10 -- T = 5 call 21.9 -> 20.8 us with the grad_loc groups
+// first, 19.5 with the grad_value groups first once everything is resident in one round; B = 10 35.4 -> 33.1), 640 at the
+// 720p pyramid (S = 19 560: 35.1 against 40.3 us with 768 -- there a unit's time is its rows' stores).
+__host__ __device__ inline int gvd_rows_max(int S) {
+  const int r = S <= VNX_GVD_SMALL_S ? VNX_GVD_ROWS : VNX_GVD_ROWS_LARGE;
+  return r < VNX_GVD_ROWS ? r : VNX_GVD_ROWS;
+}
+// Units per (batch, head) the launchers expect (an estimate for tuning choices: the host knows S and L, not the level sizes;
+// pyramids whose levels shrink four-fold need S / rows + L - 1)
+__host__ __device__ inline int gvd_units_estimate(int S, int L, int rows) { return S / rows + (L > 1 ? L - 1 : 1); }
+__host__ __device__ inline int gvd_units_min(int S, int L, int batch_heads, int rows, int64_t other_workgroups = 0) {
   // (the host knows S and L, not the level sizes: S / ROWS + L bounds the units of the 640-row split; the levels that gain a
   //  unit are the one or two smallest -- a heuristic for a tuning choice, any value is correct)
-  return int64_t(batch_heads) * (S / VNX_GVD_ROWS + L) <= VNX_GVD_ONE_ROUND ? 2 : 1;
+  //  `other_workgroups`: what shares the round with the units -- the grad_loc workgroups of the paired kernel, msda_d32.hip)
+  return int64_t(batch_heads) * (gvd_units_estimate(S, L, rows) + 2) + other_workgroups <= VNX_GVD_ONE_ROUND ? 2 : 1;
 }
-__host__ __device__ inline GvdSplit gvd_level_split(int n, int ut, int Lq, int P) {
+__host__ __device__ inline GvdSplit gvd_level_split(int n, int ut, int Lq, int P, int rows_max) {
   GvdSplit s{0, 1, 0};
   if (n <= 0) return s;
-  int units = (n + VNX_GVD_ROWS - 1) / VNX_GVD_ROWS;
+  int units = (n + rows_max - 1) / rows_max;
   if (units < ut) units = ut;
   if (units > n) units = n;
   s.rpu = (n + units - 1) / units;
