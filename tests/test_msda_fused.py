@@ -201,3 +201,40 @@ def test_fused_at_the_encoder_shape_of_the_baseline_configs(res):
     lhs = float((out.double() * gout.double()).sum())
     rhs = float((value.double() * v.grad.double()).sum())
     assert abs(lhs - rhs) <= 1e-4 * max(abs(lhs), 1.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ref_dim,ref_grad", [(2, True), (4, False)])
+def test_fused_backward_with_the_coarse_levels_staged_in_lds(ref_dim, ref_grad):
+    """msda_bwd_slab_kernel<FUSED> (development variant 734; measured in round 6, not the product path: msda_d32.hip,
+    fused_dispatch) against the gather form the product takes, on an encoder-sized call: every gradient incl. the
+    reference points', ragged query count."""
+    from vnext_amd import _lib
+    from vnext_amd.ops.functions import MSDeformAttnFusedFunction, level_tensors as lt
+    shapes = [(48, 80), (24, 40), (12, 20), (6, 10)]
+    dev = "cuda:0"
+    S = sum(h * w for h, w in shapes)
+    B, M, L, P, Lq = 2, 8, 4, 4, S - 3
+    g = torch.Generator(device=dev).manual_seed(29 + ref_dim)
+    value = torch.randn(B, S, M, 32, device=dev, generator=g)
+    offsets = 2.0 * torch.randn(B, Lq, M, L, P, 2, device=dev, generator=g)
+    logits = torch.randn(B, Lq, M, L * P, device=dev, generator=g)
+    ref = torch.rand(B, Lq, L, ref_dim, device=dev, generator=g)
+    if ref_dim == 4:
+        ref[..., 2:] = 0.05 + 0.1 * ref[..., 2:]
+    gout = torch.randn(B, Lq, M * 32, device=dev, generator=g)
+    shapes_t, lsi = lt(shapes, dev)
+
+    def grads(variant):
+        v, o, lg = value.clone().requires_grad_(True), offsets.clone().requires_grad_(True), logits.clone().requires_grad_(True)
+        r = ref.clone().requires_grad_(ref_grad)
+        _lib.set_kernel_variant(variant)
+        try:
+            MSDeformAttnFusedFunction.apply(v, shapes_t, lsi, o, lg, r).backward(gout)
+            torch.cuda.synchronize()
+        finally:
+            _lib.set_kernel_variant(0)
+        return [v.grad, o.grad, lg.grad] + ([r.grad] if ref_grad else [])
+    for name, got, want in zip(("value", "offsets", "logits", "reference"), grads(734), grads(0)):
+        scale = float(want.abs().max()) + 1e-12
+        assert float((got - want).abs().max()) <= 2e-5 * scale, name

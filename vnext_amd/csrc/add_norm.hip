@@ -12,6 +12,10 @@
 // Forward traffic: x, r read, y and z = x + dropout(r) written (z is what the backward needs; r is then dead);
 // backward: grad_y, z read, grad_x, grad_r written; the gamma / beta gradients leave as per-workgroup partial rows
 // that a second, tiny kernel adds in a fixed order (deterministic, no atomics).
+// Round 6: the BRANCH r (and its gradient) may be bf16 -- under torch.autocast(bfloat16) the Linear or attention output that
+// arrives here is bf16 while the residual stream x, the LayerNorm and its output are fp32, exactly the eager chain's types
+// (x + dropout(r) promotes; autocast runs layer_norm in fp32).  `dtype` of the C entry points names r's type; everything else
+// is fp32.  (Until then the op fell to the eager chain under autocast: 3 + 4 launches per site, 30 sites per step.)
 #include "vnx_common.h"
 
 #include <algorithm>
@@ -68,8 +72,9 @@ __device__ __forceinline__ float4_t an_residual(float4_t x, float4_t r, int64_t 
   return z;
 }
 
+template <typename TR>
 __global__ void __launch_bounds__(64 * kAnWaves)
-add_dropout_layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ r_bias,
+add_dropout_layernorm_fwd_kernel(const float* __restrict__ x, const TR* __restrict__ r, const float* __restrict__ r_bias,
                                  const float* __restrict__ gamma, const float* __restrict__ beta,
                                  float* __restrict__ y, float* __restrict__ z_out, float* __restrict__ stats,
                                  int64_t rows, uint32_t threshold, float scale, float eps, uint32_t seed_lo,
@@ -80,7 +85,7 @@ add_dropout_layernorm_fwd_kernel(const float* __restrict__ x, const float* __res
   if (threshold != 0u) an_effective_seed(seed_lo, seed_hi, seed_device);
   const int64_t at = row * kAnC + lane * 4;
   const float4_t xv = *reinterpret_cast<const float4_t*>(x + at);
-  float4_t rv = *reinterpret_cast<const float4_t*>(r + at);
+  float4_t rv = row4_load<TR>(r + at);
   if (r_bias != nullptr) rv += *reinterpret_cast<const float4_t*>(r_bias + lane * 4);      // r = Linear output WITHOUT its bias
   const float4_t g = *reinterpret_cast<const float4_t*>(gamma + lane * 4);
   const float4_t b = *reinterpret_cast<const float4_t*>(beta + lane * 4);
@@ -96,10 +101,11 @@ add_dropout_layernorm_fwd_kernel(const float* __restrict__ x, const float* __res
 
 // grad_x = dz, grad_r = keep * scale * dz, partial[block] = {sum_rows g * xhat, sum_rows g, sum_rows grad_r} over this
 // workgroup's rows (the third row is the gradient of the bias folded into r, ABI 11)
+template <typename TR>
 __global__ void __launch_bounds__(64 * kAnWaves)
 add_dropout_layernorm_bwd_kernel(const float* __restrict__ grad_y, const float* __restrict__ z,
                                  const float* __restrict__ stats, const float* __restrict__ gamma,
-                                 float* __restrict__ grad_x, float* __restrict__ grad_r, float* __restrict__ partial,
+                                 float* __restrict__ grad_x, TR* __restrict__ grad_r, float* __restrict__ partial,
                                  int64_t rows, uint32_t threshold, float scale, uint32_t seed_lo, uint32_t seed_hi,
                                  const unsigned long long* __restrict__ seed_device) {
   __shared__ float4_t red[kAnParts][kAnWaves][64];
@@ -130,7 +136,7 @@ add_dropout_layernorm_bwd_kernel(const float* __restrict__ grad_y, const float* 
       dr.w = an_hash(base + 3u, seed_lo, hi) >= threshold ? dz.w * scale : 0.f;
     }
     dbias += dr;
-    __builtin_nontemporal_store(dr, reinterpret_cast<float4_t*>(grad_r + at));
+    row4_store_nt<TR>(grad_r + at, dr);
   }
   red[0][wave][lane] = dg;
   red[1][wave][lane] = db;
@@ -176,7 +182,10 @@ layernorm_param_grad_kernel(const float* __restrict__ partial, float* __restrict
 }
 
 static int an_check(const char* who, int dtype, int64_t rows, int channels, float p) {
-  if (dtype != VNX_F32) { set_error("%s: only f32 is built (got dtype %d)", who, dtype); return VNX_ERR_UNSUPPORTED; }
+  if (dtype != VNX_F32 && dtype != VNX_BF16) {
+    set_error("%s: the branch is f32 or bf16 (got dtype %d)", who, dtype);
+    return VNX_ERR_UNSUPPORTED;
+  }
   if (channels != kAnC) { set_error("%s: built for %d channels per row (got %d)", who, kAnC, channels); return VNX_ERR_UNSUPPORTED; }
   if (rows < 0 || rows >= (int64_t(1) << 40) || !(p >= 0.f && p < 1.f)) {
     set_error("%s: bad sizes rows=%lld p=%g", who, (long long)rows, double(p));
@@ -207,10 +216,13 @@ extern "C" int vnx_add_dropout_layernorm_forward(int dtype, const void* x, const
     return VNX_ERR_INVALID_ARGUMENT;
   }
   const int64_t blocks = (rows + kAnWaves - 1) / kAnWaves;
-  hipLaunchKernelGGL(add_dropout_layernorm_fwd_kernel, dim3(uint32_t(blocks)), dim3(64 * kAnWaves), 0,
-                     (hipStream_t)hip_stream, (const float*)x, (const float*)r, (const float*)r_bias, (const float*)gamma,
-                     (const float*)beta, (float*)y, (float*)z, (float*)stats, int64_t(rows), an_threshold(p), 1.f / (1.f - p), eps,
-                     uint32_t(seed), uint32_t(seed >> 32), seed_device);
+#define VNX_AN_FWD(TR)                                                                                                   \
+  hipLaunchKernelGGL(add_dropout_layernorm_fwd_kernel<TR>, dim3(uint32_t(blocks)), dim3(64 * kAnWaves), 0,               \
+                     (hipStream_t)hip_stream, (const float*)x, (const TR*)r, (const float*)r_bias, (const float*)gamma,  \
+                     (const float*)beta, (float*)y, (float*)z, (float*)stats, int64_t(rows), an_threshold(p),           \
+                     1.f / (1.f - p), eps, uint32_t(seed), uint32_t(seed >> 32), seed_device)
+  if (dtype == VNX_BF16) VNX_AN_FWD(bf16_t); else VNX_AN_FWD(float);
+#undef VNX_AN_FWD
   return check_launch("add_dropout_layernorm_fwd");
 }
 
@@ -231,10 +243,13 @@ extern "C" int vnx_add_dropout_layernorm_backward(int dtype, const void* grad_y,
       set_error("vnx_add_dropout_layernorm_backward: null pointer argument");
       return VNX_ERR_INVALID_ARGUMENT;
     }
-    hipLaunchKernelGGL(add_dropout_layernorm_bwd_kernel, dim3(uint32_t(blocks)), dim3(64 * kAnWaves), 0, stream,
-                       (const float*)grad_y, (const float*)z, (const float*)stats, (const float*)gamma, (float*)grad_x,
-                       (float*)grad_r, (float*)partial, int64_t(rows), an_threshold(p), 1.f / (1.f - p), uint32_t(seed),
-                       uint32_t(seed >> 32), seed_device);
+#define VNX_AN_BWD(TR)                                                                                                   \
+    hipLaunchKernelGGL(add_dropout_layernorm_bwd_kernel<TR>, dim3(uint32_t(blocks)), dim3(64 * kAnWaves), 0, stream,       \
+                       (const float*)grad_y, (const float*)z, (const float*)stats, (const float*)gamma, (float*)grad_x,   \
+                       (TR*)grad_r, (float*)partial, int64_t(rows), an_threshold(p), 1.f / (1.f - p), uint32_t(seed),     \
+                       uint32_t(seed >> 32), seed_device)
+    if (dtype == VNX_BF16) VNX_AN_BWD(bf16_t); else VNX_AN_BWD(float);
+#undef VNX_AN_BWD
   } else {
     blocks = 0;
   }

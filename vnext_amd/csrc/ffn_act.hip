@@ -13,6 +13,8 @@
 //   * y > 0  <=>  the element passed the ReLU AND was kept, so the backward needs neither a mask nor the seed:
 //     g_h = y > 0 ? g / (1 - p) : 0, read from the activation linear2's weight gradient needs anyway;
 //   * grad_bias[c] = sum_rows g_h[row][c]: per-workgroup partial rows, then a fixed-order reduction (deterministic).
+// Round 6: h, the gradient that comes in and the one that goes out may be bf16 (`dtype`; under torch.autocast(bfloat16) the
+// GEMMs around this pass emit and take bf16); the bias, its gradient and the partial sums stay fp32, the arithmetic is fp32.
 #include "vnx_common.h"
 
 #include <algorithm>
@@ -42,8 +44,9 @@ __device__ __forceinline__ void fa_effective_seed(uint32_t& lo, uint32_t& hi, co
 
 // in place over h [rows, cols]; thread = 4 consecutive columns (blockIdx.x * 256 + threadIdx.x), rows blockIdx.y,
 // blockIdx.y + gridDim.y, ...: no division anywhere, the bias quad is loaded once per thread
+template <typename T>
 __global__ void __launch_bounds__(256)
-bias_relu_dropout_fwd_kernel(float* __restrict__ h, const float* __restrict__ bias, const uint8_t* __restrict__ row_zero,
+bias_relu_dropout_fwd_kernel(T* __restrict__ h, const float* __restrict__ bias, const uint8_t* __restrict__ row_zero,
                              int64_t rows, int cols4, int relu, uint32_t threshold, float scale, uint32_t seed_lo,
                              uint32_t seed_hi, const unsigned long long* __restrict__ seed_device) {
   const int c4 = int(blockIdx.x) * 256 + int(threadIdx.x);
@@ -53,10 +56,10 @@ bias_relu_dropout_fwd_kernel(float* __restrict__ h, const float* __restrict__ bi
   for (int64_t row = blockIdx.y; row < rows; row += gridDim.y) {
     const int64_t i = row * cols4 + c4;                                // float4 index
     if (row_zero != nullptr && row_zero[row]) {                        // a padding row: zeros, whatever h holds (masked_fill)
-      *reinterpret_cast<ffn_f4*>(h + i * 4) = ffn_f4{0.f, 0.f, 0.f, 0.f};
+      row4_store<T>(h + i * 4, ffn_f4{0.f, 0.f, 0.f, 0.f});
       continue;
     }
-    ffn_f4 v = *reinterpret_cast<const ffn_f4*>(h + i * 4) + b;
+    ffn_f4 v = row4_load<T>(h + i * 4) + b;
     // (a comparison, not fmaxf: fmaxf(NaN, 0) is 0, ATen's relu(NaN) is NaN -- a diverging run must stay visible)
     if (relu) { v.x = v.x <= 0.f ? 0.f : v.x; v.y = v.y <= 0.f ? 0.f : v.y; v.z = v.z <= 0.f ? 0.f : v.z; v.w = v.w <= 0.f ? 0.f : v.w; }
     if (threshold != 0u) {
@@ -67,33 +70,34 @@ bias_relu_dropout_fwd_kernel(float* __restrict__ h, const float* __restrict__ bi
       v.z = fa_hash(base + 2u, seed_lo, hi) >= threshold ? v.z * scale : 0.f;
       v.w = fa_hash(base + 3u, seed_lo, hi) >= threshold ? v.w * scale : 0.f;
     }
-    *reinterpret_cast<ffn_f4*>(h + i * 4) = v;
+    row4_store<T>(h + i * 4, v);
   }
 }
 
 // g [rows, cols] -> out (out may be g itself: every element is read before it is written, by the same thread); thread t owns
 // columns 4t..4t+3, a workgroup (cols / 4 threads) walks the rows blockIdx.x, blockIdx.x + gridDim.x, ...;
 // partial[blockIdx.x][cols] = this workgroup's column sums
+template <typename T>
 __global__ void __launch_bounds__(1024)
-bias_relu_dropout_bwd_kernel(const float* g, const float* __restrict__ y, const uint8_t* __restrict__ row_zero, float* out,
+bias_relu_dropout_bwd_kernel(const T* g, const T* __restrict__ y, const uint8_t* __restrict__ row_zero, T* out,
                              float* __restrict__ partial, int64_t rows, int cols, float scale) {
   const int c = int(threadIdx.x) * 4;
   ffn_f4 acc = {0.f, 0.f, 0.f, 0.f};
   for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
     const int64_t at = row * cols + c;
-    ffn_f4 gv = *reinterpret_cast<const ffn_f4*>(g + at);
+    ffn_f4 gv = row4_load<T>(g + at);
     if (row_zero != nullptr && row_zero[row]) gv = ffn_f4{0.f, 0.f, 0.f, 0.f};
     if (y != nullptr) {                         // ReLU (+ dropout): y > 0 <=> passed and kept
       // written as !(y <= 0), ATen's threshold_backward: a NaN activation lets its gradient through instead of
       // silently zeroing it (a diverging run must stay visible downstream)
-      const ffn_f4 yv = *reinterpret_cast<const ffn_f4*>(y + at);
+      const ffn_f4 yv = row4_load<T>(y + at);
       gv.x = !(yv.x <= 0.f) ? gv.x * scale : 0.f;
       gv.y = !(yv.y <= 0.f) ? gv.y * scale : 0.f;
       gv.z = !(yv.z <= 0.f) ? gv.z * scale : 0.f;
       gv.w = !(yv.w <= 0.f) ? gv.w * scale : 0.f;
     }
     acc += gv;
-    *reinterpret_cast<ffn_f4*>(out + at) = gv;
+    row4_store<T>(out + at, gv);
   }
   if (partial != nullptr) *reinterpret_cast<ffn_f4*>(partial + int64_t(blockIdx.x) * cols + c) = acc;
 }
@@ -122,7 +126,7 @@ column_partial_sum_kernel(const float* __restrict__ partial, float* __restrict__
 }
 
 static int fa_check(const char* who, int dtype, int64_t rows, int cols, float p) {
-  if (dtype != VNX_F32) { set_error("%s: only f32 is built (got dtype %d)", who, dtype); return VNX_ERR_UNSUPPORTED; }
+  if (dtype != VNX_F32 && dtype != VNX_BF16) { set_error("%s: f32 or bf16 rows (got dtype %d)", who, dtype); return VNX_ERR_UNSUPPORTED; }
   if (cols <= 0 || (cols & 3) || cols > kFaMaxCols) {
     set_error("%s: built for rows of 4..%d channels, a multiple of 4 (got %d)", who, kFaMaxCols, cols);
     return VNX_ERR_UNSUPPORTED;
@@ -162,9 +166,12 @@ extern "C" int vnx_bias_relu_dropout_forward(int dtype, void* h, const void* bia
   }
   const int cols4 = channels / 4;
   const dim3 grid(uint32_t((cols4 + 255) / 256), uint32_t(std::min<int64_t>(rows, 16384)));
-  hipLaunchKernelGGL(bias_relu_dropout_fwd_kernel, grid, dim3(256), 0, (hipStream_t)hip_stream, (float*)h,
-                     (const float*)bias, (const uint8_t*)row_zero, int64_t(rows), channels / 4, relu, fa_threshold(p),
-                     1.f / (1.f - p), uint32_t(seed), uint32_t(seed >> 32), seed_device);
+#define VNX_FA_FWD(T)                                                                                                  \
+  hipLaunchKernelGGL(bias_relu_dropout_fwd_kernel<T>, grid, dim3(256), 0, (hipStream_t)hip_stream, (T*)h,              \
+                     (const float*)bias, (const uint8_t*)row_zero, int64_t(rows), channels / 4, relu, fa_threshold(p), \
+                     1.f / (1.f - p), uint32_t(seed), uint32_t(seed >> 32), seed_device)
+  if (dtype == VNX_BF16) VNX_FA_FWD(bf16_t); else VNX_FA_FWD(float);
+#undef VNX_FA_FWD
   return check_launch("bias_relu_dropout_fwd");
 }
 
@@ -183,9 +190,12 @@ extern "C" int vnx_bias_relu_dropout_backward(int dtype, const void* grad, const
       set_error("vnx_bias_relu_dropout_backward: null pointer argument");
       return VNX_ERR_INVALID_ARGUMENT;
     }
-    hipLaunchKernelGGL(bias_relu_dropout_bwd_kernel, dim3(uint32_t(blocks)), dim3(channels / 4), 0, stream, (const float*)grad,
-                       (const float*)y, (const uint8_t*)row_zero, (float*)grad_h, grad_bias ? (float*)partial : (float*)nullptr,
-                       int64_t(rows), channels, 1.f / (1.f - p));
+#define VNX_FA_BWD(T)                                                                                                         \
+    hipLaunchKernelGGL(bias_relu_dropout_bwd_kernel<T>, dim3(uint32_t(blocks)), dim3(channels / 4), 0, stream, (const T*)grad, \
+                       (const T*)y, (const uint8_t*)row_zero, (T*)grad_h, grad_bias ? (float*)partial : (float*)nullptr,       \
+                       int64_t(rows), channels, 1.f / (1.f - p))
+    if (dtype == VNX_BF16) VNX_FA_BWD(bf16_t); else VNX_FA_BWD(float);
+#undef VNX_FA_BWD
   } else {
     blocks = 0;
   }

@@ -1767,11 +1767,16 @@ int msda_backward_pair_d32(int vdt, const void* value, const int64_t* shapes, co
 // row> of each of its query's 16 samples -- rows of the staged levels from LDS, the others gathered -- and the decode's lane
 // of each sample combines them (cuh:123-158) and stores the gradients once, non-temporal.  The dots of a sample overwrite its
 // tap offsets in the wave's records (they are in registers by then), so the LDS budget is the forward's.
+// FUSED (round 6; what the models' encoder layers call): `loc` / `attn` are the raw offsets and attention logits of the fused
+// prologue (fused_decode: reference point + scaled offset, softmax over a (query, head)'s 16 logits), the decoded locations
+// and weights are left for the tile-fed grad_value kernel in fa.tile_loc / fa.tile_attn, and phase 3 applies the chain rule
+// through the prologue as the gather kernel's FUSED instantiation does (msda_bwd_d32_body).
+template <bool FUSED>
 __global__ void __launch_bounds__(64 * kSlabWaves, 2 * kSlabWaves / 4)
 msda_bwd_slab_kernel(const float* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
                      const float* __restrict__ loc, const float* __restrict__ attn, const float* __restrict__ grad_out,
                      float* __restrict__ grad_loc, float* __restrict__ grad_attn, uint32_t* __restrict__ tile_summary, MsdaDims d,
-                     int parts, unsigned long long* stamps) {
+                     int parts, unsigned long long* stamps, FusedArgs fa) {
   stamp_begin(stamps);
   constexpr int D = 32, LP = 16, kRowBytes = 128;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1835,10 +1840,22 @@ msda_bwd_slab_kernel(const float* __restrict__ value, const int64_t* __restrict_
       uint4_t o4 = {none, none, none, none};
       float4_t g4 = {0.f, 0.f, 0.f, 0.f};
       uint32_t tile_kx = 0xffffffffu, tile_ky = 0xffffffffu;
+      const int64_t wi = ((int64_t(b) * d.Lq + q) * d.M + m) * LP + p;
+      float sx = 0.f, sy = 0.f, a = 0.f;
+      if constexpr (FUSED) {      // (all 16 lanes of a (query, head) row together: q is uniform over them)
+        const bool valid = q < d.Lq;
+        float dx, dy;
+        fused_decode<float>(loc, attn, fa, wi, b, q, l, valid ? s_lvl[4 * l] : 1, valid ? s_lvl[4 * l + 1] : 1, d, valid, sx, sy, a, dx, dy);
+        g4.w = a;      // the softmax weight of every sample, in or out of the map (softmax backward, phase 3)
+        if (valid && fa.tile_loc != nullptr) {      // [batch][head][level][query][point]: what the tile-fed grad_value kernel walks
+          const int64_t ci = ((int64_t(b) * d.M + m) * 4 + l) * (int64_t(d.Lq) * 4) + int64_t(q) * 4 + (p & 3);
+          *reinterpret_cast<float2_t*>(fa.tile_loc + 2 * ci) = float2_t{sx, sy};
+          fa.tile_attn[ci] = a;
+        }
+      }
       if (q < d.Lq) {
-        const int64_t wi = ((int64_t(b) * d.Lq + q) * d.M + m) * LP + p;
         const int H = s_lvl[4 * l], W = s_lvl[4 * l + 1], start = s_lvl[4 * l + 2];
-        const float sx = loc[2 * wi], sy = loc[2 * wi + 1], a = attn[wi];
+        if constexpr (!FUSED) { sx = loc[2 * wi]; sy = loc[2 * wi + 1]; a = attn[wi]; }
         const float h = sy * float(H) - 0.5f, w = sx * float(W) - 0.5f;
         if (h > -1.f && w > -1.f && h < float(H) && w < float(W)) {
           const float hf = floorf(h), wf = floorf(w);
@@ -1942,8 +1959,35 @@ msda_bwd_slab_kernel(const float* __restrict__ value, const int64_t* __restrict_
         const float gh = a * (hw * (d3 - d1) + lw * (d4 - d2));
         const float ga = hh * (hw * d1 + lw * d2) + lh * (hw * d3 + lw * d4);
         const float Hf = float(s_lvl[4 * l]), Wf = float(s_lvl[4 * l + 1]);
-        __builtin_nontemporal_store(float2_t{Wf * gw, Hf * gh}, reinterpret_cast<float2_t*>(grad_loc + 2 * wi));
-        __builtin_nontemporal_store(ga, grad_attn + wi);
+        if constexpr (!FUSED) {
+          __builtin_nontemporal_store(float2_t{Wf * gw, Hf * gh}, reinterpret_cast<float2_t*>(grad_loc + 2 * wi));
+          __builtin_nontemporal_store(ga, grad_attn + wi);
+        } else {
+          // chain rule through the prologue (as msda_bwd_d32_body): d loc / d offset is a per-sample scale, the softmax backward
+          // g_logit = a (g_a - sum_j a_j g_a_j) a 16-lane row sum, and 2-d reference points collect the location gradients of
+          // their level over points (lanes) and heads (atomics)
+          const float gx = Wf * gw, gy = Hf * gh, aw = gq.w;
+          const float dot = row16_sum(aw * ga);
+          float kx, ky;
+          if (fa.ref_dim == 2) {
+            kx = 1.f / Wf; ky = 1.f / Hf;
+          } else {
+            const float* rf = static_cast<const float*>(fa.reference) + ((int64_t(b / fa.ref_div) * d.Lq + q) * d.L + l) * 4;
+            kx = rf[2] * 0.5f / 4.f; ky = rf[3] * 0.5f / 4.f;
+          }
+          __builtin_nontemporal_store(float2_t{gx * kx, gy * ky}, reinterpret_cast<float2_t*>(grad_loc + 2 * wi));
+          __builtin_nontemporal_store(aw * (ga - dot), grad_attn + wi);
+          if (fa.grad_reference != nullptr) {
+            float rx = gx, ry = gy;
+            rx += __shfl_xor(rx, 1, 16); ry += __shfl_xor(ry, 1, 16);
+            rx += __shfl_xor(rx, 2, 16); ry += __shfl_xor(ry, 2, 16);
+            if ((p & 3) == 0) {
+              float* gr = fa.grad_reference + ((int64_t(b) * d.Lq + q) * d.L + l) * 2;
+              atomic_add(gr, rx);
+              atomic_add(gr + 1, ry);
+            }
+          }
+        }
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -1951,9 +1995,10 @@ msda_bwd_slab_kernel(const float* __restrict__ value, const int64_t* __restrict_
   stamp_end(stamps);
 }
 
+template <bool FUSED>
 static int launch_bwd_slab(const void* value, const int64_t* shapes, const int64_t* lsi, const void* loc, const void* attn,
                            const void* grad_out, void* grad_loc, void* grad_attn, void* tile_summary, const MsdaDims& d,
-                           hipStream_t stream) {
+                           const FusedArgs& fa, hipStream_t stream) {
   const int n_tiles = (d.Lq + kSlabWaves * kSlabQpw - 1) / (kSlabWaves * kSlabQpw);
   const int parts = slab_parts(d, n_tiles);
   const int64_t blocks = int64_t(parts) * d.B * d.M;
@@ -1961,16 +2006,16 @@ static int launch_bwd_slab(const void* value, const int64_t* shapes, const int64
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (raised_on != dev) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&msda_bwd_slab_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&msda_bwd_slab_kernel<FUSED>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             int(kSlabLdsBytes)) != hipSuccess)
       return check_launch("msda_bwd_slab (LDS limit)");
     raised_on = dev;
   }
-  hipLaunchKernelGGL(msda_bwd_slab_kernel, dim3(uint32_t(blocks)), dim3(64 * kSlabWaves), kSlabLdsBytes, stream,
+  hipLaunchKernelGGL(msda_bwd_slab_kernel<FUSED>, dim3(uint32_t(blocks)), dim3(64 * kSlabWaves), kSlabLdsBytes, stream,
                      (const float*)value, shapes, lsi, (const float*)loc, (const float*)attn, (const float*)grad_out,
                      (float*)grad_loc, (float*)grad_attn, (uint32_t*)tile_summary, d, parts,
-                     take_stamp_region(kStampGradLoc, blocks));
-  return check_launch("msda_bwd_slab");
+                     take_stamp_region(kStampGradLoc, blocks), fa);
+  return check_launch(FUSED ? "msda_bwd_slab_fused" : "msda_bwd_slab");
 }
 
 int msda_bwd_tile_queries(const MsdaDims& d, int variant) {
@@ -1999,7 +2044,7 @@ int msda_backward_d32(int vdt, int ldt, const void* value, const int64_t* shapes
     const int kv = kernel_variant();
     if (vdt == VNX_F32 && ldt == VNX_F32 && v == 0 && gv == nullptr && records == nullptr && tile_copy == nullptr &&
         tile_summary != nullptr && kv != 733 && msda_bwd_tile_queries(d, 0) == 4 && use_slab_forward(vdt, ldt, d, kv))
-      return launch_bwd_slab(value, shapes, lsi, loc, attn, grad_out, grad_loc, grad_attn, tile_summary, d, stream);
+      return launch_bwd_slab<false>(value, shapes, lsi, loc, attn, grad_out, grad_loc, grad_attn, tile_summary, d, FusedArgs{}, stream);
   }
   if (vdt == VNX_F32) return launch_bwd<float, float>(VNX_ARGS);
   if (vdt == VNX_BF16 && ldt == VNX_F32) return launch_bwd<bf16_t, float>(VNX_ARGS);
@@ -2061,6 +2106,15 @@ static int fused_dispatch(bool backward, const void* value, const int64_t* shape
   if constexpr (sizeof(TV) == 4 && sizeof(TL) == 4) {      // encoder calls: the coarse levels staged in LDS (msda_fwd_slab_kernel)
     if (!backward && use_slab_forward(VNX_F32, VNX_F32, d, kernel_variant()))
       return launch_fwd_slab<float>(value, shapes, lsi, raw_off, raw_logit, out_or_grad_off, d, &fa, stream);
+    // ... their backward, tile-fed grad_value: msda_bwd_slab_kernel<true> was built and measured in round 6 (boxes per 4 queries, as
+    // the automatic configuration's) and is NOT the product path -- kbench cold, fused backward, slab / gather form of the grad_loc
+    // half: encoder-360p B = 5 175.2 / 171.0 us, B = 10 356.6 / 322.5, 720p B = 5 660.7 / 632.0, B = 2 287.0 / 286.0.  The fused
+    // form decodes (exp, two 16-lane reductions per sample) and writes the 12-byte decoded copy of every sample on top of the
+    // unfused kernel's work, at four waves per SIMD (128 VGPRs, 32 B of scratch): the slab's few per cent (66.0 against 69.7 us
+    // unfused) do not survive it.  Development build only: variant 734.
+    if (backward && records == nullptr && tile_summary != nullptr && fa.tile_loc != nullptr && fa.qsplit_zero == nullptr &&
+        kernel_variant() == 734 && msda_bwd_tile_queries(d, 0) == 4 && use_slab_forward(VNX_F32, VNX_F32, d, 0))
+      return launch_bwd_slab<true>(value, shapes, lsi, raw_off, raw_logit, grad_out, out_or_grad_off, grad_logit, tile_summary, d, fa, stream);
   }
   const FwdCfg c = pick_fwd_cfg(d, 0);
 #define VNX_CASE(Q, W)                                                                                   \

@@ -43,6 +43,15 @@ namespace rec {
 #ifndef VNX_GVT_ABL
 #define VNX_GVT_ABL 0
 #endif
+// Workgroup order: 0 = the batch element minor (all B batch elements of a unit on neighbouring workgroups), 1 = major
+// (gv_decode_block_bm).  Round 6, measured both ways (kbench cold + FETCH_SIZE): major fetches less -- 619 against 722 MB per 720p
+// B = 5 launch, 68.5 against 95.3 at 360p (counter units as reported) -- and is SLOWER: encoder-360p backward 185.5 against
+// 150.9 us, 720p B = 5 716.5 against 575.9, B = 2 308.8 against 257.5, bf16 165.8 against 130.8.  The kernel is bound by issue and
+// LDS, not by what it fetches, and with one batch element resident per XCD its ~90 units all read the same tile words and the
+// same stretch of decoded samples at the same time.  Minor stays.
+#ifndef VNX_GVT_BATCH_MAJOR
+#define VNX_GVT_BATCH_MAJOR 0
+#endif
 constexpr int kTileRowsMax = kGvTileRowsMax;      // 256 rows per unit: 4 per 8-lane group
 constexpr int kTileRounds = VNX_TILE_ROUNDS;
 constexpr int kTileWin = kTileRounds * kThreads;  // tile words examined per selection round: 1 024
@@ -58,7 +67,7 @@ msda_bwd_gv_tiles_kernel(const int64_t* __restrict__ shapes, const int64_t* __re
                          const TL* __restrict__ loc, const TL* __restrict__ attn,
                          const uint2_t* __restrict__ summaries, const TV* __restrict__ grad_out,
                          TV* __restrict__ grad_value, MsdaDims d, int units_min, int tile_shift, int n_tiles,
-                         float* __restrict__ partials, int compact) {
+                         float* __restrict__ partials, int compact, int units_pb) {
   constexpr int D = 32, P = 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float4_t* grows = reinterpret_cast<float4_t*>(smem);                       // [128][8] grad_out rows
@@ -74,12 +83,21 @@ msda_bwd_gv_tiles_kernel(const int64_t* __restrict__ shapes, const int64_t* __re
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // dispatch order = cost order (units numbered from the last level back), head <-> XCD map rotating with the
-  // batch element: as in msda_d32_gvrec.hip
-  int rest, b, m;
-  if (kGvPair16 && sizeof(TV) == 2 && (d.M & 1) == 0) gv_decode_block<true>(blockIdx.x, d.M, d.B, rest, b, m);
-  else gv_decode_block<false>(blockIdx.x, d.M, d.B, rest, b, m);
-  const int unit = rest / d.B;
+  // dispatch order = batch element, then cost order (units numbered from the last level back); head <-> XCD map rotating
+  // with the batch element: gv_decode_block_bm (msda_gv_common.h)
+  int unit, b, m;
+#if VNX_GVT_BATCH_MAJOR
+  if (kGvPair16 && sizeof(TV) == 2 && (d.M & 1) == 0) gv_decode_block_bm<true>(blockIdx.x, d.M, units_pb, unit, b, m);
+  else gv_decode_block_bm<false>(blockIdx.x, d.M, units_pb, unit, b, m);
+  if (b >= d.B) return;      // uniform: the padding workgroup of an odd grid
+#else
+  {
+    int rest;
+    if (kGvPair16 && sizeof(TV) == 2 && (d.M & 1) == 0) gv_decode_block<true>(blockIdx.x, d.M, d.B, rest, b, m);
+    else gv_decode_block<false>(blockIdx.x, d.M, d.B, rest, b, m);
+    unit = rest / d.B;
+  }
+#endif
 
   if (tid < d.L) {     // level table: {H, W, start, workgroups, query pieces, block width, blocks per row, block height}
     const int H = int(shapes[2 * tid]), W = int(shapes[2 * tid + 1]);
@@ -462,11 +480,12 @@ static int launch_gvtiles(const int64_t* shapes, const int64_t* lsi, const void*
     return VNX_ERR_UNSUPPORTED;
   }
   const int n_tiles = (d.Lq + tile_queries - 1) / tile_queries;
-  const int64_t blocks = ((int64_t(d.B) * msda_gvtiles_units_bound(d, units_min) + 1) & ~int64_t(1)) * d.M;   // even: gv_decode_block
+  const int units_pb = msda_gvtiles_units_bound(d, units_min);
+  const int64_t blocks = ((int64_t(d.B) * units_pb + 1) & ~int64_t(1)) * d.M;   // even: gv_decode_block
   hipLaunchKernelGGL((rec::msda_bwd_gv_tiles_kernel<TV, TL>), dim3(uint32_t(blocks)), dim3(rec::kThreads),
                      rec::kTilesLdsBytes, stream, shapes, lsi, (const TL*)loc, (const TL*)attn,
                      (const rec::uint2_t*)summaries, (const TV*)grad_out, (TV*)grad_value, d, units_min, tile_shift, n_tiles,
-                     partials, compact);
+                     partials, compact, units_pb);
   int st = check_launch("msda_bwd_gv_tiles");
   if (st != VNX_OK) return st;
   // the pieces of the query-split levels -> grad_value (sized by the bound on split pixels; idle threads leave at once)

@@ -96,6 +96,28 @@ __device__ __forceinline__ void gv_decode_block(uint32_t block, int M, int B, in
     m = (x + b) % M;
   }
 }
+// The same map with the BATCH ELEMENT major (round 6; the tile-fed kernel): workgroup -> (batch element, unit), all
+// `units_pb` units of a batch element before the next one's.  The workgroups resident on an XCD at one time then belong to
+// one or two batch elements, whose grad_out rows, decoded samples and tile words of the XCD's head class (6 MB per batch
+// element at 720p) are re-read from that XCD's 4-MB L2 by neighbouring units instead of from memory: with the batch element
+// minor every resident group of units spans all B of them (the change that cut the slab forward's reads 929 -> 379 MB).
+// b may come out as B for the padding workgroup of an odd grid: the caller leaves.
+template <bool PAIR>
+__device__ __forceinline__ void gv_decode_block_bm(uint32_t block, int M, int units_pb, int& unit, int& b, int& m) {
+  const int x = int(block % uint32_t(M)), j = int(block / uint32_t(M));
+  if constexpr (PAIR) {
+    const int half = M >> 1;
+    const int xh = x % half, side = x / half;
+    const int rest = (j >> 1) * 2 + side;
+    b = rest / units_pb;
+    unit = rest - b * units_pb;
+    m = 2 * ((xh + b) % half) + (j & 1);
+  } else {
+    b = j / units_pb;
+    unit = j - b * units_pb;
+    m = (x + b) % M;
+  }
+}
 #ifdef VNX_GV_PAIR16
 constexpr bool kGvPair16 = true;
 #else

@@ -37,11 +37,32 @@ __device__ __forceinline__ uint32_t f32x2_to_bf16x2(float lo, float hi) {       
 }
 __device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) { return uint16_t(f32x2_to_bf16x2(f, 0.f)); }
 
+// four consecutive channels of a row as fp32, whatever the storage type (fp32: 16 bytes, bf16 / f16: 8) -- the element-wise kernels
+// of the layer stack (add_norm.hip, ffn_act.hip) compute in fp32 and round once on the way out
+typedef float vnx_f4 __attribute__((ext_vector_type(4)));
+typedef uint32_t vnx_u2 __attribute__((ext_vector_type(2)));
+template <typename T> __device__ __forceinline__ vnx_f4 row4_load(const T* p);
+template <> __device__ __forceinline__ vnx_f4 row4_load<float>(const float* p) { return *reinterpret_cast<const vnx_f4*>(p); }
+template <> __device__ __forceinline__ vnx_f4 row4_load<bf16_t>(const bf16_t* p) {
+  const vnx_u2 r = *reinterpret_cast<const vnx_u2*>(p);
+  return vnx_f4{__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u)};
+}
+template <typename T> __device__ __forceinline__ void row4_store(T* p, vnx_f4 v);
+template <> __device__ __forceinline__ void row4_store<float>(float* p, vnx_f4 v) { *reinterpret_cast<vnx_f4*>(p) = v; }
+template <typename T> __device__ __forceinline__ void row4_store_nt(T* p, vnx_f4 v);
+template <> __device__ __forceinline__ void row4_store_nt<float>(float* p, vnx_f4 v) { __builtin_nontemporal_store(v, reinterpret_cast<vnx_f4*>(p)); }
+
 template <typename T> __device__ __forceinline__ T from_acc(acc_t<T> x);
 template <> __device__ __forceinline__ float from_acc<float>(float x) { return x; }
 template <> __device__ __forceinline__ double from_acc<double>(double x) { return x; }
 template <> __device__ __forceinline__ bf16_t from_acc<bf16_t>(float x) { return bf16_t{f32_to_bf16_bits(x)}; }
 template <> __device__ __forceinline__ f16_t from_acc<f16_t>(float x) { return f16_t{_Float16(x)}; }
+template <> __device__ __forceinline__ void row4_store<bf16_t>(bf16_t* p, vnx_f4 v) {
+  *reinterpret_cast<vnx_u2*>(p) = vnx_u2{f32x2_to_bf16x2(v.x, v.y), f32x2_to_bf16x2(v.z, v.w)};
+}
+template <> __device__ __forceinline__ void row4_store_nt<bf16_t>(bf16_t* p, vnx_f4 v) {
+  __builtin_nontemporal_store(vnx_u2{f32x2_to_bf16x2(v.x, v.y), f32x2_to_bf16x2(v.z, v.w)}, reinterpret_cast<vnx_u2*>(p));
+}
 
 // hardware floating-point atomics (global_atomic_add_f32 / _f64), agent scope
 __device__ __forceinline__ void atomic_add(float* p, float v) { unsafeAtomicAdd(p, v); }

@@ -20,7 +20,9 @@ def flatten_levels(srcs, masks, pos_embeds, level_embed):
     sizes = [tuple(int(v) for v in s.shape[-2:]) for s in srcs]
     total = sum(h * w for h, w in sizes)
     feats = srcs[0].new_empty(*lead, total, channels)
-    pos = pos_embeds[0].new_empty(*lead, total, channels)
+    # (the sum's own dtype: under bf16 autocast the position embeddings may arrive in bf16 while the level embedding is an fp32
+    #  parameter -- the promoted sum must not be rounded back into a bf16 buffer; the `cat`-based form kept it: ADVICE r5)
+    pos = pos_embeds[0].new_empty(*lead, total, channels, dtype=torch.result_type(pos_embeds[0], level_embed))
     pad = masks[0].new_empty(*lead, total)
     at = 0
     for lvl, (h, w) in enumerate(sizes):

@@ -14,7 +14,8 @@ which ATen runs as three clamps, a subtraction, a division, a log, a slice + add
 
 a softmax, a broadcast multiply and a reduction forward; two multiplies, two reductions and the softmax backward.
 
-Both ARE those expressions (evaluated by torch) wherever the kernels do not apply: CPU, autocast, other dtypes.
+Both ARE those expressions (evaluated by torch) wherever the kernels do not apply: CPU, other dtypes.  Under torch.autocast
+the 16-bit tensors a Linear hands over are promoted on the way in and the results are fp32 (round 6).
 """
 from __future__ import annotations
 
@@ -25,6 +26,7 @@ import torch
 from .. import _lib
 
 EPS = 1e-5
+_FLOATS = (torch.float32, torch.bfloat16, torch.float16)      # 16-bit inputs only under autocast: promoted by custom_fwd, results fp32
 ENABLE = os.environ.get("VNX_FUSED_DECODER_GLUE", "1") != "0"      # A/B switch: off = the reference expressions, by torch
 
 
@@ -35,7 +37,9 @@ def inverse_sigmoid(x, eps=EPS):
 
 
 class _RefineBoxes(torch.autograd.Function):
+    # (autocast: the box MLP's bf16 output is promoted on the way in, the boxes come out fp32 -- custom_fwd)
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, delta, reference):
         lib = _lib.lib()
         delta, reference = delta.contiguous(), reference.contiguous()
@@ -48,11 +52,12 @@ class _RefineBoxes(torch.autograd.Function):
         return out
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     @torch.autograd.function.once_differentiable
     def backward(ctx, grad_out):
         lib = _lib.lib()
         out, reference = ctx.saved_tensors
-        grad_out = grad_out.contiguous()
+        grad_out = grad_out.float().contiguous()
         grad_delta = torch.empty_like(out)
         grad_ref = torch.empty_like(reference) if ctx.needs_input_grad[1] else None
         with torch.cuda.device(out.device):
@@ -66,9 +71,9 @@ class _RefineBoxes(torch.autograd.Function):
 def refined_boxes(delta, reference_points):
     """The layer's refined boxes (see the module docstring), WITH their graph: they are also the layer's box prediction (the
     reference's detector evaluates the same expression a second time for its loss, deformable_detr.py:195-213)."""
-    if (ENABLE and delta.is_cuda and delta.dtype == torch.float32 and reference_points.dtype == torch.float32
-            and delta.shape[-1] == 4 and reference_points.shape[-1] in (2, 4) and delta.shape[:-1] == reference_points.shape[:-1]
-            and not torch.is_autocast_enabled()):
+    if (ENABLE and delta.is_cuda and delta.dtype in _FLOATS and reference_points.dtype in _FLOATS
+            and (delta.dtype == torch.float32 or torch.is_autocast_enabled())
+            and delta.shape[-1] == 4 and reference_points.shape[-1] in (2, 4) and delta.shape[:-1] == reference_points.shape[:-1]):
         return _RefineBoxes.apply(delta, reference_points)
     if reference_points.shape[-1] == 4:
         moved = delta + inverse_sigmoid(reference_points)
@@ -79,6 +84,7 @@ def refined_boxes(delta, reference_points):
 
 class _TimeWeightedSum(torch.autograd.Function):
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, x, logits):
         lib = _lib.lib()
         x, logits = x.contiguous(), logits.contiguous()
@@ -93,12 +99,13 @@ class _TimeWeightedSum(torch.autograd.Function):
         return out
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     @torch.autograd.function.once_differentiable
     def backward(ctx, grad_out):
         lib = _lib.lib()
         x, weights = ctx.saved_tensors
         N, T, Q, C = x.shape
-        grad_out = grad_out.contiguous()
+        grad_out = grad_out.float().contiguous()
         grad_x = torch.empty_like(x)
         grad_logits = torch.empty(ctx.logits_shape, dtype=x.dtype, device=x.device)
         with torch.cuda.device(x.device):
@@ -110,9 +117,10 @@ class _TimeWeightedSum(torch.autograd.Function):
 
 def time_weighted_sum(x, logits):
     """`(x * softmax(logits, 1)).sum(1)`: x [N, T, Q, C], logits [N, T, Q, 1] (or [N, T, Q]) -> [N, Q, C]."""
-    if (ENABLE and x.is_cuda and x.dtype == torch.float32 and logits.dtype == torch.float32 and x.dim() == 4
+    if (ENABLE and x.is_cuda and x.dtype in _FLOATS and logits.dtype in _FLOATS and x.dim() == 4
+            and ((x.dtype == torch.float32 and logits.dtype == torch.float32) or torch.is_autocast_enabled())
             and 1 <= x.shape[1] <= 16 and x.shape[-1] % 4 == 0 and logits.numel() == x.numel() // x.shape[-1]
-            and tuple(logits.shape[:3]) == tuple(x.shape[:3]) and x.numel() > 0 and not torch.is_autocast_enabled()):
+            and tuple(logits.shape[:3]) == tuple(x.shape[:3]) and x.numel() > 0):
         return _TimeWeightedSum.apply(x, logits)
     if logits.dim() == 3:
         logits = logits.unsqueeze(-1)

@@ -22,8 +22,9 @@ hidden tensor instead of 5.25 + 6.25 (209 MB per encoder layer of a two-clip tra
 
 Same modules, same parameters, same state dict.  The dropout masks are this package's hash masks (fused_norm.py), not
 torch's Philox stream; in eval mode (p = 0) the block is bit-for-bit a GEMM / relu / GEMM / LayerNorm chain.  Everywhere
-the fused kernels do not apply (CPU, autocast, other activations or widths, capture without a step_scope) `ffn_block` IS the
-reference expression, evaluated by torch.
+the fused kernels do not apply (CPU, other dtypes, activations or widths, capture without a step_scope) `ffn_block` IS the
+reference expression, evaluated by torch.  Under torch.autocast(bfloat16) the two GEMMs run in bf16 and the in-place passes
+read and write their bf16 rows (round 6); the residual stream and the LayerNorm stay fp32, as in the eager chain.
 """
 from __future__ import annotations
 
@@ -43,6 +44,18 @@ ENABLE_FFN = os.environ.get("VNX_FUSED_FFN", "1") != "0"
 ENABLE_MASKED_LINEAR = os.environ.get("VNX_FUSED_MASKED_LINEAR", "1") != "0"
 
 
+def _code(dtype):
+    return _lib.VNX_BF16 if dtype == torch.bfloat16 else _lib.VNX_F32
+
+
+def _gemm_dtype_ok(x, *weights) -> bool:
+    """fp32 activations and weights: plain fp32 GEMMs, or -- under torch.autocast(bfloat16) -- bf16 GEMMs whose outputs the
+    in-place passes take as they are (ffn_act.hip / add_norm.hip read bf16 rows and compute in fp32)."""
+    if x.dtype != torch.float32 or any(w.dtype != torch.float32 for w in weights):
+        return False
+    return not torch.is_autocast_enabled() or torch.get_autocast_dtype("cuda") == torch.bfloat16
+
+
 class _BiasReluDropout(torch.autograd.Function):
     """a = dropout(relu(h + bias)) (relu=True) or h + bias (relu=False, p = 0), rows flagged in row_zero written as zeros,
     in place over h (h is the GEMM's fresh output: nobody else holds it); backward: grad_h (a new tensor: autograd's
@@ -55,13 +68,13 @@ class _BiasReluDropout(torch.autograd.Function):
         rows, cols = h.numel() // h.shape[-1], h.shape[-1]
         with torch.cuda.device(h.device):
             _lib.check(lib.vnx_bias_relu_dropout_forward(
-                _lib.VNX_F32, h.data_ptr(), bias.data_ptr() if bias is not None else None,
+                _code(h.dtype), h.data_ptr(), bias.data_ptr() if bias is not None else None,
                 row_zero.data_ptr() if row_zero is not None else None, rows, cols, int(bool(relu)), float(p), int(seed),
                 seed_tensor.data_ptr() if seed_tensor is not None else None, _lib.current_stream(h)))
         ctx.mark_dirty(h)
         ctx.save_for_backward(*((h,) if relu else ()), *((row_zero,) if row_zero is not None else ()))
         ctx.p, ctx.has_bias, ctx.relu, ctx.masked = float(p), bias is not None, bool(relu), row_zero is not None
-        ctx.cols = cols
+        ctx.cols, ctx.dtype = cols, h.dtype
         return h
 
     @staticmethod
@@ -72,6 +85,8 @@ class _BiasReluDropout(torch.autograd.Function):
         y = saved.pop(0) if ctx.relu else None
         row_zero = saved.pop(0) if ctx.masked else None
         grad = grad.contiguous()
+        if grad.dtype != ctx.dtype:
+            grad = grad.to(ctx.dtype)
         grad_h = torch.empty_like(grad)
         cols = ctx.cols
         rows = grad.numel() // cols
@@ -80,7 +95,7 @@ class _BiasReluDropout(torch.autograd.Function):
             if ctx.has_bias else None
         with torch.cuda.device(grad.device):
             _lib.check(lib.vnx_bias_relu_dropout_backward(
-                _lib.VNX_F32, grad.data_ptr(), y.data_ptr() if y is not None else None,
+                _code(ctx.dtype), grad.data_ptr(), y.data_ptr() if y is not None else None,
                 row_zero.data_ptr() if row_zero is not None else None, grad_h.data_ptr(),
                 grad_bias.data_ptr() if grad_bias is not None else None,
                 partial.data_ptr() if partial is not None else None, rows, cols, ctx.p, _lib.current_stream(grad)))
@@ -96,8 +111,8 @@ def linear_masked(x, linear, row_mask):
     def reference():
         out = linear(x)
         return out if row_mask is None else out.masked_fill(row_mask[..., None], float(0))
-    ok = (x.is_cuda and x.dtype == torch.float32 and linear.weight.dtype == torch.float32 and linear.bias is not None
-          and not torch.is_autocast_enabled() and linear.out_features % 4 == 0 and linear.out_features <= MAX_CHANNELS
+    ok = (x.is_cuda and _gemm_dtype_ok(x, linear.weight) and linear.bias is not None
+          and linear.out_features % 4 == 0 and linear.out_features <= MAX_CHANNELS
           and (row_mask is None or (row_mask.dtype == torch.bool and row_mask.shape == x.shape[:-1])))
     if not ok or row_mask is None or not ENABLE_MASKED_LINEAR:       # without a mask the GEMM's own bias epilogue is the cheaper form
         return reference()
@@ -107,11 +122,10 @@ def linear_masked(x, linear, row_mask):
 
 
 def fused_applies(x, linear1, linear2, norm, activation) -> bool:
-    return (activation is F.relu and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled()
+    return (activation is F.relu and x.is_cuda and _gemm_dtype_ok(x, linear1.weight, linear2.weight)
             and x.shape[-1] == fused_norm.CHANNELS and linear1.in_features == fused_norm.CHANNELS
             and linear2.out_features == fused_norm.CHANNELS and linear1.out_features == linear2.in_features
             and linear1.out_features % 4 == 0 and linear1.out_features <= MAX_CHANNELS
-            and linear1.weight.dtype == torch.float32 and linear2.weight.dtype == torch.float32
             and linear1.bias is not None and linear2.bias is not None
             and fused_norm.fused_applies(x, x, norm))
 

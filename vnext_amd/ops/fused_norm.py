@@ -103,10 +103,11 @@ class _AddDropoutLayerNorm(torch.autograd.Function):
         x, r = x.contiguous(), r.contiguous()
         rows = x.numel() // CHANNELS
         y, z = torch.empty_like(x), torch.empty_like(x)
+        ctx.branch_dtype = r.dtype          # fp32, or bf16 under autocast (the Linear / attention output): the kernel reads it as it is
         stats = torch.empty(rows, 2, dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
             _lib.check(lib.vnx_add_dropout_layernorm_forward(
-                _lib.VNX_F32, x.data_ptr(), r.data_ptr(), r_bias.data_ptr() if r_bias is not None else None,
+                _branch_code(r.dtype), x.data_ptr(), r.data_ptr(), r_bias.data_ptr() if r_bias is not None else None,
                 gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), z.data_ptr(),
                 stats.data_ptr(), rows, CHANNELS, float(p), float(eps), int(seed),
                 seed_tensor.data_ptr() if seed_tensor is not None else None, _lib.current_stream(x)))
@@ -120,14 +121,16 @@ class _AddDropoutLayerNorm(torch.autograd.Function):
         lib = _lib.lib()
         z, stats, gamma = ctx.saved_tensors
         grad_y = grad_y.contiguous()
+        if grad_y.dtype != torch.float32:
+            grad_y = grad_y.float()
         rows = z.numel() // CHANNELS
-        grad_x, grad_r = torch.empty_like(z), torch.empty_like(z)
+        grad_x, grad_r = torch.empty_like(z), torch.empty_like(z, dtype=ctx.branch_dtype)
         grad_gamma, grad_beta = torch.empty_like(gamma), torch.empty_like(gamma)
         grad_bias = torch.empty_like(gamma) if ctx.has_bias else None      # the folded Linear bias: column sums of grad_r
         partial = torch.empty(lib.vnx_add_dropout_layernorm_partial_bytes(), dtype=torch.uint8, device=z.device)
         with torch.cuda.device(z.device):
             _lib.check(lib.vnx_add_dropout_layernorm_backward(
-                _lib.VNX_F32, grad_y.data_ptr(), z.data_ptr(), stats.data_ptr(), gamma.data_ptr(), grad_x.data_ptr(),
+                _branch_code(ctx.branch_dtype), grad_y.data_ptr(), z.data_ptr(), stats.data_ptr(), gamma.data_ptr(), grad_x.data_ptr(),
                 grad_r.data_ptr(), grad_gamma.data_ptr(), grad_beta.data_ptr(),
                 grad_bias.data_ptr() if grad_bias is not None else None, partial.data_ptr(), rows, CHANNELS,
                 ctx.p, ctx.seed, ctx.seed_tensor.data_ptr() if ctx.seed_tensor is not None else None,
@@ -135,11 +138,16 @@ class _AddDropoutLayerNorm(torch.autograd.Function):
         return grad_x, grad_r, grad_gamma, grad_beta, None, None, None, None, grad_bias
 
 
+def _branch_code(dtype):
+    return _lib.VNX_BF16 if dtype == torch.bfloat16 else _lib.VNX_F32
+
+
 def fused_applies(x, r, norm) -> bool:
-    return (x.is_cuda and x.dtype == torch.float32 and r.dtype == torch.float32 and x.shape == r.shape
+    """fp32 residual stream and LayerNorm; the branch fp32 or -- what a Linear emits under torch.autocast(bfloat16) -- bf16.
+    The result is fp32 either way, as the eager chain's (the sum promotes, autocast runs layer_norm in fp32)."""
+    return (x.is_cuda and x.dtype == torch.float32 and r.dtype in (torch.float32, torch.bfloat16) and x.shape == r.shape
             and x.shape[-1] == CHANNELS and tuple(norm.normalized_shape) == (CHANNELS,)
-            and norm.weight is not None and norm.bias is not None and norm.weight.dtype == torch.float32
-            and not torch.is_autocast_enabled())
+            and norm.weight is not None and norm.bias is not None and norm.weight.dtype == torch.float32)
 
 
 def dropout_site(x, dropout):

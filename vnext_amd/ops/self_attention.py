@@ -48,7 +48,11 @@ class _QuerySelfAttention(torch.autograd.Function):
     """x [B, Q, C] (contiguous), pos [B // t, Q, C] or None, in_proj weight [3C, C] / bias [3C] -> the attention context
     [B, Q, C] (before the output projection).  t: frames that share one pos row block (box queries: B = N * t)."""
 
+    # Under torch.autocast the block runs in fp32 (custom_fwd casts what arrives and switches autocast off inside): x is the
+    # fp32 residual stream anyway, the 300-query GEMMs are small, and one launch each way replaces the 18 + 27 of the eager
+    # nn.MultiheadAttention -- which is what the block fell to under autocast until round 6.
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, x, pos, w_in, b_in, heads, p, seed, seed_tensor, t):
         lib = _lib.lib()
         B, Q, C = x.shape
@@ -74,10 +78,13 @@ class _QuerySelfAttention(torch.autograd.Function):
         return out
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     @torch.autograd.function.once_differentiable
     def backward(ctx, grad_out):
         lib = _lib.lib()
         x, xp2, w_in, b_in, qkv, out, lse = ctx.saved_tensors
+        if grad_out.dtype != torch.float32:
+            grad_out = grad_out.float()
         B, Q, C = x.shape
         x2 = x.view(B * Q, C)
         if xp2 is None:
@@ -103,7 +110,7 @@ class _QuerySelfAttention(torch.autograd.Function):
 
 def fused_applies(x, pos, mha) -> bool:
     C = x.shape[-1]
-    return (ENABLE and x.is_cuda and x.dim() == 3 and x.dtype == torch.float32 and not torch.is_autocast_enabled()
+    return (ENABLE and x.is_cuda and x.dim() == 3 and x.dtype == torch.float32
             and isinstance(mha, torch.nn.MultiheadAttention) and mha._qkv_same_embed_dim and mha.embed_dim == C
             and mha.head_dim == HEAD_DIM and mha.in_proj_weight.dtype == torch.float32 and mha.bias_k is None
             and mha.bias_v is None and not mha.add_zero_attn and not mha.batch_first
