@@ -41,6 +41,8 @@ def main():
     sys.modules[spec.name] = mod
     spec.loader.exec_module(mod)
 
+    torch.manual_seed(37)      # the constructors below draw their initial weights from the GLOBAL generator: seeded, so that this
+    # script regenerates its fixture bit for bit (round-5 review; as make_golden_modules.py)
     gen = torch.Generator().manual_seed(37)
     C, M, L, P, N, Q = 32, 2, 4, 4, 2, 9        # L == P: the reference's sample keeper divides the POINT axis by
     # the per-level valid ratios (deformable_transformer.py:356) and only broadcasts when they are equal; M*L*P >= 30

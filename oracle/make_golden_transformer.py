@@ -44,6 +44,8 @@ def main():
     sys.modules[spec.name] = mod
     spec.loader.exec_module(mod)
 
+    torch.manual_seed(31)      # the constructors below draw their initial weights from the GLOBAL generator: seeded, so that this
+    # script regenerates its fixture bit for bit (round-5 review; as make_golden_modules.py)
     gen = torch.Generator().manual_seed(31)
     C, M, L, P, T, N, Q = 32, 1, 3, 4, 2, 2, 6
     tr = mod.DeformableTransformer(d_model=C, nhead=M, num_encoder_layers=1, num_decoder_layers=2,
