@@ -16,7 +16,7 @@ DEV_LIB_PATH = os.path.join(_HERE, "lib", "libvnext_hip_dev.so")
 
 VNX_F32, VNX_F64, VNX_BF16, VNX_F16 = 0, 1, 2, 3
 VNX_OK = 0
-ABI_VERSION = 13
+ABI_VERSION = 14
 MSDA_LEVELS_PACKED = 1
 MSDA_FORK = 2              # vnx_msda_backward: grad_value kernel on the library's side stream (include/vnext_hip.h)
 

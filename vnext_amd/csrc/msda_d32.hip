@@ -191,17 +191,18 @@ __device__ __forceinline__ void load_sample_f32(const int64_t* __restrict__ shap
   float2_t xy;
   if constexpr (NT)
     asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx2 %1, %5, off\n\t"
-                 "global_load_dwordx2 %2, %6, off nt\n\tglobal_load_dword %3, %7, off nt"
+                 "global_load_dwordx2 %2, %6, off nt\n\tglobal_load_dword %3, %7, off nt\n\ts_waitcnt vmcnt(0)"
                  : "=&v"(hw), "=&v"(st), "=&v"(xy), "=&v"(a)
                  : "v"(shapes + 2 * l), "v"(lsi + l), "v"(loc + 2 * wi), "v"(attn + wi)
                  : "memory");
   else
     asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx2 %1, %5, off\n\t"
-                 "global_load_dwordx2 %2, %6, off\n\tglobal_load_dword %3, %7, off"
+                 "global_load_dwordx2 %2, %6, off\n\tglobal_load_dword %3, %7, off\n\ts_waitcnt vmcnt(0)"
                  : "=&v"(hw), "=&v"(st), "=&v"(xy), "=&v"(a)
                  : "v"(shapes + 2 * l), "v"(lsi + l), "v"(loc + 2 * wi), "v"(attn + wi)
                  : "memory");
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(hw), "+v"(st), "+v"(xy), "+v"(a) : : "memory");
+  // (the wait is part of the SAME statement: between two statements the compiler would take the destination registers for
+  //  valid and might copy or spill them before the data has landed -- ADVICE r5; nothing was overlapped between them anyway)
   H = hw.x; W = hw.z; start = st.x;      // int64 entries, narrowed as the reference does (cuh:276-277)
   x = xy.x; y = xy.y;
 }

@@ -80,23 +80,35 @@ bool msda_d32_gvdirect_supported(int vdt, int ldt, const MsdaDims& d) {
 template <typename TV, typename TL>
 static int launch_gvdirect(const int64_t* shapes, const int64_t* lsi, const void* loc, const void* attn, const void* grad_out,
                            void* grad_value, const MsdaDims& d, int compact, hipStream_t stream) {
+#ifdef VNX_GVD_ROWS_ALONE      // A/B: rows per unit of the stand-alone launch
+  const int rows = VNX_GVD_ROWS_ALONE;
+#else
   const int rows = gvd_rows_max(d.S);
+#endif
+#ifdef VNX_GVD_UT_ALONE
+  const int ut = VNX_GVD_UT_ALONE;
+#else
   const int ut = gvd_units_min(d.S, d.L, d.B * d.M, rows);
+#endif
   const int64_t blocks = ((int64_t(d.B) * msda_gvdirect_units_bound(d, ut, rows) + 1) & ~int64_t(1)) * d.M;   // (unit, batch) pairs: even (gv_decode_block)
   // more than 64 KiB of LDS per workgroup: the limit is raised once per kernel (and device: the attribute is per function)
+#ifndef VNX_GVD_LDS_ALONE      // A/B: LDS bytes the stand-alone launch asks for (more than the kernel needs = fewer units per CU)
+#define VNX_GVD_LDS_ALONE rec::kGvdLdsBytes
+#endif
+  const size_t lds = VNX_GVD_LDS_ALONE;
 #define VNX_LAUNCH(PT)                                                                                                    \
   do {                                                                                                                    \
     static thread_local int raised_on = -1;                                                                               \
     int dev = 0;                                                                                                          \
     (void)hipGetDevice(&dev);                                                                                             \
-    if (rec::kGvdLdsBytes > 64 * 1024 && raised_on != dev) {                                                               \
+    if (lds > 64 * 1024 && raised_on != dev) {                                                                            \
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rec::msda_bwd_gv_direct_kernel<TV, TL, PT>),                  \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, int(rec::kGvdLdsBytes)) != hipSuccess)           \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)) != hipSuccess)                         \
         return check_launch("msda_bwd_gv_direct (LDS limit)");                                                             \
       raised_on = dev;                                                                                                    \
     }                                                                                                                     \
     hipLaunchKernelGGL((rec::msda_bwd_gv_direct_kernel<TV, TL, PT>), dim3(uint32_t(blocks)), dim3(rec::kThreads),        \
-                       rec::kGvdLdsBytes, stream, shapes, lsi, (const TL*)loc, (const TL*)attn, (const TV*)grad_out,     \
+                       lds, stream, shapes, lsi, (const TL*)loc, (const TL*)attn, (const TV*)grad_out,     \
                        (TV*)grad_value, d, ut, rows, compact, take_stamp_region(kStampGradValue, blocks));                     \
   } while (0)
   if (d.P == 4) VNX_LAUNCH(4); else VNX_LAUNCH(0);

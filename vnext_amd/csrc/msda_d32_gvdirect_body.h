@@ -122,6 +122,9 @@ __device__ __forceinline__ void msda_bwd_gv_direct_body(const int64_t* __restric
   int lvl = -1, r0 = 0, r1 = 0, Hl = 0, Wl = 0, start = 0, gshift = 0;
   bool packed = true;
   if (tid < d.L) {      // level table: lane l works out level l's unit split once
+    // (Round 6, timing ablation: the table from compile-time constants instead of from memory -- what a host-side copy of the
+    //  level sizes in the kernel arguments would save: 19.6-20.2 against 19.8 us at the T = 5 call, 33.2 against 33.2 at B = 10:
+    //  nothing.  The kernel is bound by issue -- 65 % of the vector issue slots, profiles/r06_backward_pmc.csv -- not by this trip.)
     const int H = int(shapes[2 * tid]), W = int(shapes[2 * tid + 1]), first = int(lsi[tid]);     // (one round trip: both requested
     const GvdSplit sp = gvd_level_split(H * W, ut, d.Lq, P, rows_max);                                     //  before the divisions below)
     meta[4 * tid] = H; meta[4 * tid + 1] = W; meta[4 * tid + 2] = first;

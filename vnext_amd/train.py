@@ -215,8 +215,9 @@ def enable_channels_last() -> dict:
     convolutions are NHWC kernels either way; given NCHW tensors it transposes around each: SeqFormer step 66.2 -> 64.3 ms).
     Two process-wide settings, which is why this is an explicit call and not an import side effect:
       * PYTORCH_MIOPEN_SUGGEST_NHWC=1 -- PyTorch hands MIOpen an NHWC problem only with it, and reads it ONCE: call this
-        before the process runs its first convolution (a later call converts inputs for nothing and is refused here when
-        the caller says a convolution already ran);
+        before the process runs its first convolution (a later call still flips the trunk's switch, but PyTorch has read
+        the variable by then and the inputs are converted for nothing -- this function cannot see that; it is the caller's
+        ordering to keep);
       * the trunk's switch `models.seqformer.CHANNELS_LAST`.
     VNX_CHANNELS_LAST=0 or an explicit PYTORCH_MIOPEN_SUGGEST_NHWC=0 opt out.  -> {"enabled", "why"} for the bench line."""
     from .models import seqformer
