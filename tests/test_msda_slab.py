@@ -92,3 +92,43 @@ def test_the_two_kernels_agree_closely_at_the_encoder_shape():
     a = fwd(case[2], case[0], case[1], case[3], case[4], 730)
     b = fwd(case[2], case[0], case[1], case[3], case[4], 731)
     np.testing.assert_allclose(a, b, rtol=0, atol=2e-6 * float(np.abs(b).max()))
+
+
+# ---- 16-bit values (round 6): 64-byte rows, the same staging rule with twice the rows ----------------------------------------
+@pytest.mark.parametrize("vdt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shapes,B", [(S360, 2), (S720, 1),
+                                      ([(30, 40), (20, 16), (16, 20), (1, 1)], 2),      # 641 rows behind level 0: exactly the 16-bit cap
+                                      ([(30, 40), (20, 16), (16, 20), (2, 1)], 2)])     # 642: only the last two levels
+def test_sixteen_bit_values_through_the_slab_kernel(vdt, shapes, B):
+    """the oracle on the SAME 16-bit-rounded values (fp64 arithmetic) at the 16-bit tolerance; against the gather kernel (731),
+    which reads the same values and sums in fp32, far tighter: both round their fp32 sums once on the way out"""
+    case = encoder_case(shapes, B, seed=13)
+    sh, lsi, value, loc, attn = case
+    v16 = value.to(vdt)
+    want = oracle(v16.float(), sh, lsi, loc, attn)
+    tol = 8e-3 if vdt == torch.bfloat16 else 1e-3
+    got = fwd(v16, sh, lsi, loc, attn, 730)
+    close(got, want, tol)
+    close(fwd(v16, sh, lsi, loc, attn, 0), want, tol)      # automatic: the gather kernel for unfused 16-bit calls (msda_forward_d32)
+    gather = fwd(v16, sh, lsi, loc, attn, 731)
+    # one unit in the last place of the output type at most (different summation orders before the single rounding)
+    ulp = 2.0 ** -8 if vdt == torch.bfloat16 else 2.0 ** -11
+    assert float(np.abs(got - gather).max()) <= 2 * ulp * float(np.abs(gather).max())
+
+
+def test_fused_prologue_with_bf16_values_takes_the_slab_kernel_and_matches_the_gather_form():
+    from vnext_amd.ops.functions import MSDeformAttnFusedFunction, level_tensors
+    shapes = [tuple(x) for x in S360]
+    S = sum(h * w for h, w in shapes)
+    g = torch.Generator(device=DEV).manual_seed(4)
+    value = torch.randn(2, S, 8, 32, device=DEV, generator=g).bfloat16()
+    offsets = 2.0 * torch.randn(2, S, 8, 4, 4, 2, device=DEV, generator=g)
+    logits = torch.randn(2, S, 8, 16, device=DEV, generator=g)
+    ref = torch.rand(2, S, 4, 2, device=DEV, generator=g)
+    shapes_t, lsi = level_tensors(shapes, DEV)
+    outs = {}
+    for variant in (0, 731):
+        _lib.set_kernel_variant(variant)
+        outs[variant] = MSDeformAttnFusedFunction.apply(value, shapes_t, lsi, offsets, logits, ref).float()
+        torch.cuda.synchronize()
+    assert float((outs[0] - outs[731]).abs().max()) <= 2 * 2.0 ** -8 * float(outs[731].abs().max())

@@ -355,7 +355,8 @@ int main(int argc, char** argv) {
   CK(hipStreamCreate(&st));
   auto fwd = [&](Set& s) {
     if (op == "ffwd" && vnx_get_kernel_variant() != 1) {
-      VK(vnx_msda_fused_forward(VNX_F32, VNX_F32, s.value, dshapes, dlsi, s.off, s.logit, refpts, s.out, B, S, M, D, L, Lq, P, 2, 1, st));
+      if (b16) VK(vnx_msda_fused_forward(VNX_BF16, VNX_F32, s.value16, dshapes, dlsi, s.off, s.logit, refpts, s.out16, B, S, M, D, L, Lq, P, 2, 1, st));
+      else VK(vnx_msda_fused_forward(VNX_F32, VNX_F32, s.value, dshapes, dlsi, s.off, s.logit, refpts, s.out, B, S, M, D, L, Lq, P, 2, 1, st));
       return;
     }
     if (b16) { VK(vnx_msda_forward(VNX_BF16, VNX_F32, s.value16, dshapes, dlsi, s.loc, s.attn, s.out16, B, S, M, D, L, Lq, P, st)); return; }

@@ -612,17 +612,34 @@ constexpr int kSlabEnt = kSlabQpw * 17;                                         
 constexpr size_t kSlabRecBytes = size_t(kSlabWaves) * 2 * kSlabEnt * 16;            // offsets (uint4) + weights (float4)
 constexpr size_t kSlabLdsBytes = size_t(kSlabRowsCap + 1) * 128 + kSlabRecBytes + 64;
 
-template <typename TL, bool FUSED>
+// a staged row's four channels of this lane, as fp32 (fp32 rows: 16 bytes; 16-bit rows: 8)
+template <typename TV> __device__ __forceinline__ float4_t slab_tap(const unsigned char* p);
+template <> __device__ __forceinline__ float4_t slab_tap<float>(const unsigned char* p) { return *reinterpret_cast<const float4_t*>(p); }
+template <> __device__ __forceinline__ float4_t slab_tap<bf16_t>(const unsigned char* p) {
+  const uint2_t r = *reinterpret_cast<const uint2_t*>(p);
+  return float4_t{__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u)};
+}
+template <> __device__ __forceinline__ float4_t slab_tap<f16_t>(const unsigned char* p) {
+  const uint2_t r = *reinterpret_cast<const uint2_t*>(p);
+  return float4_t{half_bits_to_float(r.x & 0xffffu), half_bits_to_float(r.x >> 16), half_bits_to_float(r.y & 0xffffu), half_bits_to_float(r.y >> 16)};
+}
+
+// Round 6: TV = the value's (and the output's) element type.  16-bit rows are 64 bytes, so the slab region of the fp32 layout
+// (41 KB) holds 641 of them -- the same two coarsest levels at 360p (300 rows, 19 KB) and level 3 at 720p -- a staged tap is a
+// `ds_read_b64`, a gathered one the 8-byte load of the gather kernel's 8-lane map.  Until round 6 calls with 16-bit values (every
+// encoder layer of a model under bf16 autocast) kept the gather kernel.
+template <typename TV, typename TL, bool FUSED>
 __global__ void __launch_bounds__(64 * kSlabWaves, 2 * kSlabWaves / 4)      // two workgroups per CU: 4 waves per SIMD, <= 128 VGPRs
-msda_fwd_slab_kernel(const float* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
-                     const TL* __restrict__ loc, const TL* __restrict__ attn, float* __restrict__ out, MsdaDims d,
+msda_fwd_slab_kernel(const TV* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
+                     const TL* __restrict__ loc, const TL* __restrict__ attn, TV* __restrict__ out, MsdaDims d,
                      int parts, unsigned long long* stamps, FusedArgs fa) {
   stamp_begin(stamps);
-  constexpr int D = 32, LP = 16, kRowBytes = 128;
+  constexpr int D = 32, LP = 16, kRowBytes = D * int(sizeof(TV)), kPieces = kRowBytes / 16, kLaneBytes = kRowBytes / 8;
+  constexpr int kRowsCap = (kSlabRowsCap + 1) * 128 / kRowBytes - 1;      // rows the slab region holds (+ the zero row)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* slab = smem;                                                        // [rows + 1][128 B]
-  uint4_t* rec_base = reinterpret_cast<uint4_t*>(smem + size_t(kSlabRowsCap + 1) * kRowBytes);
-  int* s_lvl = reinterpret_cast<int*>(smem + size_t(kSlabRowsCap + 1) * kRowBytes + kSlabRecBytes);      // [4][4]: H, W, start, -
+  unsigned char* slab = smem;                                                        // [rows + 1][row bytes]
+  uint4_t* rec_base = reinterpret_cast<uint4_t*>(smem + size_t(kSlabRowsCap + 1) * 128);
+  int* s_lvl = reinterpret_cast<int*>(smem + size_t(kSlabRowsCap + 1) * 128 + kSlabRecBytes);      // [4][4]: H, W, start, -
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #ifndef VNX_SLAB_BATCH_MAJOR
@@ -650,18 +667,18 @@ msda_fwd_slab_kernel(const float* __restrict__ value, const int64_t* __restrict_
     if (packed) {
 #pragma unroll
       for (int l = 3; l >= 0; --l)
-        if (d.S - s_lvl[4 * l + 2] <= kSlabRowsCap) { first_staged = l; slab_first = s_lvl[4 * l + 2]; }
+        if (d.S - s_lvl[4 * l + 2] <= kRowsCap) { first_staged = l; slab_first = s_lvl[4 * l + 2]; }
     }
   }
   first_staged = __builtin_amdgcn_readfirstlane(first_staged);
   slab_first = __builtin_amdgcn_readfirstlane(slab_first);
   const int n_slab = d.S - slab_first;
   {
-    const float* src = value + ((int64_t(b) * d.S + slab_first) * d.M + m) * D;
-    for (int i = tid; i < n_slab * 8; i += 64 * kSlabWaves)
-      *reinterpret_cast<float4_t*>(slab + (i >> 3) * kRowBytes + (i & 7) * 16) =
-          *reinterpret_cast<const float4_t*>(src + int64_t(i >> 3) * d.M * D + (i & 7) * 4);
-    if (tid < 8) *reinterpret_cast<float4_t*>(slab + n_slab * kRowBytes + tid * 16) = float4_t{0.f, 0.f, 0.f, 0.f};
+    const TV* src = value + ((int64_t(b) * d.S + slab_first) * d.M + m) * D;
+    for (int i = tid; i < n_slab * kPieces; i += 64 * kSlabWaves)      // 16-byte pieces
+      *reinterpret_cast<uint4_t*>(slab + (i / kPieces) * kRowBytes + (i % kPieces) * 16) =
+          *reinterpret_cast<const uint4_t*>(src + int64_t(i / kPieces) * d.M * D + (i % kPieces) * (16 / int(sizeof(TV))));
+    if (tid < kPieces) *reinterpret_cast<uint4_t*>(slab + n_slab * kRowBytes + tid * 16) = uint4_t{0u, 0u, 0u, 0u};
   }
   __syncthreads();
   const uint32_t zero_row = uint32_t(n_slab) * kRowBytes;
@@ -669,10 +686,10 @@ msda_fwd_slab_kernel(const float* __restrict__ value, const int64_t* __restrict_
   uint4_t* s_off = rec_base + size_t(wave) * 2 * kSlabEnt;
   float4_t* s_wt = reinterpret_cast<float4_t*>(s_off + kSlabEnt);
   const int pixel_bytes = d.M * kRowBytes;
-  const float* head_base = value + (int64_t(b) * d.S * d.M + m) * D;
+  const TV* head_base = value + (int64_t(b) * d.S * d.M + m) * D;
   const __amdgpu_buffer_rsrc_t rsrc = uniform_rsrc(head_base, uint32_t((int64_t(d.S) * d.M - m) * kRowBytes));
   const int ch = lane & 7, qi2 = lane >> 3;
-  const uint32_t lane_off = uint32_t(ch * 16);
+  const uint32_t lane_off = uint32_t(ch * kLaneBytes);
 
   const int n_tiles = (d.Lq + kSlabWaves * kSlabQpw - 1) / (kSlabWaves * kSlabQpw);
   // The locations and weights of a tile's two decode passes are REQUESTED one tile ahead (plain calls, fp32: six registers) --
@@ -760,6 +777,60 @@ msda_fwd_slab_kernel(const float* __restrict__ value, const int64_t* __restrict_
     //  lanes masked.)
     const uint4_t* g_off = s_off + qi2 * 17;
     const float4_t* g_wt = s_wt + qi2 * 17;
+    if constexpr (sizeof(TV) == 2) {
+      // 16-bit rows: a row is 4 lanes x 16 bytes (8 channels per lane), so the 8-lane set of a query is two 4-lane halves that
+      // take points {0, 1} and {2, 3} of every level: 8 loads of 16 bytes per lane and level instead of 16 of 8 bytes -- the
+      // gather kernel's map for 16-bit rows (sixteen rows per wave instruction).  With 8 lanes x 8 bytes this kernel LOST to the
+      // gather kernel on 16-bit values (encoder-360p bf16, cold: 43.9 against 39.5 us unfused, 56.0 against 50.5 fused).
+      const int sub = (lane >> 2) & 1, c4 = lane & 3;
+      const uint32_t off16 = uint32_t(c4 * 16);
+      float4_t acc_lo = {0.f, 0.f, 0.f, 0.f}, acc_hi = acc_lo;
+#pragma unroll 1
+      for (int l = 0; l < 4; ++l) {
+        uint4_t o[2];
+        float4_t w[2];
+        uint4_t raw[2][4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { o[j] = g_off[4 * l + 2 * sub + j]; w[j] = g_wt[4 * l + 2 * sub + j]; }
+        if (l < first_staged) {      // uniform
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            raw[j][0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, int(o[j].x + off16), 0, 0);
+            raw[j][1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, int(o[j].y + off16), 0, 0);
+            raw[j][2] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, int(o[j].z + off16), 0, 0);
+            raw[j][3] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, int(o[j].w + off16), 0, 0);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            raw[j][0] = *reinterpret_cast<const uint4_t*>(slab + o[j].x + off16);
+            raw[j][1] = *reinterpret_cast<const uint4_t*>(slab + o[j].y + off16);
+            raw[j][2] = *reinterpret_cast<const uint4_t*>(slab + o[j].z + off16);
+            raw[j][3] = *reinterpret_cast<const uint4_t*>(slab + o[j].w + off16);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const float wt[4] = {w[j].x, w[j].y, w[j].z, w[j].w};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            float4_t lo, hi;
+            unpack8<TV>(raw[j][k], lo, hi);
+            acc_lo += wt[k] * lo;
+            acc_hi += wt[k] * hi;
+          }
+        }
+      }
+      // the two halves of the set meet (lane ^ 4)
+      acc_lo.x += __shfl_xor(acc_lo.x, 4, 64); acc_lo.y += __shfl_xor(acc_lo.y, 4, 64);
+      acc_lo.z += __shfl_xor(acc_lo.z, 4, 64); acc_lo.w += __shfl_xor(acc_lo.w, 4, 64);
+      acc_hi.x += __shfl_xor(acc_hi.x, 4, 64); acc_hi.y += __shfl_xor(acc_hi.y, 4, 64);
+      acc_hi.z += __shfl_xor(acc_hi.z, 4, 64); acc_hi.w += __shfl_xor(acc_hi.w, 4, 64);
+      const int q = q0 + qi2;
+      if (q < d.Lq && sub == 0)
+        *reinterpret_cast<uint4_t*>(out + ((int64_t(b) * d.Lq + q) * d.M + m) * D + c4 * 8) = pack8<TV>(acc_lo, acc_hi);
+    } else {
     float4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
     for (int l = 0; l < 4; ++l) {      // (not unrolled: one level's sixteen rows in registers at a time)
@@ -771,18 +842,18 @@ msda_fwd_slab_kernel(const float* __restrict__ value, const int64_t* __restrict_
       if (l < first_staged) {      // uniform
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          v[j][0] = load_tap<float>(rsrc, o[j].x + lane_off);
-          v[j][1] = load_tap<float>(rsrc, o[j].y + lane_off);
-          v[j][2] = load_tap<float>(rsrc, o[j].z + lane_off);
-          v[j][3] = load_tap<float>(rsrc, o[j].w + lane_off);
+          v[j][0] = load_tap<TV>(rsrc, o[j].x + lane_off);
+          v[j][1] = load_tap<TV>(rsrc, o[j].y + lane_off);
+          v[j][2] = load_tap<TV>(rsrc, o[j].z + lane_off);
+          v[j][3] = load_tap<TV>(rsrc, o[j].w + lane_off);
         }
       } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          v[j][0] = *reinterpret_cast<const float4_t*>(slab + o[j].x + lane_off);
-          v[j][1] = *reinterpret_cast<const float4_t*>(slab + o[j].y + lane_off);
-          v[j][2] = *reinterpret_cast<const float4_t*>(slab + o[j].z + lane_off);
-          v[j][3] = *reinterpret_cast<const float4_t*>(slab + o[j].w + lane_off);
+          v[j][0] = slab_tap<TV>(slab + o[j].x + lane_off);
+          v[j][1] = slab_tap<TV>(slab + o[j].y + lane_off);
+          v[j][2] = slab_tap<TV>(slab + o[j].z + lane_off);
+          v[j][3] = slab_tap<TV>(slab + o[j].w + lane_off);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -795,7 +866,8 @@ msda_fwd_slab_kernel(const float* __restrict__ value, const int64_t* __restrict_
       }
     }
     const int q = q0 + qi2;
-    if (q < d.Lq) store_row4<float>(out + ((int64_t(b) * d.Lq + q) * d.M + m) * D + ch * 4, acc);
+    if (q < d.Lq) store_row4<TV>(out + ((int64_t(b) * d.Lq + q) * d.M + m) * D + ch * 4, acc);
+    }
     __builtin_amdgcn_wave_barrier();      // this tile's records have been read: the next decode may overwrite them
   }
   stamp_end(stamps);
@@ -804,7 +876,8 @@ msda_fwd_slab_kernel(const float* __restrict__ value, const int64_t* __restrict_
 // the slab kernel takes a call when it is built for it (fp32 values, 4 levels x 4 points) and the call has enough queries per
 // (batch, head) for a workgroup's slab copy to pay (an encoder's; development build: variant 730 forces, 731 forbids)
 static bool use_slab_forward(int vdt, int ldt, const MsdaDims& d, int variant) {
-  if (vdt != VNX_F32 || ldt != VNX_F32 || d.L != 4 || d.P != 4 || d.D != 32) return false;
+  if (ldt != VNX_F32 || d.L != 4 || d.P != 4 || d.D != 32) return false;
+  if (vdt != VNX_F32 && vdt != VNX_BF16 && vdt != VNX_F16) return false;      // (16-bit values: round 6)
   if (int64_t(d.S) * d.M * 128 >= (int64_t(1) << 31) || d.S >= (1 << 23)) return false;
   if (variant == 731) return false;
   return variant == 730 || d.Lq >= 2048;
@@ -826,7 +899,7 @@ static int slab_parts(const MsdaDims& d, int n_tiles) {
   return parts > n_tiles ? n_tiles : parts;
 }
 
-template <typename TL>
+template <typename TV, typename TL>
 static int launch_fwd_slab(const void* value, const int64_t* shapes, const int64_t* lsi, const void* loc, const void* attn,
                            void* out, const MsdaDims& d, const FusedArgs* fa, hipStream_t stream) {
   const int n_tiles = (d.Lq + kSlabWaves * kSlabQpw - 1) / (kSlabWaves * kSlabQpw);
@@ -837,19 +910,19 @@ static int launch_fwd_slab(const void* value, const int64_t* shapes, const int64
   (void)hipGetDevice(&dev);
   const int which = fa != nullptr;
   if (raised_on[which] != dev) {
-    const void* fn = fa ? reinterpret_cast<const void*>(&msda_fwd_slab_kernel<TL, true>)
-                        : reinterpret_cast<const void*>(&msda_fwd_slab_kernel<TL, false>);
+    const void* fn = fa ? reinterpret_cast<const void*>(&msda_fwd_slab_kernel<TV, TL, true>)
+                        : reinterpret_cast<const void*>(&msda_fwd_slab_kernel<TV, TL, false>);
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(kSlabLdsBytes)) != hipSuccess)
       return check_launch("msda_fwd_slab (LDS limit)");
     raised_on[which] = dev;
   }
   if (fa)
-    hipLaunchKernelGGL((msda_fwd_slab_kernel<TL, true>), dim3(uint32_t(blocks)), dim3(64 * kSlabWaves), kSlabLdsBytes, stream,
-                       (const float*)value, shapes, lsi, (const TL*)loc, (const TL*)attn, (float*)out, d, parts,
+    hipLaunchKernelGGL((msda_fwd_slab_kernel<TV, TL, true>), dim3(uint32_t(blocks)), dim3(64 * kSlabWaves), kSlabLdsBytes, stream,
+                       (const TV*)value, shapes, lsi, (const TL*)loc, (const TL*)attn, (TV*)out, d, parts,
                        take_stamp_region(kStampFwd, blocks), *fa);
   else
-    hipLaunchKernelGGL((msda_fwd_slab_kernel<TL, false>), dim3(uint32_t(blocks)), dim3(64 * kSlabWaves), kSlabLdsBytes, stream,
-                       (const float*)value, shapes, lsi, (const TL*)loc, (const TL*)attn, (float*)out, d, parts,
+    hipLaunchKernelGGL((msda_fwd_slab_kernel<TV, TL, false>), dim3(uint32_t(blocks)), dim3(64 * kSlabWaves), kSlabLdsBytes, stream,
+                       (const TV*)value, shapes, lsi, (const TL*)loc, (const TL*)attn, (TV*)out, d, parts,
                        take_stamp_region(kStampFwd, blocks), FusedArgs{});
   return check_launch("msda_fwd_slab");
 }
@@ -963,8 +1036,11 @@ bool msda_d32_fwd_supported(int vdt, int ldt, const MsdaDims& d) {
 int msda_forward_d32(int vdt, int ldt, const void* value, const int64_t* shapes,
                      const int64_t* lsi, const void* loc, const void* attn, void* out, MsdaDims d,
                      int variant, hipStream_t stream) {
-  if (use_slab_forward(vdt, ldt, d, variant))
-    return launch_fwd_slab<float>(value, shapes, lsi, loc, attn, out, d, nullptr, stream);
+  if (use_slab_forward(vdt, ldt, d, variant)) {
+    if (vdt == VNX_F32) return launch_fwd_slab<float, float>(value, shapes, lsi, loc, attn, out, d, nullptr, stream);
+    if (vdt == VNX_BF16) return launch_fwd_slab<bf16_t, float>(value, shapes, lsi, loc, attn, out, d, nullptr, stream);
+    return launch_fwd_slab<f16_t, float>(value, shapes, lsi, loc, attn, out, d, nullptr, stream);
+  }
   if (vdt == VNX_F32) return launch_fwd<float, float>(value, shapes, lsi, loc, attn, out, d, variant, stream);
   if (vdt == VNX_BF16 && ldt == VNX_F32) return launch_fwd<bf16_t, float>(value, shapes, lsi, loc, attn, out, d, variant, stream);
   if (vdt == VNX_BF16 && ldt == VNX_BF16) return launch_fwd<bf16_t, bf16_t>(value, shapes, lsi, loc, attn, out, d, variant, stream);
@@ -2104,9 +2180,11 @@ static int fused_dispatch(bool backward, const void* value, const int64_t* shape
                           const void* raw_off, const void* raw_logit, const void* grad_out, void* out_or_grad_off,
                           void* grad_logit, const MsdaDims& d, void* records, void* tile_summary, const FusedArgs& fa,
                           hipStream_t stream) {
-  if constexpr (sizeof(TV) == 4 && sizeof(TL) == 4) {      // encoder calls: the coarse levels staged in LDS (msda_fwd_slab_kernel)
-    if (!backward && use_slab_forward(VNX_F32, VNX_F32, d, kernel_variant()))
-      return launch_fwd_slab<float>(value, shapes, lsi, raw_off, raw_logit, out_or_grad_off, d, &fa, stream);
+  if constexpr (sizeof(TL) == 4) {      // encoder calls: the coarse levels staged in LDS (msda_fwd_slab_kernel; 16-bit values: round 6)
+    if (!backward && use_slab_forward(sizeof(TV) == 4 ? VNX_F32 : VNX_BF16, VNX_F32, d, kernel_variant()))
+      return launch_fwd_slab<TV, float>(value, shapes, lsi, raw_off, raw_logit, out_or_grad_off, d, &fa, stream);
+  }
+  if constexpr (sizeof(TV) == 4 && sizeof(TL) == 4) {
     // ... their backward, tile-fed grad_value: msda_bwd_slab_kernel<true> was built and measured in round 6 (boxes per 4 queries, as
     // the automatic configuration's) and is NOT the product path -- kbench cold, fused backward, slab / gather form of the grad_loc
     // half: encoder-360p B = 5 175.2 / 171.0 us, B = 10 356.6 / 322.5, 720p B = 5 660.7 / 632.0, B = 2 287.0 / 286.0.  The fused
