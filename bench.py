@@ -1084,8 +1084,11 @@ def main():
             r = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                  "traffic": None, "kernel": what, "algorithmic_bytes_per_launch": nbytes, "us_per_launch": us_events,
                  "timing": "HIP events on the launch stream around hipGraphs of back-to-back launches on rotating inputs (cold): "
-                           "(three replays - one replay) / (2 x launches); agrees with the rocprofv3 --kernel-trace average "
-                           "of this command (profiles/)"}
+                           "(three replays - one replay) / (2 x launches), i.e. launch-to-launch time INCLUDING the gap between "
+                           "consecutive launches; the rocprofv3 --kernel-trace average of this command (profiles/, attached as "
+                           "rocprofv3_kernel_avg_us) counts the kernel alone and has come out 4 % above (round 5, a traced run on "
+                           "another box) to 13 % below (round 6, the backward) this figure; us_kernel_span = first workgroup's start "
+                           "to last workgroup's end by in-kernel stamps"}
             if us_span:
                 r["us_kernel_span"] = us_span
                 r["frac_kernel_span"] = nbytes / us_span / 1e3 / HBM_PEAK_GBS

@@ -313,7 +313,7 @@ int vnx_tracker_frame(const vnx_tracker_config* cfg, void* state, const float* m
  * deformable transformer (projects/SeqFormer/seqformer/models/deformable_transformer.py:201-236,286-385:
  * `src = src + self.dropout1(src2); src = self.norm1(src)`), three ATen launches forward and four backward per site.
  *   x, r, y, z [rows, 256] fp32 contiguous; gamma, beta [256]; stats [rows, 2] = {mean, rstd} per row.
- *   dtype (ABI 14) names the element type of the BRANCH -- r and grad_r: VNX_F32 or VNX_BF16 -- and nothing else: under
+ *   dtype (ABI 14) names the element type of the BRANCH -- r and grad_r: VNX_F32, VNX_BF16 or VNX_F16 -- and nothing else: under
  *   torch.autocast(bfloat16) the Linear or attention output that arrives here is bf16 while the residual stream x, the
  *   LayerNorm and its output are fp32 (the eager chain's types: the sum promotes, autocast runs layer_norm in fp32).
  *   Arithmetic is fp32 either way; grad_r is rounded once on its way out.
@@ -343,7 +343,7 @@ int vnx_add_dropout_layernorm_backward(int dtype, const void* grad_y, const void
 
 /*
  * Bias / activation epilogues of a library GEMM that ran WITHOUT its bias, IN PLACE over h [rows, channels] -- dtype:
- * VNX_F32, or (ABI 14) VNX_BF16 for the output of a bf16 GEMM under autocast: h, grad and grad_h in that type, the bias, its
+ * VNX_F32, or (ABI 14) VNX_BF16 / VNX_F16 for the output of a 16-bit GEMM under autocast: h, grad and grad_h in that type, the bias, its
  * gradient and the partial sums fp32, arithmetic fp32 -- (channels a multiple of 4, <= 4 096), with the bias gradient produced
  * by the backward pass itself:
  *   relu != 0: y = dropout(relu(h + bias)) -- the middle of a transformer FFN

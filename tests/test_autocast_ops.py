@@ -33,14 +33,15 @@ def _norm(seed=0):
 
 @pytest.mark.parametrize("shape", [(1, 256), (5, 300, 256), (2, 5100, 256)])
 @pytest.mark.parametrize("with_bias", [False, True])
-def test_add_dropout_norm_with_a_bf16_branch(shape, with_bias):
+@pytest.mark.parametrize("bdt", [torch.bfloat16, torch.float16])
+def test_add_dropout_norm_with_a_bf16_branch(shape, with_bias, bdt):
     """x fp32, r bf16 (a Linear's output under autocast), optional folded fp32 bias: y fp32 = LayerNorm(x + r (+ b)); grad_x fp32,
     grad_r bf16, grad_gamma / grad_beta / grad_bias fp32 -- against the fp64 composition on the same bf16-rounded r."""
     norm = _norm()
     drop = torch.nn.Dropout(0.1).eval()
     g = torch.Generator().manual_seed(3)
     x = (2 * torch.randn(shape, generator=g) + 0.5).to(DEV).requires_grad_(True)
-    r = torch.randn(shape, generator=g).to(DEV).bfloat16().requires_grad_(True)
+    r = torch.randn(shape, generator=g).to(DEV).to(bdt).requires_grad_(True)      # (float16: what Detectron2's AMP trainer autocasts to)
     bias = (0.3 * torch.randn(256, generator=g)).to(DEV).requires_grad_(True) if with_bias else None
     assert fused_norm.fused_applies(x, r, norm)
     y = fused_norm.add_dropout_norm(x, r, drop, norm, r_bias=bias)
@@ -54,7 +55,7 @@ def test_add_dropout_norm_with_a_bf16_branch(shape, with_bias):
     go = torch.randn(shape, generator=g).to(DEV)
     y.backward(go)
     want.backward(go.double())
-    assert r.grad.dtype == torch.bfloat16 and x.grad.dtype == torch.float32
+    assert r.grad.dtype == bdt and x.grad.dtype == torch.float32
     close(x.grad, xd.grad, 1e-5, "grad_x")
     close(r.grad, rd.grad, 1e-2, "grad_r")             # stored in bf16
     close(norm.weight.grad, nd.weight.grad, 1e-5, "grad_gamma")
@@ -82,7 +83,8 @@ def test_add_dropout_norm_bf16_branch_mask_matches_between_forward_and_backward(
 
 
 @pytest.mark.parametrize("shape,d_ffn", [((5, 300, 256), 1024), ((2, 5100, 256), 1024), ((77, 256), 36)])
-def test_ffn_block_under_autocast_takes_the_kernels_and_matches_fp32(shape, d_ffn):
+@pytest.mark.parametrize("adt", [torch.bfloat16, torch.float16])
+def test_ffn_block_under_autocast_takes_the_kernels_and_matches_fp32(shape, d_ffn, adt):
     torch.manual_seed(5)
     l1, l2 = torch.nn.Linear(256, d_ffn).to(DEV), torch.nn.Linear(d_ffn, 256).to(DEV)
     norm = _norm(1)
@@ -93,7 +95,7 @@ def test_ffn_block_under_autocast_takes_the_kernels_and_matches_fp32(shape, d_ff
         for m in (l1, l2, norm):
             m.zero_grad(set_to_none=True)
         xi = x.clone().requires_grad_(True)
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+        with torch.autocast("cuda", dtype=adt, enabled=amp):
             if fused:
                 assert fused_ffn.fused_applies(xi, l1, l2, norm, F.relu)
                 y = fused_ffn.ffn_block(xi, l1, F.relu, d_mid, l2, d_out, norm)

@@ -182,8 +182,8 @@ layernorm_param_grad_kernel(const float* __restrict__ partial, float* __restrict
 }
 
 static int an_check(const char* who, int dtype, int64_t rows, int channels, float p) {
-  if (dtype != VNX_F32 && dtype != VNX_BF16) {
-    set_error("%s: the branch is f32 or bf16 (got dtype %d)", who, dtype);
+  if (dtype != VNX_F32 && dtype != VNX_BF16 && dtype != VNX_F16) {
+    set_error("%s: the branch is f32, bf16 or f16 (got dtype %d)", who, dtype);
     return VNX_ERR_UNSUPPORTED;
   }
   if (channels != kAnC) { set_error("%s: built for %d channels per row (got %d)", who, kAnC, channels); return VNX_ERR_UNSUPPORTED; }
@@ -221,7 +221,7 @@ extern "C" int vnx_add_dropout_layernorm_forward(int dtype, const void* x, const
                      (hipStream_t)hip_stream, (const float*)x, (const TR*)r, (const float*)r_bias, (const float*)gamma,  \
                      (const float*)beta, (float*)y, (float*)z, (float*)stats, int64_t(rows), an_threshold(p),           \
                      1.f / (1.f - p), eps, uint32_t(seed), uint32_t(seed >> 32), seed_device)
-  if (dtype == VNX_BF16) VNX_AN_FWD(bf16_t); else VNX_AN_FWD(float);
+  if (dtype == VNX_BF16) VNX_AN_FWD(bf16_t); else if (dtype == VNX_F16) VNX_AN_FWD(f16_t); else VNX_AN_FWD(float);
 #undef VNX_AN_FWD
   return check_launch("add_dropout_layernorm_fwd");
 }
@@ -248,7 +248,7 @@ extern "C" int vnx_add_dropout_layernorm_backward(int dtype, const void* grad_y,
                        (const float*)grad_y, (const float*)z, (const float*)stats, (const float*)gamma, (float*)grad_x,   \
                        (TR*)grad_r, (float*)partial, int64_t(rows), an_threshold(p), 1.f / (1.f - p), uint32_t(seed),     \
                        uint32_t(seed >> 32), seed_device)
-    if (dtype == VNX_BF16) VNX_AN_BWD(bf16_t); else VNX_AN_BWD(float);
+    if (dtype == VNX_BF16) VNX_AN_BWD(bf16_t); else if (dtype == VNX_F16) VNX_AN_BWD(f16_t); else VNX_AN_BWD(float);
 #undef VNX_AN_BWD
   } else {
     blocks = 0;

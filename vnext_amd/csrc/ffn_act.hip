@@ -126,7 +126,7 @@ column_partial_sum_kernel(const float* __restrict__ partial, float* __restrict__
 }
 
 static int fa_check(const char* who, int dtype, int64_t rows, int cols, float p) {
-  if (dtype != VNX_F32 && dtype != VNX_BF16) { set_error("%s: f32 or bf16 rows (got dtype %d)", who, dtype); return VNX_ERR_UNSUPPORTED; }
+  if (dtype != VNX_F32 && dtype != VNX_BF16 && dtype != VNX_F16) { set_error("%s: f32, bf16 or f16 rows (got dtype %d)", who, dtype); return VNX_ERR_UNSUPPORTED; }
   if (cols <= 0 || (cols & 3) || cols > kFaMaxCols) {
     set_error("%s: built for rows of 4..%d channels, a multiple of 4 (got %d)", who, kFaMaxCols, cols);
     return VNX_ERR_UNSUPPORTED;
@@ -170,7 +170,7 @@ extern "C" int vnx_bias_relu_dropout_forward(int dtype, void* h, const void* bia
   hipLaunchKernelGGL(bias_relu_dropout_fwd_kernel<T>, grid, dim3(256), 0, (hipStream_t)hip_stream, (T*)h,              \
                      (const float*)bias, (const uint8_t*)row_zero, int64_t(rows), channels / 4, relu, fa_threshold(p), \
                      1.f / (1.f - p), uint32_t(seed), uint32_t(seed >> 32), seed_device)
-  if (dtype == VNX_BF16) VNX_FA_FWD(bf16_t); else VNX_FA_FWD(float);
+  if (dtype == VNX_BF16) VNX_FA_FWD(bf16_t); else if (dtype == VNX_F16) VNX_FA_FWD(f16_t); else VNX_FA_FWD(float);
 #undef VNX_FA_FWD
   return check_launch("bias_relu_dropout_fwd");
 }
@@ -194,7 +194,7 @@ extern "C" int vnx_bias_relu_dropout_backward(int dtype, const void* grad, const
     hipLaunchKernelGGL(bias_relu_dropout_bwd_kernel<T>, dim3(uint32_t(blocks)), dim3(channels / 4), 0, stream, (const T*)grad, \
                        (const T*)y, (const uint8_t*)row_zero, (T*)grad_h, grad_bias ? (float*)partial : (float*)nullptr,       \
                        int64_t(rows), channels, 1.f / (1.f - p))
-    if (dtype == VNX_BF16) VNX_FA_BWD(bf16_t); else VNX_FA_BWD(float);
+    if (dtype == VNX_BF16) VNX_FA_BWD(bf16_t); else if (dtype == VNX_F16) VNX_FA_BWD(f16_t); else VNX_FA_BWD(float);
 #undef VNX_FA_BWD
   } else {
     blocks = 0;

@@ -56,7 +56,17 @@ template <typename TV> __device__ __forceinline__ void store4(TV* p, float4_t v)
 template <> __device__ __forceinline__ void store4<float>(float* p, float4_t v) {
   // grad_value is written once and read by another kernel much later: `nt` (decoder-360p backward 33.8 -> 31.4 us)
   // (same WRITE_SIZE / FETCH_SIZE per launch as plain stores; rocprofv3 18.9 vs 20.0 us for this kernel)
+#if defined(VNX_GV_STORE_POLICY) && VNX_GV_STORE_POLICY == 1      // A/B (round 6): cache policy of the row stores, for the step (fwd behind bwd)
+  asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" : : "v"(p), "v"(v) : "memory");
+#elif defined(VNX_GV_STORE_POLICY) && VNX_GV_STORE_POLICY == 2
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" : : "v"(p), "v"(v) : "memory");
+#elif defined(VNX_GV_STORE_POLICY) && VNX_GV_STORE_POLICY == 3
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+#elif defined(VNX_GV_STORE_POLICY) && VNX_GV_STORE_POLICY == 4
+  *reinterpret_cast<float4_t*>(p) = v;
+#else
   __builtin_nontemporal_store(v, reinterpret_cast<float4_t*>(p));
+#endif
 }
 template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, float4_t v) {
   uint2_t r;

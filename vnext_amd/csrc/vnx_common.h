@@ -47,6 +47,11 @@ template <> __device__ __forceinline__ vnx_f4 row4_load<bf16_t>(const bf16_t* p)
   const vnx_u2 r = *reinterpret_cast<const vnx_u2*>(p);
   return vnx_f4{__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u)};
 }
+template <> __device__ __forceinline__ vnx_f4 row4_load<f16_t>(const f16_t* p) {
+  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+  const h4 r = *reinterpret_cast<const h4*>(p);
+  return vnx_f4{float(r.x), float(r.y), float(r.z), float(r.w)};
+}
 template <typename T> __device__ __forceinline__ void row4_store(T* p, vnx_f4 v);
 template <> __device__ __forceinline__ void row4_store<float>(float* p, vnx_f4 v) { *reinterpret_cast<vnx_f4*>(p) = v; }
 template <typename T> __device__ __forceinline__ void row4_store_nt(T* p, vnx_f4 v);
@@ -59,6 +64,14 @@ template <> __device__ __forceinline__ bf16_t from_acc<bf16_t>(float x) { return
 template <> __device__ __forceinline__ f16_t from_acc<f16_t>(float x) { return f16_t{_Float16(x)}; }
 template <> __device__ __forceinline__ void row4_store<bf16_t>(bf16_t* p, vnx_f4 v) {
   *reinterpret_cast<vnx_u2*>(p) = vnx_u2{f32x2_to_bf16x2(v.x, v.y), f32x2_to_bf16x2(v.z, v.w)};
+}
+template <> __device__ __forceinline__ void row4_store<f16_t>(f16_t* p, vnx_f4 v) {
+  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+  *reinterpret_cast<h4*>(p) = h4{_Float16(v.x), _Float16(v.y), _Float16(v.z), _Float16(v.w)};
+}
+template <> __device__ __forceinline__ void row4_store_nt<f16_t>(f16_t* p, vnx_f4 v) {
+  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+  __builtin_nontemporal_store(h4{_Float16(v.x), _Float16(v.y), _Float16(v.z), _Float16(v.w)}, reinterpret_cast<h4*>(p));
 }
 template <> __device__ __forceinline__ void row4_store_nt<bf16_t>(bf16_t* p, vnx_f4 v) {
   __builtin_nontemporal_store(vnx_u2{f32x2_to_bf16x2(v.x, v.y), f32x2_to_bf16x2(v.z, v.w)}, reinterpret_cast<vnx_u2*>(p));

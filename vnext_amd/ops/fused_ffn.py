@@ -45,7 +45,7 @@ ENABLE_MASKED_LINEAR = os.environ.get("VNX_FUSED_MASKED_LINEAR", "1") != "0"
 
 
 def _code(dtype):
-    return _lib.VNX_BF16 if dtype == torch.bfloat16 else _lib.VNX_F32
+    return {torch.bfloat16: _lib.VNX_BF16, torch.float16: _lib.VNX_F16}.get(dtype, _lib.VNX_F32)
 
 
 def _gemm_dtype_ok(x, *weights) -> bool:
@@ -53,7 +53,7 @@ def _gemm_dtype_ok(x, *weights) -> bool:
     in-place passes take as they are (ffn_act.hip / add_norm.hip read bf16 rows and compute in fp32)."""
     if x.dtype != torch.float32 or any(w.dtype != torch.float32 for w in weights):
         return False
-    return not torch.is_autocast_enabled() or torch.get_autocast_dtype("cuda") == torch.bfloat16
+    return not torch.is_autocast_enabled() or torch.get_autocast_dtype("cuda") in (torch.bfloat16, torch.float16)
 
 
 class _BiasReluDropout(torch.autograd.Function):

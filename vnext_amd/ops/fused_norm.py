@@ -139,13 +139,14 @@ class _AddDropoutLayerNorm(torch.autograd.Function):
 
 
 def _branch_code(dtype):
-    return _lib.VNX_BF16 if dtype == torch.bfloat16 else _lib.VNX_F32
+    return {torch.bfloat16: _lib.VNX_BF16, torch.float16: _lib.VNX_F16}.get(dtype, _lib.VNX_F32)
 
 
 def fused_applies(x, r, norm) -> bool:
-    """fp32 residual stream and LayerNorm; the branch fp32 or -- what a Linear emits under torch.autocast(bfloat16) -- bf16.
+    """fp32 residual stream and LayerNorm; the branch fp32 or -- what a Linear emits under torch.autocast -- bf16 / f16 (Detectron2's
+    AMP trainer autocasts to float16).
     The result is fp32 either way, as the eager chain's (the sum promotes, autocast runs layer_norm in fp32)."""
-    return (x.is_cuda and x.dtype == torch.float32 and r.dtype in (torch.float32, torch.bfloat16) and x.shape == r.shape
+    return (x.is_cuda and x.dtype == torch.float32 and r.dtype in (torch.float32, torch.bfloat16, torch.float16) and x.shape == r.shape
             and x.shape[-1] == CHANNELS and tuple(norm.normalized_shape) == (CHANNELS,)
             and norm.weight is not None and norm.bias is not None and norm.weight.dtype == torch.float32)
 
