@@ -1102,6 +1102,13 @@ def main():
         line["roofline_bwd"] = roof(bytes_bwd, us_bwd, k_us[4],
                                     "msda_bwd_pair_kernel: one launch per ms_deform_attn_backward call, its workgroups either "
                                     "grad_value units (from the op's inputs) or eight grad_loc / grad_attn waves")
+        line["roofline_bwd"]["alone_vs_in_step"] = (
+            "us_per_launch is the backward replayed back to back (backward behind backward).  The unit split the launcher takes "
+            "for this call -- the small levels cut in two, 815 workgroups for 768 resident -- was chosen on ms_per_step (backward "
+            "behind forward: 24.8 against 25.7 us per step, the product library built both ways on one box); in backward-only "
+            "sequences it is the slower split (23.4 against 21.2 us by these events; rocprofv3 18.6 against 18.5).  "
+            "step_us_minus_forward_us = ms_per_step - the forward's us_per_launch: the backward's share of a step")
+        line["roofline_bwd"]["step_us_minus_forward_us"] = line["ms_per_step"] * 1e3 - us_fwd
         if k_us[2]:
             line["roofline_bwd"]["us_grad_loc_kernel_span"] = k_us[2]
         if k_us[3]:

@@ -1,6 +1,6 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-for v in base p_st1 p_st2 p_st3 base; do
+for v in base p_f44 p_f21 p_f81 base; do
   if [ "$v" = base ]; then L=""; else L=$GRAFT_REPO_ROOT/tools/ab/$v/libvnext_hip.so; fi
   VNX_HIP_LIB=$L python bench.py --no-cpu --no-model --no-cases --no-warm > gpurun_out/r6_bench_ab_$v.json 2> gpurun_out/r6_bench_ab_$v.err
   python - <<PY

@@ -1795,7 +1795,11 @@ static int launch_pair(const void* value, const int64_t* shapes, const int64_t* 
   const int64_t gl_blocks = int64_t(d.B) * tiles_per_batch * d.M;
   const int64_t gl_groups = (gl_blocks + int64_t(kPairWaves) * d.M - 1) / (int64_t(kPairWaves) * d.M);      // of M workgroups each
   const int rows = gvd_rows_max(d.S);
-  const int ut = gvd_units_min(d.S, d.L, d.B * d.M, rows, gl_groups * d.M);      // (the small levels are cut only if BOTH roles then fit one round)
+#ifdef VNX_PAIR_UT      // A/B: units per level at least, forced
+  const int ut = VNX_PAIR_UT;
+#else
+  const int ut = gvd_units_min(d.S, d.L, d.B * d.M, rows, gl_groups * d.M);      // (the small levels are cut only if BOTH roles then fit about one round)
+#endif
   const int64_t gv_blocks = ((int64_t(d.B) * msda_gvdirect_units_bound(d, ut, rows) + 1) & ~int64_t(1)) * d.M;
   // Role order (see the kernel): with everything resident in ONE round of three workgroups per CU the grad_value groups go
   // first -- their units are the longest workgroups (T = 5 call, 735 workgroups: 19.5 us against 20.7 with the grad_loc groups

@@ -58,7 +58,7 @@ extern "C" int vnx_debug_read_gvd_stamps(unsigned long long* host, int n) {
 // Workgroups per (batch, head): the host knows S, not the level shapes.  A level of n pixels has
 // max(ceil(n / ROWS), min(ut, n)) units (gvd_level_split): ceil(n / ROWS) + 1 bounds it for ut <= 2, and
 // sum ceil(n_l / ROWS) <= S / ROWS + L.
-int msda_gvdirect_units_bound(const MsdaDims& d, int ut, int rows) { return d.S / rows + d.L + (ut > 1 ? d.L : 0); }
+int msda_gvdirect_units_bound(const MsdaDims& d, int ut, int rows) { return d.S / rows + d.L + (ut > 1 ? (ut - 1) * d.L : 0); }
 int msda_gvdirect_units_bound(const MsdaDims& d) {      // the stand-alone launcher's
   const int rows = gvd_rows_max(d.S);
   return msda_gvdirect_units_bound(d, gvd_units_min(d.S, d.L, d.B * d.M, rows), rows);

@@ -256,7 +256,12 @@ __host__ __device__ inline GvSplit gv_level_split(int n, int units_min, int rows
 #define VNX_GVD_SMALL_S 8192
 #endif
 #ifndef VNX_GVD_ONE_ROUND
-#define VNX_GVD_ONE_ROUND 768     // workgroups resident at once: 3 per CU x 256 CUs
+#define VNX_GVD_ONE_ROUND 832     // workgroups resident at once -- 3 per CU x 256 CUs = 768 -- plus a twelfth: the T = 5 decoder call with
+                                  // its small levels cut in two is 440 + 375 = 815 workgroups, and in the bench's fwd + bwd step that
+                                  // is the best split measured (round 6, the product library built each way, same box: 7.73-7.76
+                                  // Gpoints/s against 7.45-7.47 uncut -- the uncut call's longest units, whole coarse levels, end the
+                                  // launch alone on their CUs and hold the next launch back -- 6.80 with three units per level, 6.45
+                                  // with four; backward-only sequences prefer the uncut call, 19.5 against 21.5 us)
 #endif
 struct GvdSplit { int units, rpu, gshift; };
 // Units per level at least.  A level that fits one unit (the 240- and 60-pixel levels at 360p) receives as many taps as a
