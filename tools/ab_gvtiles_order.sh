@@ -1,5 +1,6 @@
 #!/bin/bash
-# round 6: tile-fed grad_value kernel, batch element major against minor (encoder shapes, kbench cold + FETCH_SIZE)
+# Round 6: tile-fed grad_value kernel, batch element major (tools/ab/gvt_bmajor: -DVNX_GVT_BATCH_MAJOR=1 on msda_d32_gvtiles.hip) against
+# minor (base): encoder shapes, kbench cold + FETCH_SIZE
 cd $GRAFT_REPO_ROOT
 K=$GRAFT_REPO_ROOT/tools/kbench.bin
 O=$GRAFT_REPO_ROOT/gpurun_out/r6_ab_enc.log
@@ -7,14 +8,14 @@ P=$GRAFT_REPO_ROOT/gpurun_out/r6_ab_enc_pmc
 mkdir -p $P
 : > $O
 run() { echo "=== $1: ${@:2}" >> $O; if [ "$1" = base ]; then ${@:2} >> $O 2>&1; else LD_LIBRARY_PATH=$GRAFT_REPO_ROOT/tools/ab/$1 ${@:2} >> $O 2>&1; fi; }
-for v in base gvt_bminor; do
+for v in base gvt_bmajor; do
   run $v $K --shape enc360 --dist M --op bwd --variants 0 --check --inner 8
   run $v $K --shape enc720 --dist M --op bwd --variants 0 --inner 4 --reps 5
   run $v $K --shape enc720 --dist M --B 2 --op bwd --variants 0 --inner 4 --reps 5
   run $v $K --shape enc360 --dist M --dtype bf16 --op bwd --variants 0 --inner 8
 done
 cd /tmp && export TMPDIR=/tmp
-for v in base gvt_bminor; do
+for v in base gvt_bmajor; do
   if [ "$v" = base ]; then L=""; else L=$GRAFT_REPO_ROOT/tools/ab/$v; fi
   LD_LIBRARY_PATH=$L rocprofv3 --pmc FETCH_SIZE --output-format csv -d $P -o ${v}_enc720 -- $K --shape enc720 --dist M --op bwd --variants 0 --cold-only --inner 2 --reps 2 > /dev/null 2> $P/${v}_enc720.err
   LD_LIBRARY_PATH=$L rocprofv3 --pmc FETCH_SIZE --output-format csv -d $P -o ${v}_enc360 -- $K --shape enc360 --dist M --op bwd --variants 0 --cold-only --inner 2 --reps 2 > /dev/null 2> $P/${v}_enc360.err
