@@ -107,8 +107,14 @@ def test_nothing_touches_the_slab_forwards_prefetched_samples_before_the_wait(tm
     subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-I", os.path.dirname(D32), "-S",
                            "--cuda-device-only", "-o", str(out), D32], stderr=subprocess.DEVNULL)
     text = open(out).read()
-    m = re.search(r"^(_ZN3vnx20msda_fwd_slab_kernelIfLb0EEE\w*):[^\n]*\n(.*?)^\.Lfunc_end", text, re.S | re.M)
-    assert m, "the unfused slab kernel is gone?"
+    # every unfused instantiation with fp32 locations prefetches its samples this way: fp32, bf16 and f16 values (round 6)
+    for tv in ("f", "NS_6bf16_tE", "NS_5f16_tE"):
+        m = re.search(r"^(_ZN3vnx20msda_fwd_slab_kernelI" + tv + r"fLb0EEE\w*):[^\n]*\n(.*?)^\.Lfunc_end", text, re.S | re.M)
+        assert m, "the unfused slab kernel (%s) is gone?" % tv
+        _check_slab_prefetch(m)
+
+
+def _check_slab_prefetch(m):
     lines = [l.split(";")[0].strip() for l in m.group(2).splitlines()]
     # hand-issued loads: the instructions between ;;#ASMSTART / ;;#ASMEND markers (the split above removed the markers'
     # text, so find them in the raw body)

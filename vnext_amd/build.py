@@ -70,6 +70,8 @@ def build_hip(force: bool = False, verbose: bool = False, out: str | None = None
         return LIB_PATH
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     obj_dir = OBJ_DIR if not defines else OBJ_DIR + "_" + "_".join(d.replace("=", "-") for d in defines)
+    if out is not None and os.path.dirname(os.path.abspath(out)) != os.path.abspath(LIB_DIR):
+        obj_dir = os.path.join(os.path.dirname(os.path.abspath(out)), "obj")      # experiment builds keep their objects beside them (tools/ab/...)
     os.makedirs(obj_dir, exist_ok=True)
     hdr_time = max(os.path.getmtime(h) for h in _headers())
 
