@@ -18,7 +18,7 @@ import torch
 from torch import nn
 from torch.nn.init import constant_, normal_, xavier_uniform_
 
-from ..ops.fused_ffn import ffn_block
+from ..ops.fused_ffn import autocast_once, ffn_block
 from ..ops.fused_norm import add_dropout_norm
 from ..ops.self_attention import query_self_attention_block
 from ..ops.modules import MSDeformAttnIDOL
@@ -110,6 +110,7 @@ class DeformableTransformerDecoder(nn.Module):
         (queries, references).  The box predictions are the refined references before they are detached: what the detector's
         box head would compute again (projects/IDOL/idol/models/deformable_detr.py:214-232; see seqformer_transformer.py)."""
         scaled = ReferenceScaler(src_valid_ratios, extra_axes=1)       # [N, 1, L, 2|4] against [N, Q, 1, 2|4]
+        src = autocast_once(src)      # every layer's cross attention projects it: one cast under autocast, not one per call
         unscale = src_valid_ratios[:, None, None, None, :, :]
         queries = tgt
         kept, kept_refs, kept_samples, kept_boxes = [], [], [], []

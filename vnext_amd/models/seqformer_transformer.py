@@ -21,7 +21,7 @@ import torch.nn.functional as F
 from torch import nn
 from torch.nn.init import constant_, normal_, xavier_uniform_
 
-from ..ops.fused_ffn import ffn_block
+from ..ops.fused_ffn import autocast_once, ffn_block
 from ..ops.fused_norm import add_dropout_norm
 from ..ops.decoder_glue import time_weighted_sum
 from ..ops.modules import MSDeformAttnSeqFormer
@@ -198,6 +198,7 @@ class DeformableTransformerDecoder(nn.Module):
         head evaluates exactly this expression again for its loss (reference: deformable_detr.py:195-213) -- here it takes
         them from this loop instead (six box MLPs, logits and sigmoids less per step)."""
         scaled = ReferenceScaler(src_valid_ratios, extra_axes=2)       # [N, 1, 1, L, 2|4] against [N, T, Q, 1, 2|4]
+        src = autocast_once(src)      # every layer's cross attention projects it: one cast under autocast, not one per call
         queries, box_queries = tgt, tgt
         kept = ([], [], [], [])
         for lid, layer in enumerate(self.layers):

@@ -48,12 +48,28 @@ def _code(dtype):
     return {torch.bfloat16: _lib.VNX_BF16, torch.float16: _lib.VNX_F16}.get(dtype, _lib.VNX_F32)
 
 
+def autocast_once(t):
+    """`t` in the autocast dtype when autocast is on and `t` is an fp32 CUDA tensor, else `t` itself.  Autocast casts the fp32
+    INPUT of every GEMM at the call -- a tensor that feeds k Linears is cast k times forward, and autograd casts k gradients back
+    and adds them in fp32.  A tensor with several consumers is cast ONCE with this instead (round 6: the decoder's `memory`
+    feeds the value projection of all 12 cross-attention calls of a SeqFormer step -- 12 x 78 MB of casts forward, 12 x 78 MB of
+    casts + 12 fp32 accumulations of 52 MB backward; a query feeds two Linears).  The cast is part of the graph: gradients meet
+    in the 16-bit dtype and come back through one cast."""
+    if torch.is_autocast_enabled() and t.is_cuda and t.dtype == torch.float32:
+        return t.to(torch.get_autocast_dtype("cuda"))
+    return t
+
+
 def _gemm_dtype_ok(x, *weights) -> bool:
-    """fp32 activations and weights: plain fp32 GEMMs, or -- under torch.autocast(bfloat16) -- bf16 GEMMs whose outputs the
-    in-place passes take as they are (ffn_act.hip / add_norm.hip read bf16 rows and compute in fp32)."""
-    if x.dtype != torch.float32 or any(w.dtype != torch.float32 for w in weights):
+    """fp32 activations and weights: plain fp32 GEMMs, or -- under torch.autocast(bfloat16 / float16) -- 16-bit GEMMs whose
+    outputs the in-place passes take as they are (ffn_act.hip / add_norm.hip read 16-bit rows and compute in fp32); the
+    activation may already be in the autocast dtype (autocast_once)."""
+    if any(w.dtype != torch.float32 for w in weights):
         return False
-    return not torch.is_autocast_enabled() or torch.get_autocast_dtype("cuda") in (torch.bfloat16, torch.float16)
+    if not torch.is_autocast_enabled():
+        return x.dtype == torch.float32
+    adt = torch.get_autocast_dtype("cuda")
+    return adt in (torch.bfloat16, torch.float16) and x.dtype in (torch.float32, adt)
 
 
 class _BiasReluDropout(torch.autograd.Function):

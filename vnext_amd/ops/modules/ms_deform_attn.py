@@ -27,7 +27,7 @@ from torch import nn
 from torch.nn.init import constant_, xavier_uniform_
 
 from ... import msda_ext
-from ..fused_ffn import linear_masked
+from ..fused_ffn import autocast_once, linear_masked
 from ..functions import MSDeformAttnFunction, MSDeformAttnFusedFunction, check_flattened_length
 
 
@@ -90,6 +90,7 @@ class _MSDeformAttnBase(nn.Module):
 
     def _raw_offsets_and_logits(self, query):
         lead = query.shape[:-1]
+        query = autocast_once(query)      # (feeds two Linears: one cast under autocast instead of two)
         offsets = self.sampling_offsets(query).view(*lead, self.n_heads, self.n_levels, self.n_points, 2)
         logits = self.attention_weights(query).view(*lead, self.n_heads, self.n_levels * self.n_points)
         return offsets, logits
@@ -118,6 +119,7 @@ class _MSDeformAttnBase(nn.Module):
 
     def _offsets_and_weights(self, query):
         lead = query.shape[:-1]
+        query = autocast_once(query)
         offsets = self.sampling_offsets(query).view(*lead, self.n_heads, self.n_levels, self.n_points, 2)
         weights = self.attention_weights(query).view(*lead, self.n_heads, self.n_levels * self.n_points)
         weights = F.softmax(weights, -1).view(*lead, self.n_heads, self.n_levels, self.n_points)
