@@ -164,7 +164,10 @@ int vnx_msda_backward(int value_dtype, int loc_dtype,
  * reference_batch_div > 1: that many consecutive batch elements share one reference row (the
  * frames of a clip in SeqFormer's encoder).  Requirements: channels == 32,
  * num_levels * num_point == 16, value f32 or bf16 (offsets / logits / references all
- * `query_dtype`: f32, or bf16 with a bf16 value), PACKED levels (level_start_index = running
+ * `query_dtype`: f32, or bf16 with a bf16 value; ABI 14: `ref_dim | VNX_MSDA_REF_F32` says the
+ * reference points are fp32 although offsets / logits are bf16 -- under torch.autocast the two
+ * Linears emit bf16 while the reference points stay fp32, and rounding positions to 8 mantissa
+ * bits would cost more than half a pixel at 720p), PACKED levels (level_start_index = running
  * sum of H*W; the backward's grad_value kernel does nothing on the device otherwise).  Anything
  * else: VNX_ERR_UNSUPPORTED -- use vnx_msda_forward / vnx_msda_backward.
  * Backward: grad_sampling_offsets / grad_attention_logits like their inputs; grad_value like
@@ -172,6 +175,7 @@ int vnx_msda_backward(int value_dtype, int loc_dtype,
  * and reference_batch_div 1 only) is zero-filled inside and accumulated over heads with fp32
  * atomics.  workspace: vnx_msda_fused_backward_workspace_bytes(...) bytes of device memory.
  */
+#define VNX_MSDA_REF_F32 0x100      /* or-ed into ref_dim of vnx_msda_fused_forward / _backward (see above) */
 int vnx_msda_fused_forward(int value_dtype, int query_dtype, const void* value, const int64_t* spatial_shapes,
                            const int64_t* level_start_index, const void* sampling_offsets,
                            const void* attention_logits, const void* reference_points, void* output,

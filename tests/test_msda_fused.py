@@ -238,3 +238,41 @@ def test_fused_backward_with_the_coarse_levels_staged_in_lds(ref_dim, ref_grad):
     for name, got, want in zip(("value", "offsets", "logits", "reference"), grads(734), grads(0)):
         scale = float(want.abs().max()) + 1e-12
         assert float((got - want).abs().max()) <= 2e-5 * scale, name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Lq,ref_dim,ref_div,ref_grad", [(300, 4, 1, False), (300, 2, 1, True), (5100, 2, 2, False), (2300, 4, 1, False)])
+def test_bf16_offsets_and_logits_beside_fp32_reference_points(Lq, ref_dim, ref_div, ref_grad):
+    """what torch.autocast(bfloat16) leaves at the op: bf16 value, bf16 Linear outputs, fp32 reference points
+    (VNX_MSDA_REF_F32, round 6).  Against the same call with the SAME offsets / logits promoted to fp32 (what the module did
+    until round 6): the forward differs by the output's rounding at most, the gradients of the 16-bit inputs by theirs."""
+    from vnext_amd.ops.functions import MSDeformAttnFusedFunction, level_tensors as lt
+    shapes = [(48, 80), (24, 40), (12, 20), (6, 10)]
+    dev = "cuda:0"
+    S = sum(h * w for h, w in shapes)
+    B, M, L, P = 4, 8, 4, 4
+    g = torch.Generator(device=dev).manual_seed(Lq + ref_dim)
+    value = torch.randn(B, S, M, 32, device=dev, generator=g).bfloat16()
+    offsets = (2.0 * torch.randn(B, Lq, M, L, P, 2, device=dev, generator=g)).bfloat16()
+    logits = torch.randn(B, Lq, M, L * P, device=dev, generator=g).bfloat16()
+    ref = torch.rand(B // ref_div, Lq, L, ref_dim, device=dev, generator=g)
+    if ref_dim == 4:
+        ref[..., 2:] = 0.05 + 0.1 * ref[..., 2:]
+    gout = torch.randn(B, Lq, M * 32, device=dev, generator=g).bfloat16()
+    shapes_t, lsi = lt(shapes, dev)
+
+    def run(promote):
+        v = value.clone().requires_grad_(True)
+        o = (offsets.float() if promote else offsets.clone()).requires_grad_(True)
+        lg = (logits.float() if promote else logits.clone()).requires_grad_(True)
+        r = ref.clone().requires_grad_(ref_grad)
+        out = MSDeformAttnFusedFunction.apply(v, shapes_t, lsi, o, lg, r)
+        out.backward(gout)
+        torch.cuda.synchronize()
+        return [out, v.grad, o.grad, lg.grad] + ([r.grad] if ref_grad else [])
+    got, want = run(False), run(True)
+    assert got[2].dtype == torch.bfloat16 and got[3].dtype == torch.bfloat16
+    for name, a, b in zip(("out", "grad_value", "grad_offsets", "grad_logits", "grad_reference"), got, want):
+        scale = float(b.float().abs().max()) + 1e-12
+        tol = 2e-5 if name == "grad_reference" else 1e-2      # fp32 atomics over heads vs one bf16 rounding
+        assert float((a.float() - b.float()).abs().max()) <= tol * scale, name

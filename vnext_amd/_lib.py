@@ -18,6 +18,7 @@ VNX_F32, VNX_F64, VNX_BF16, VNX_F16 = 0, 1, 2, 3
 VNX_OK = 0
 ABI_VERSION = 14
 MSDA_LEVELS_PACKED = 1
+MSDA_REF_F32 = 0x100       # or-ed into ref_dim of vnx_msda_fused_*: fp32 reference points beside 16-bit offsets / logits
 MSDA_FORK = 2              # vnx_msda_backward: grad_value kernel on the library's side stream (include/vnext_hip.h)
 
 _vp, _i, _sz, _ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_longlong

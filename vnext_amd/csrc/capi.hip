@@ -69,7 +69,7 @@ int msda_fused_d32(bool backward, int vdt, int ldt, const void* value, const int
                    const void* raw_off, const void* raw_logit, const void* grad_out, void* out_or_grad_off,
                    void* grad_logit, MsdaDims d, void* records, const void* reference, float* grad_reference,
                    int ref_dim, int ref_div, void* grad_value_f32, void* tile_summary, float* tile_loc, float* tile_attn,
-                   hipStream_t stream);
+                   hipStream_t stream, int ref_f32);
 bool msda_d32_gvrec_supported(int vdt, int ldt, const MsdaDims& d);
 size_t msda_gvrec_record_bytes(const MsdaDims& d);
 int msda_backward_gvrec_d32(int vdt, const int64_t*, const int64_t*, const void* records, const void*,
@@ -598,6 +598,8 @@ int vnx_msda_fused_forward(int value_dtype, int query_dtype, const void* value, 
                            const void* attention_logits, const void* reference_points, void* output, int batch,
                            int spatial_size, int num_heads, int channels, int num_levels, int num_query,
                            int num_point, int ref_dim, int reference_batch_div, void* hip_stream) {
+  const int ref_f32 = (ref_dim & VNX_MSDA_REF_F32) != 0;      // fp32 reference points beside 16-bit offsets / logits (ABI 14)
+  ref_dim &= ~VNX_MSDA_REF_F32;
   const MsdaDims d{batch, spatial_size, num_heads, channels, num_levels, num_query, num_point};
   const int st = check_fused("vnx_msda_fused_forward", value_dtype, query_dtype, d, ref_dim, reference_batch_div);
   if (st != VNX_OK) return st;
@@ -616,7 +618,7 @@ int vnx_msda_fused_forward(int value_dtype, int query_dtype, const void* value, 
 #endif
   return msda_fused_d32(false, value_dtype, query_dtype, value, spatial_shapes, level_start_index, sampling_offsets,
                         attention_logits, nullptr, output, nullptr, d, nullptr, reference_points, nullptr, ref_dim,
-                        reference_batch_div, nullptr, nullptr, nullptr, nullptr, (hipStream_t)hip_stream);
+                        reference_batch_div, nullptr, nullptr, nullptr, nullptr, (hipStream_t)hip_stream, ref_f32);
 }
 
 // Scratch of the fused backward.  Record-fed grad_value: the sample records.  Tile-fed (use_tiles; the fused launcher
@@ -663,6 +665,8 @@ int vnx_msda_fused_backward(int value_dtype, int query_dtype, const void* value,
                             float* grad_reference_points, int batch, int spatial_size, int num_heads,
                             int channels, int num_levels, int num_query, int num_point, int ref_dim,
                             int reference_batch_div, void* workspace, size_t workspace_bytes, void* hip_stream) {
+  const int ref_f32 = (ref_dim & VNX_MSDA_REF_F32) != 0;
+  ref_dim &= ~VNX_MSDA_REF_F32;
   const MsdaDims d{batch, spatial_size, num_heads, channels, num_levels, num_query, num_point};
   int st = check_fused("vnx_msda_fused_backward", value_dtype, query_dtype, d, ref_dim, reference_batch_div);
   if (st != VNX_OK) return st;
@@ -706,7 +710,7 @@ int vnx_msda_fused_backward(int value_dtype, int query_dtype, const void* value,
     st = msda_fused_d32(true, value_dtype, query_dtype, value, spatial_shapes, level_start_index, sampling_offsets,
                         attention_logits, grad_output, grad_sampling_offsets, grad_attention_logits, d, nullptr,
                         reference_points, grad_reference_points, ref_dim, reference_batch_div, nullptr, nullptr, d_loc, d_attn,
-                        stream);
+                        stream, ref_f32);
     if (st != VNX_OK) return st;
     return msda_backward_gvdirect_d32(value_dtype, VNX_F32, spatial_shapes, level_start_index, d_loc, d_attn, grad_output,
                                       grad_value, d, true, stream);
@@ -721,7 +725,7 @@ int vnx_msda_fused_backward(int value_dtype, int query_dtype, const void* value,
     st = msda_fused_d32(true, value_dtype, query_dtype, value, spatial_shapes, level_start_index, sampling_offsets,
                         attention_logits, grad_output, grad_sampling_offsets, grad_attention_logits, d, nullptr,
                         reference_points, grad_reference_points, ref_dim, reference_batch_div, fp32_target, words, tile_loc,
-                        tile_attn, stream);
+                        tile_attn, stream, ref_f32);
     if (st != VNX_OK) return st;
     st = msda_backward_gvtiles_d32(value_dtype, VNX_F32, spatial_shapes, level_start_index, tile_loc, tile_attn, words,
                                    grad_output, grad_value, d, msda_bwd_tile_queries(d, 0), partials, true, stream);
@@ -730,7 +734,7 @@ int vnx_msda_fused_backward(int value_dtype, int query_dtype, const void* value,
     st = msda_fused_d32(true, value_dtype, query_dtype, value, spatial_shapes, level_start_index, sampling_offsets,
                         attention_logits, grad_output, grad_sampling_offsets, grad_attention_logits, d, workspace,
                         reference_points, grad_reference_points, ref_dim, reference_batch_div, fp32_target, nullptr, nullptr,
-                        nullptr, stream);
+                        nullptr, stream, ref_f32);
     if (st != VNX_OK) return st;
     st = msda_backward_gvrec_d32(value_dtype, spatial_shapes, level_start_index, workspace, grad_output,
                                  grad_value, d, variant, split_image, stream);

@@ -230,18 +230,17 @@ __device__ __forceinline__ void fused_decode(const TL* __restrict__ raw_off, con
   a = ex / row16_sum(ex);
   x = y = sx = sy = 0.f;
   if (valid) {
-    const TL* r = static_cast<const TL*>(fa.reference) +
-                  ((int64_t(b / fa.ref_div) * d.Lq + q) * d.L + l) * fa.ref_dim;
+    const int64_t r = ((int64_t(b / fa.ref_div) * d.Lq + q) * d.L + l) * fa.ref_dim;
     const float ox = to_acc(raw_off[2 * wi]), oy = to_acc(raw_off[2 * wi + 1]);
     if (fa.ref_dim == 2) {
-      x = to_acc(r[0]) + ox / float(W);
-      y = to_acc(r[1]) + oy / float(H);
+      x = fused_ref<TL>(fa, r) + ox / float(W);
+      y = fused_ref<TL>(fa, r + 1) + oy / float(H);
       sx = 1.f / float(W);
       sy = 1.f / float(H);
     } else {
-      const float rw = to_acc(r[2]), rh = to_acc(r[3]), np = float(d.P);
-      x = to_acc(r[0]) + ox / np * rw * 0.5f;
-      y = to_acc(r[1]) + oy / np * rh * 0.5f;
+      const float rw = fused_ref<TL>(fa, r + 2), rh = fused_ref<TL>(fa, r + 3), np = float(d.P);
+      x = fused_ref<TL>(fa, r) + ox / np * rw * 0.5f;
+      y = fused_ref<TL>(fa, r + 1) + oy / np * rh * 0.5f;
       sx = rw * 0.5f / np;
       sy = rh * 0.5f / np;
     }
@@ -1608,8 +1607,8 @@ msda_bwd_d32_body(const TV* __restrict__ value, const int64_t* __restrict__ shap
         if (fa.ref_dim == 2) {
           sx = 1.f / Wf; sy = 1.f / Hf;
         } else {
-          const TL* rf = static_cast<const TL*>(fa.reference) + ((int64_t(b / fa.ref_div) * d.Lq + q3) * d.L + l) * 4;
-          sx = to_acc(rf[2]) * 0.5f / float(d.P); sy = to_acc(rf[3]) * 0.5f / float(d.P);
+          const int64_t rf = ((int64_t(b / fa.ref_div) * d.Lq + q3) * d.L + l) * 4;
+          sx = fused_ref<TL>(fa, rf + 2) * 0.5f / float(d.P); sy = fused_ref<TL>(fa, rf + 3) * 0.5f / float(d.P);
         }
 #if VNX_K1_P3 >= 2 && !defined(VNX_K1_P3F_PLAIN)      // as in the unfused branch: one 8-byte store per (x, y), both gradients `nt`
         if constexpr (sizeof(TL) == 4) {
@@ -2186,10 +2185,9 @@ static int fused_dispatch(bool backward, const void* value, const int64_t* shape
                           const void* raw_off, const void* raw_logit, const void* grad_out, void* out_or_grad_off,
                           void* grad_logit, const MsdaDims& d, void* records, void* tile_summary, const FusedArgs& fa,
                           hipStream_t stream) {
-  if constexpr (sizeof(TL) == 4) {      // encoder calls: the coarse levels staged in LDS (msda_fwd_slab_kernel; 16-bit values: round 6)
-    if (!backward && use_slab_forward(sizeof(TV) == 4 ? VNX_F32 : VNX_BF16, VNX_F32, d, kernel_variant()))
-      return launch_fwd_slab<TV, float>(value, shapes, lsi, raw_off, raw_logit, out_or_grad_off, d, &fa, stream);
-  }
+  // encoder calls: the coarse levels staged in LDS (msda_fwd_slab_kernel; 16-bit values, and 16-bit offsets / logits: round 6)
+  if (!backward && use_slab_forward(sizeof(TV) == 4 ? VNX_F32 : VNX_BF16, VNX_F32, d, kernel_variant()))
+    return launch_fwd_slab<TV, TL>(value, shapes, lsi, raw_off, raw_logit, out_or_grad_off, d, &fa, stream);
   if constexpr (sizeof(TV) == 4 && sizeof(TL) == 4) {
     // ... their backward, tile-fed grad_value: msda_bwd_slab_kernel<true> was built and measured in round 6 (boxes per 4 queries, as
     // the automatic configuration's) and is NOT the product path -- kbench cold, fused backward, slab / gather form of the grad_loc
@@ -2223,12 +2221,12 @@ int msda_fused_d32(bool backward, int vdt, int ldt, const void* value, const int
                    const void* raw_off, const void* raw_logit, const void* grad_out, void* out_or_grad_off,
                    void* grad_logit, MsdaDims d, void* records, const void* reference, float* grad_reference,
                    int ref_dim, int ref_div, void* grad_value_f32, void* tile_summary, float* tile_loc, float* tile_attn,
-                   hipStream_t stream) {
+                   hipStream_t stream, int ref_f32) {
   // grad_value_f32: the fp32 target of the query-split levels' atomics (grad_value itself for fp32 values, the split
   // image for 16-bit ones), or null.  Backward: either `records` (record-fed grad_value kernel) or tile_summary +
   // tile_loc + tile_attn (tile-fed one: queries per tile = msda_bwd_tile_queries(d, 0))
   const FusedArgs fa{reference, grad_reference, ref_dim, ref_div, backward ? static_cast<float*>(grad_value_f32) : nullptr,
-                     backward ? tile_loc : nullptr, backward ? tile_attn : nullptr};
+                     backward ? tile_loc : nullptr, backward ? tile_attn : nullptr, ref_f32};
 #define VNX_ARGS backward, value, shapes, lsi, raw_off, raw_logit, grad_out, out_or_grad_off, grad_logit, d, records, tile_summary, fa, stream
   if (vdt == VNX_F32) return fused_dispatch<float, float>(VNX_ARGS);
   if (vdt == VNX_BF16 && ldt == VNX_F32) return fused_dispatch<bf16_t, float>(VNX_ARGS);

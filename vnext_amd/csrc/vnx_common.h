@@ -165,7 +165,14 @@ struct FusedArgs {
   float* qsplit_zero;      // backward, fp32 grad_value: rows of the query-split levels are zeroed here (or null)
   float* tile_loc;         // backward, tile mode of grad_value (msda_d32_gvtiles.hip): the decoded locations [B,Lq,M,L,P,2]
   float* tile_attn;        //   and softmax weights [B,Lq,M,L,P] are left here in fp32 for that kernel (or null)
+  int ref_f32;             // the reference points are fp32 whatever the offsets' type (round 6: under autocast the Linears emit
+                           // 16-bit offsets / logits while the reference points stay fp32 -- VNX_MSDA_REF_F32 of the C ABI)
 };
+// element i of the reference points as fp32
+template <typename TL>
+__device__ __forceinline__ float fused_ref(const FusedArgs& fa, int64_t i) {
+  return fa.ref_f32 ? static_cast<const float*>(fa.reference)[i] : to_acc(static_cast<const TL*>(fa.reference)[i]);
+}
 
 // Query split of the grad_value units (msda_d32_gvrec.hip).  A level of at most two row-units (the coarse
 // levels: 240 and 60 pixels at 360p) receives taps from EVERY query, so each of its units sorts one chunk

@@ -156,7 +156,10 @@ def fused_supported(value, spatial_shapes, sampling_offsets, attention_logits, r
     if not packed_promise_holds(spatial_shapes, level_start_index, value.shape[1]):
         return False
     q = sampling_offsets.dtype
-    if attention_logits.dtype != q or reference_points.dtype != q:
+    if attention_logits.dtype != q:
+        return False
+    # reference points in the offsets' dtype, or fp32 beside bf16 offsets (what autocast leaves: VNX_MSDA_REF_F32)
+    if reference_points.dtype != q and not (q == torch.bfloat16 and reference_points.dtype == torch.float32):
         return False
     return (value.dtype == torch.float32 and q == torch.float32) or \
         (value.dtype == torch.bfloat16 and q in (torch.float32, torch.bfloat16))
@@ -176,6 +179,8 @@ def _fused_dims(value, sampling_offsets, reference_points):
     ref_dim = reference_points.shape[-1]
     if reference_points.shape[0] == 0 or B % reference_points.shape[0] != 0:
         raise RuntimeError("ms_deform_attn_fused: batch must be a multiple of the reference batch")
+    if reference_points.dtype == torch.float32 and sampling_offsets.dtype != torch.float32:
+        ref_dim |= _lib.MSDA_REF_F32      # fp32 reference points beside 16-bit offsets / logits (include/vnext_hip.h)
     return B, S, M, D, L, Lq, P, ref_dim, B // reference_points.shape[0]
 
 

@@ -100,10 +100,12 @@ class _MSDeformAttnBase(nn.Module):
         -> sampled [B, Lq, C] or None when the fused kernels do not take this case."""
         if self.return_samples or not self.fused_prologue:
             return None
-        if reference.dtype != offsets.dtype:
-            # autocast: the Linears emit bf16, reference points stay fp32.  Promote the (small) query-side
-            # tensors rather than rounding positions to 8 mantissa bits; the kernels take a 16-bit value
-            # with fp32 offsets / logits / references.
+        if reference.dtype != offsets.dtype and not (offsets.dtype == torch.bfloat16 and value.dtype == torch.bfloat16
+                                                     and reference.dtype == torch.float32):
+            # autocast: the Linears emit 16-bit tensors, the reference points stay fp32 -- rounding positions to 8 mantissa bits
+            # would cost more than half a pixel at 720p.  bf16: the kernels read the offsets / logits as they are beside fp32
+            # reference points (VNX_MSDA_REF_F32, round 6: until then both were promoted here, two casts forward and two
+            # backward per call, 78 MB each on an encoder call); other combinations are promoted.
             offsets, logits, reference = offsets.float(), logits.float(), reference.float()
         reference = reference.contiguous()
         if not msda_ext.fused_supported(value, spatial_shapes, offsets, logits, reference, level_start_index):
