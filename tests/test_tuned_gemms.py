@@ -1,7 +1,8 @@
 """vnext_amd.tuning: the rocBLAS / hipBLASLt solutions recorded offline for the models' GEMM shapes on MI355X (PyTorch
 TunableOp, tuning OFF at run time).  CPU: the recorded file is well-formed and `enable()` is a no-op without a ROCm device.
 GPU: TunableOp accepts the file on this stack, and the SeqFormer training losses with the recorded solutions equal the
-library-default ones (they are all fp32 GEMMs with fp32 accumulation: only the summation order differs)."""
+library-default ones (fp32 GEMMs with fp32 accumulation: only the summation order differs; round 6: the bf16 GEMMs of the
+autocast legs are recorded too -- tools/tune_gemms_bf16.py -- and the same holds for the bf16 step at bf16's tolerance)."""
 import csv
 
 import pytest
@@ -18,7 +19,7 @@ def test_recorded_file_is_well_formed():
     entries = [r for r in rows if r[0] != "Validator"]
     assert len(entries) > 50
     for op, shape, solution, ms in entries:
-        assert "float" in op.lower(), f"only fp32 GEMMs are recorded, got {op}"       # (the bf16 tuning pass faulted, see tuning/__init__)
+        assert "_float_" in op or "_BFloat16_" in op, f"fp32 and bf16 GEMMs are recorded, got {op}"
         assert solution == "Default" or solution.startswith(("Gemm_Hipblaslt_", "Gemm_Rocblas_"))
         assert float(ms) > 0
     # the shapes that decide the SeqFormer step: the encoder's FFN and value projection over two T=5 360p clips (51 000 rows).
@@ -33,6 +34,20 @@ def test_recorded_file_is_well_formed():
         assert (op, shape) in keys, f"no recorded solution for {op} {shape}: re-run tools/tune_gemms.py at HEAD"
     # config 4's N = 1 point (one T=5 720p clip: 97 800 rows) is tuned too
     assert any("97800" in r[1] for r in entries)
+    # round 6: the bf16 (autocast) legs -- the same FFN GEMMs in bf16, both resolutions, and config 3's IDOL pair
+    for op, shape in (("GemmTunableOp_BFloat16_TN", "tn_1024_51000_256"), ("GemmTunableOp_BFloat16_NN", "nn_256_51000_1024"),
+                      ("GemmTunableOp_BFloat16_NT", "nt_256_1024_51000"), ("GemmTunableOp_BFloat16_TN", "tn_1024_97800_256")):
+        assert (op, shape) in keys, f"no recorded solution for {op} {shape}: re-run tools/tune_gemms_bf16.py at HEAD"
+    # every shape the bf16 legs presented when they were recorded (tuning/bf16_step_shapes.csv) has an entry
+    import os
+    want = {tuple(line.strip().split(",")[:2]) for line in open(os.path.join(os.path.dirname(tuning.TUNED_FILE), "bf16_step_shapes.csv"))
+            if line.startswith("Gemm")}
+    have = {(r[0], r[1]) for r in entries}
+    # (not tunable offline, library default at run time: GEMMs with a dimension of 1, and the fp32 projections of the
+    #  self-attention block on SLICES of in_proj_weight -- torch.cuda.tunable rebuilds a sub-matrix operand with another
+    #  leading dimension than the recorded one; 300-3 000 rows each)
+    missing = [k for k in want - have if "_BFloat16_" in k[0] and "_1_" not in k[1]]
+    assert not missing, sorted(missing)[:5]
 
 
 def test_enable_is_a_noop_without_a_rocm_device():
@@ -74,3 +89,40 @@ def test_recorded_solutions_load_and_leave_the_losses_unchanged():
     assert plain.keys() == tuned.keys()
     for k in plain:
         assert tuned[k] == pytest.approx(plain[k], rel=2e-3, abs=1e-5), k
+
+
+@pytest.mark.gpu
+def test_recorded_bf16_solutions_leave_the_autocast_losses_unchanged():
+    """The bf16 entries: the SeqFormer losses under torch.autocast(bfloat16) with the recorded solutions against the library
+    default -- every candidate multiplies bf16 operands and accumulates in fp32, so the two differ by summation order and by
+    where a bf16 result rounds: BASELINE.json's bf16 tolerance (1e-2 of the value)."""
+    import vnext_amd.models  # noqa: F401
+    from vnext_amd import train as T
+    from vnext_amd.registry import build_model, get_seqformer_cfg
+    dev = "cuda:0"
+    torch.manual_seed(0)
+    model = build_model(get_seqformer_cfg(**{"MODEL.DEVICE": dev})).train()
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+        if isinstance(m, torch.nn.MultiheadAttention):
+            m.dropout = 0.0
+    clips = T.synthetic_clips(2, 5, 360, 640, dev, seed=100, num_instances=4)
+
+    def losses():
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            out = model(clips)
+        torch.cuda.synchronize()
+        return {k: float(v) for k, v in out.items()}
+
+    try:
+        tuning.disable()
+        plain = losses()
+        st = tuning.enable()
+        assert st["enabled"], st
+        tuned = losses()
+    finally:
+        tuning.disable()
+    assert plain.keys() == tuned.keys()
+    for k in plain:
+        assert tuned[k] == pytest.approx(plain[k], rel=1e-2, abs=1e-3), k

@@ -25,6 +25,13 @@ torch.manual_seed(0)
 model = build_model(get_seqformer_cfg(**{"MODEL.DEVICE": dev})).train()
 opt = T.build_optimizer(model)
 clips = T.synthetic_clips(2, 5, 360, 640, dev, seed=100, num_instances=4)
+if os.environ.get("VNX_PROF_AUTOCAST", "") == "bf16":         # the same step under torch.autocast(bfloat16)
+    _step = T.train_step
+
+    def _autocast_step(*a, **k):
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            return _step(*a, **k)
+    T.train_step = _autocast_step
 for _ in range(4):                 # warm-up outside the profiled region: MIOpen's kernel search runs in the first steps
     T.train_step(model, opt, clips)
 torch.cuda.synchronize()

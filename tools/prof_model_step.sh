@@ -3,7 +3,7 @@
 #   python tools/summarize_model_step.py gpurun_out/prof_r05_model/model_kernel_stats.csv 12 profiles/r05_model_step_top_kernels.csv
 set -x
 R=${1:-r05}
-OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_${R}_model
+OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_${R}_model${VNX_PROF_AUTOCAST:+_$VNX_PROF_AUTOCAST}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export VNX_PROF_DELAY=${VNX_PROF_DELAY:-170} VNX_PROF_STEPS=6
