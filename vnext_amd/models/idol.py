@@ -50,6 +50,37 @@ class CondInstSegmIDOL(nn.Module):
         self.reid_embed_head = MLP(hidden, hidden, hidden, 3)
 
 
+class _TrainTrunk(nn.Module):
+    """The shape-static, sync-free part of an IDOL training step -- normalise + pad, backbone, input projections, 6 + 6
+    transformer layers, the class / box heads of every decoder layer on the key frames, the stride-8 mask features, the
+    reference frames' class scores and the reid embeddings -- as one module, so that `torch.cuda.make_graphed_callables` can
+    capture its forward AND its backward into two hipGraphs (SeqFormer's twin:
+    seqformer.py:_TrainTrunk).  Shares the owner's parameters; not registered on the owner.
+
+    Why IDOL wants it more than SeqFormer: a key / reference pair is TWO frames -- the ~3 300 launches of a step carry 38 ms of
+    kernels (720p, bf16) and the step took 52-56 ms: the host could not issue them fast enough (round 6)."""
+
+    def __init__(self, owner):
+        super().__init__()
+        self.detr = owner.detr
+        object.__setattr__(self, "_owner", owner)
+
+    def forward(self, stack):
+        from ..ops.fused_norm import step_scope
+        with step_scope(stack.device):     # the fused dropout sites read a device-side step seed bumped HERE per replay
+            return self._forward(stack)
+
+    def _forward(self, stack):
+        o = self._owner
+        h, w = stack.shape[-2:]
+        H, W = (h + 31) // 32 * 32, (w + 31) // 32 * 32
+        x = stack.new_zeros(stack.shape[0], 3, H, W)
+        x[:, :, :h, :w] = (stack - o.pixel_mean) / o.pixel_std
+        mask = torch.ones(stack.shape[0], H, W, dtype=torch.bool, device=stack.device)
+        mask[:, :h, :w] = False
+        return o._train_trunk(x, mask)
+
+
 def class_aware_nms(boxes_xyxy, scores, classes, thr):
     """torchvision.ops.batched_nms restated on host arrays (published algorithm: boxes of
     different classes never suppress each other; greedy by descending score; returns the kept
@@ -105,7 +136,10 @@ class IDOL(nn.Module):
                                        num_frames=self.num_frames)
         self.deep_supervision = m.DEEP_SUPERVISION
         self.graph_inference = True      # replay the per-chunk inference trunk from a hipGraph
+        self.graph_training = False      # capture the training trunk's forward and backward (opt-in: the trunk's gradients then
+        #                                  reach DDP's buckets together, at the end of the replayed backward)
         self._graphs = {}
+        self._train_trunks = {}
         self.register_buffer("pixel_mean", torch.tensor(cfg.MODEL.PIXEL_MEAN).view(3, 1, 1), persistent=False)
         self.register_buffer("pixel_std", torch.tensor(cfg.MODEL.PIXEL_STD).view(3, 1, 1), persistent=False)
         self.to(self.device)
@@ -167,6 +201,29 @@ class IDOL(nn.Module):
             start += h * w
         return self.detr.mask_head(mem).float().contiguous()
 
+    def _train_trunk(self, x, mask):
+        """Padded frames of the key / reference pairs (key frames at even positions) -> everything `losses` needs from the
+        network, as a flat tuple of tensors: query states of every decoder layer [Ld, N, Q, C]; class logits and boxes of every
+        layer on the KEY frames; the layers' pre-sigmoid reference xy on the key frames [Ld, bz, Q, 2]; the last layer's
+        refined references on the REFERENCE frames; the key frames' stride-8 mask features; the reference frames' class logits
+        (last layer); the reid embeddings of all frames."""
+        srcs, hs, memory, refs, inter_refs, inter_boxes = self._encode_decode(x, mask)
+        loop_boxes = None if inter_boxes is None else inter_boxes[:, 0::2]
+        logits, boxes = self._box_heads(hs[:, 0::2], [r[0::2] for r in refs], range(hs.shape[0]), loop_boxes)
+        feats = self._mask_features([s[0::2] for s in srcs], memory[0::2])
+        ref_xy = torch.stack([r[0::2, :, :2] for r in refs])
+        ref_logits = self.detr.detr.class_embed[-1](hs[-1, 1::2])
+        embeds = self.detr.reid_embed_head(hs[-1])
+        return hs, logits, boxes, ref_xy, inter_refs[-1, 1::2], feats, ref_logits, embeds
+
+    def _graphed_train_trunk(self, stack):
+        """Forward + backward hipGraphs of `_train_trunk` for this batch shape (and autocast dtype), captured on first use
+        (`torch.cuda.make_graphed_callables`: eager warm-up iterations on a side stream, then capture).  Under torch.autocast
+        the capture runs with autocast's weight cache OFF: a cast cached before the capture would be a tensor outside the
+        graph's memory pool."""
+        from .seqformer import graphed_callable
+        return graphed_callable(self._train_trunks, lambda: _TrainTrunk(self).train(), stack)
+
     # ---- training -----------------------------------------------------------------------------
     def prepare_targets(self, batched_inputs):
         """-> (det_targets, ref_targets): key / reference frame of every pair (idol.py:283-311)."""
@@ -196,13 +253,13 @@ class IDOL(nn.Module):
         det_t, ref_t = self.prepare_targets(batched_inputs)
         frames = [f for video in batched_inputs for f in video["image"]]
         sizes = [tuple(f.shape[-2:]) for f in frames][0::2]
-        x, mask = self._preprocess(frames)
-        srcs, hs, memory, refs, inter_refs, inter_boxes = self._encode_decode(x, mask)
+        if self.graph_training and frames[0].is_cuda and all(f.shape == frames[0].shape for f in frames):
+            hs, logits, boxes, ref_xy, ref_last, feats, ref_logits, embeds = self._graphed_train_trunk(
+                torch.stack([f.to(self.device, torch.float32) for f in frames]))
+        else:
+            hs, logits, boxes, ref_xy, ref_last, feats, ref_logits, embeds = self._train_trunk(*self._preprocess(frames))
         Ld, bz = hs.shape[0], len(det_t)
-        loop_boxes = None if inter_boxes is None else inter_boxes[:, 0::2]
-        logits, boxes = self._box_heads(hs[:, 0::2], [r[0::2] for r in refs], range(Ld), loop_boxes)      # key frames
         indices_list, matched = self.criterion.matcher.match_all_layers(logits, boxes, det_t)
-        feats = self._mask_features([s[0::2] for s in srcs], memory[0::2])
         # the selected queries of every decoder layer on every key frame: one gather, one controller
         # call, one mask-head launch
         q_host = [[torch.nonzero(sel).flatten() for sel, _ in ind] for ind in indices_list]
@@ -210,7 +267,6 @@ class IDOL(nn.Module):
         img = torch.cat([torch.full_like(q, i) for layer in q_host for i, q in enumerate(layer)]).to(self.device, non_blocking=True)
         qry = torch.cat([q for layer in q_host for q in layer]).to(self.device, non_blocking=True)
         key_hs = hs[:, 0::2]                                                            # [Ld, bz, Q, C]
-        ref_xy = torch.stack([r[0::2, :, :2] for r in refs])                            # [Ld, bz, Q, 2] pre-sigmoid
         scale = torch.stack([scale_tensor([sizes[i][1], sizes[i][0]], self.device) for i in range(bz)])   # [bz, (w, h)]
         params = self.detr.controller(key_hs[lay, img, qry])
         points = ref_xy[lay, img, qry].sigmoid() * scale[img]
@@ -219,9 +275,7 @@ class IDOL(nn.Module):
             masks = masks + 0 * (feats.sum() + sum(p.sum() for p in self.detr.controller.parameters()))
         masks = masks[:, None]                                                          # [n, 1, H/4, W/4]
         # contrastive sets on the reference frames (last decoder layer), embeddings of both frames
-        ref_prob = self.detr.detr.class_embed[-1](hs[-1, 1::2]).sigmoid()
-        selections = select_pos_neg_masks(inter_refs[-1, 1::2], ref_prob, ref_t)
-        embeds = self.detr.reid_embed_head(hs[-1])
+        selections = select_pos_neg_masks(ref_last, ref_logits.sigmoid(), ref_t)
         qd = reid_terms(embeds[0::2], embeds[1::2], matched, selections, loss_reid)
         if self.deep_supervision:   # every decoder layer's losses in one pass over stacked tensors
             loss = self.criterion.forward_all_layers(logits, boxes, masks, det_t, indices_list, qd)

@@ -351,6 +351,24 @@ class _TrainTrunk(nn.Module):
                 o._mask_features(srcs, memory))
 
 
+def graphed_callable(cache, make_module, stack, keep=2):
+    """`make_module()(stack)` replayed from forward + backward hipGraphs captured per (input shape, autocast dtype); `cache`: the
+    owner's dict (at most `keep` entries).  Under torch.autocast the capture -- warm-up iterations included -- runs with
+    autocast's weight cache off: a weight cast cached BEFORE the capture is a tensor outside the graph's memory pool, and one
+    cached DURING it would be served, stale, to the eager code after it.  Replays run no Python of the module, so they need
+    nothing from the ambient autocast state."""
+    amp = torch.is_autocast_enabled() and stack.is_cuda
+    adt = torch.get_autocast_dtype("cuda") if amp else None
+    key = (tuple(stack.shape), adt)
+    fn = cache.get(key)
+    if fn is None:
+        if len(cache) >= keep:
+            cache.pop(next(iter(cache)))
+        with torch.autocast("cuda", dtype=adt, enabled=amp, cache_enabled=False):
+            fn = cache[key] = torch.cuda.make_graphed_callables(make_module(), (stack.clone(),), allow_unused_input=True)
+    return fn(stack)
+
+
 @META_ARCH_REGISTRY.register()
 class SeqFormer(nn.Module):
     def __init__(self, cfg):
@@ -500,14 +518,7 @@ class SeqFormer(nn.Module):
         """Forward + backward hipGraphs of the training trunk for this clip batch shape, captured
         on first use (3 eager warm-up iterations on a side stream, then capture -- what
         make_graphed_callables does)."""
-        key = tuple(stack.shape)
-        fn = self._train_trunks.get(key)
-        if fn is None:
-            if len(self._train_trunks) >= 2:
-                self._train_trunks.pop(next(iter(self._train_trunks)))
-            fn = self._train_trunks[key] = torch.cuda.make_graphed_callables(
-                _TrainTrunk(self).train(), (stack.clone(),), allow_unused_input=True)
-        return fn(stack)
+        return graphed_callable(self._train_trunks, lambda: _TrainTrunk(self).train(), stack)
 
     def losses(self, batched_inputs):
         """CondInst_segm.forward (segmentation_condInst.py:69-207) + SetCriterion."""
