@@ -30,6 +30,7 @@ Besides the contract keys the line carries:
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import math
 import os
@@ -190,13 +191,17 @@ def count_launches(step):
 
 
 def model_step_leg(rank, local_rank, world, device, steps, warmup=3, clips_per_rank=2, bf16=False, count=False,
-                   tuned_gemms=True):
+                   tuned_gemms=True, graph=False):
     """clips/s of the SeqFormer-R50 training step (BASELINE config: T=5 synthetic 360p clip, 300
     queries): forward + backward + RCCL gradient all-reduce + clipped AdamW step, two clips per
     rank -- the reference's per-GPU batch (IMS_PER_BATCH 16 on 8 GPUs, configs/base_ytvis.yaml:18) --
     weak scaling.  The loss is the reference's objective (clip-level Hungarian matching,
     focal / L1 / GIoU / mask focal + dice over the 6 decoder layers, vnext_amd/models/criterion.py)
-    on 4 synthetic tracks per clip, with the fused dynamic mask head forward and backward."""
+    on 4 synthetic tracks per clip, with the fused dynamic mask head forward and backward.
+    graph: the training trunk (backbone, transformer, heads; forward and backward) replayed from hipGraphs
+    (train.capture_training_graphs; the clips of a step have one size).  Off for the figure this leg reports: the fp32 step
+    is bound by its kernels and a replay of ~2 800 graph nodes is SLOWER than launching them (MI355X, same process: 59.2 ms
+    eager, 62.5 replayed; round 6) -- the bf16 legs, whose kernels are shorter, are reported both ways by main()."""
     import torch.distributed as dist
     import vnext_amd.models  # noqa: F401
     from vnext_amd import train as T
@@ -209,9 +214,11 @@ def model_step_leg(rank, local_rank, world, device, steps, warmup=3, clips_per_r
     cfg = get_seqformer_cfg(**{"MODEL.DEVICE": str(device)})
     model = build_model(cfg).train()
     timer = T.CommTimer() if world > 1 else None
+    clips = T.synthetic_clips(clips_per_rank, 5, 360, 640, device, seed=100 + rank, num_instances=4)
+    graph_state = (T.capture_training_graphs(model, clips, torch.bfloat16 if bf16 else None) if graph     # (before wrap_ddp)
+                   else {"enabled": False, "why": "eager trunk"})
     ddp = T.wrap_ddp(model, local_rank, comm_timer=timer)
     opt = T.build_optimizer(model)
-    clips = T.synthetic_clips(clips_per_rank, 5, 360, 640, device, seed=100 + rank, num_instances=4)
     def step():
         if bf16:
             with torch.autocast("cuda", dtype=torch.bfloat16):
@@ -246,10 +253,11 @@ def model_step_leg(rank, local_rank, world, device, steps, warmup=3, clips_per_r
             torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
+    T.release_training_graphs(model)
     del ddp, opt, model
     torch.cuda.empty_cache()
     return {"clips_per_s": world * clips_per_rank * steps / dt, "ms_per_step": dt * 1e3 / steps, "steps": steps,
-            "launches_per_step": launches, "library_gemms": gemms,
+            "launches_per_step": launches, "library_gemms": gemms, "graph_training": graph_state,
             "clips_per_rank": clips_per_rank, "n_gpus": world, "trainable_params": n_params,
             "grad_allreduce_MB_per_step": round(n_params * 4 / 1e6, 1),
             "ddp_bucket_cap_MB": T.ddp_bucket_mb() if world > 1 else None,
@@ -286,6 +294,7 @@ def extra_model_legs(device):
                                   "config": "SeqFormer R50, T=5, 360x640, 300 queries, trunk replayed from a hipGraph, "
                                             "top-10 masks at input resolution"}
     del model
+    gc.collect()      # (the replayed inference trunk's graph must be gone before the eager training legs: train.release_training_graphs)
     model = build_model(get_idol_cfg(**{"MODEL.DEVICE": str(device)})).train()
     opt = T.build_optimizer(model, base_lr=1e-4)
     pair = T.synthetic_clips(1, 2, 720, 1280, device, seed=8, num_instances=8)
@@ -296,9 +305,17 @@ def extra_model_legs(device):
     for _ in range(3):
         idol_step()
     ms = timed(idol_step, 5)
+    graph_state = T.capture_training_graphs(model, pair, torch.bfloat16)      # (after the eager figure: a captured graph's
+    for _ in range(3):                                                        #  memory pool slows the eager step that follows)
+        idol_step()
+    ms_graph = timed(idol_step, 5)
     out["idol_train_step"] = {"ms_per_step": ms, "pairs_per_s": 1e3 / ms,
+                              "graphed_trunk": {"ms_per_step": ms_graph, "pairs_per_s": 1e3 / ms_graph, "graph_training": graph_state,
+                                                "note": "the same step with the trunk replayed from hipGraphs (IDOL.graph_training): "
+                                                        "a key / reference pair is two frames, the eager step is bound by the host's launches"},
                               "config": "IDOL R50, one key/reference pair 720x1280, 8 objects, bf16 autocast (bf16 GEMMs and op "
                                         "value, fp32 locations / losses / reid kernels), simOTA + reid losses, AdamW"}
+    T.release_training_graphs(model)
     del opt, model
     out["seqformer_train_step_720p"] = seqformer_720p_leg(device, timed)
     model = build_model(get_idol_cfg(**{"MODEL.DEVICE": str(device)})).eval()
@@ -343,6 +360,13 @@ def seqformer_720p_leg(device, timed):
         ms = timed(step, 6)
         res[key] = {"ms_per_step": ms, "clips_per_s": 1e3 / ms, "launches_per_step": count_launches(step),
                     "peak_memory_GiB": torch.cuda.max_memory_allocated(device) / 2**30}
+        if amp:      # (fp32: bound by its kernels, the replay is the slower form -- model_step_leg)
+            graph_state = T.capture_training_graphs(model, clips, torch.bfloat16)
+            for _ in range(3):
+                step()
+            msg = timed(step, 6)
+            res[key]["graphed_trunk"] = {"ms_per_step": msg, "clips_per_s": 1e3 / msg, "graph_training": graph_state}
+            T.release_training_graphs(model)
         del model, opt, clips
     torch.cuda.empty_cache()
     return res
@@ -1006,6 +1030,11 @@ def main():
             model_leg["bf16_autocast"] = {**{k: amp[k] for k in ("clips_per_s", "ms_per_step")},
                                           "note": "same step under torch.autocast(bfloat16): bf16 GEMMs and op value, fp32 "
                                                   "locations / losses; the reference trains in fp32, so this is not the headline"}
+            ampg = model_step_leg(rank, local_rank, world, device, a.model_steps, bf16=True, graph=True)
+            model_leg["bf16_autocast"]["graphed_trunk"] = {
+                **{k: ampg[k] for k in ("clips_per_s", "ms_per_step", "graph_training")},
+                "note": "the bf16 step with its trunk (backbone, transformer, heads; forward and backward) replayed from hipGraphs: "
+                        "the bf16 kernels are short enough for the host's ~3 400 launches to bound the eager step"}
 
     if rank == 0:
         if model_leg is not None:

@@ -197,3 +197,55 @@ def test_decoder_glue_under_autocast_promotes_its_inputs():
     want.square().sum().backward()
     close(x.grad, x32.grad, 1e-5, "grad_x")
     close(lg.grad, lg32.grad, 1e-2, "grad_logits")
+
+
+# ---- ops/shadow_weights.py: a layer's GEMM weights cast once, together --------------------------------------------------------
+def _transformer_step(which, shadow, monkeypatch):
+    """One forward + backward of the golden-fixture transformer under torch.autocast(bfloat16) -> (outputs, gradients, casts)."""
+    import numpy as np
+    from torch.utils._python_dispatch import TorchDispatchMode
+    from vnext_amd.ops import shadow_weights
+    import test_transformer as tt      # (tests/ is on sys.path: conftest)
+    monkeypatch.setattr(shadow_weights, "ENABLED", shadow)
+    if which == "seqformer":
+        g = tt.load()
+        tr, L = tt.build(g, DEV, torch.float32)
+    else:
+        g = tt.load_idol()
+        tr, L = tt.build_idol(g, DEV, torch.float32)
+    tr.train()          # (the fixtures' transformers are built with dropout 0)
+    srcs = [torch.from_numpy(g[f"src{i}"]).to(DEV, torch.float32) for i in range(L)]
+    poss = [torch.from_numpy(g[f"pos{i}"]).to(DEV, torch.float32) for i in range(L)]
+    masks = [torch.from_numpy(g[f"mask{i}"]).to(DEV) for i in range(L)]
+    qe = torch.from_numpy(g["query_embed"]).to(DEV, torch.float32)
+    casts = [0]
+
+    class Census(TorchDispatchMode):
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            if func.__name__.startswith("_to_copy"):
+                casts[0] += 1
+            return func(*args, **(kwargs or {}))
+    with Census(), torch.autocast("cuda", dtype=torch.bfloat16):
+        out = tr(srcs, masks, poss, qe)
+        floats = [t for t in out if isinstance(t, torch.Tensor) and t.is_floating_point() and t.requires_grad]
+        sum((t.float() ** 2).mean() for t in floats).backward()
+    torch.cuda.synchronize()
+    grads = {n: p.grad.detach().clone() for n, p in tr.named_parameters() if p.grad is not None}
+    assert all(isinstance(p, torch.nn.Parameter) and p.dtype == torch.float32 for p in tr.parameters()), "the swap is undone"
+    return [t.detach().float() for t in floats], grads, casts[0]
+
+
+@pytest.mark.parametrize("which", ["seqformer", "idol"])
+def test_a_layers_gemm_weights_are_cast_once_and_the_step_is_unchanged(which, monkeypatch):
+    """Under autocast the transformer layers swap in bf16 copies of their Linear weights made by ONE multi-tensor launch per
+    layer (and one back for the gradients): the same roundings of the same numbers as autocast's per-GEMM casts -- outputs and
+    every parameter gradient equal the unshadowed step's (the kernels on both sides are deterministic) -- with far fewer casts."""
+    out0, g0, casts0 = _transformer_step(which, False, monkeypatch)
+    out1, g1, casts1 = _transformer_step(which, True, monkeypatch)
+    assert casts1 < casts0 - 40, (casts0, casts1)
+    for a, b in zip(out0, out1):
+        assert torch.equal(a, b)
+    assert set(g0) == set(g1)
+    for n in g0:
+        scale = float(g0[n].abs().max()) + 1e-20
+        assert float((g0[n] - g1[n]).abs().max()) <= 1e-6 * scale, n

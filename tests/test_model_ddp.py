@@ -367,30 +367,57 @@ def test_frozen_batchnorm_folded_into_the_convolution():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("graph", [False, True])
 @pytest.mark.parametrize("arch", ["SeqFormer", "IDOL"])
-def test_ddp_wrapper_over_rccl_on_one_gpu(arch):
+def test_ddp_wrapper_over_rccl_on_one_gpu(arch, graph):
     """The N > 1 code path with the real backend: a one-rank RCCL process group, the DDP wrapper
     bench.py / train.py use (static graph, gradients as bucket views), the criteria's own
-    all-reduce of the box count, frozen stages and never-used parameters -- three steps."""
+    all-reduce of the box count, frozen stages and never-used parameters -- three steps.
+    graph: with the training trunk replayed from hipGraphs (`train.capture_training_graphs`, called before the wrapper; the
+    trunk's gradients reach DDP's buckets when the replayed backward returns) -- and the gradients equal the eager DDP
+    step's."""
     import torch.distributed as dist
     from torch.nn.parallel import DistributedDataParallel
     from vnext_amd.registry import get_idol_cfg
-    port = 29600 + (os.getpid() % 300) + (0 if arch == "SeqFormer" else 1)
+    port = 29600 + (os.getpid() % 300) + (0 if arch == "SeqFormer" else 1) + (2 if graph else 0)
     dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
                             device_id=torch.device("cuda", 0))
     try:
+        torch.manual_seed(21)
         if arch == "SeqFormer":
             model = build_model(get_seqformer_cfg(**{"MODEL.DEVICE": "cuda:0", **TINY})).train()
         else:
             model = build_model(get_idol_cfg(**{"MODEL.DEVICE": "cuda:0", "MODEL.IDOL.ENC_LAYERS": 1,
                                                 "MODEL.IDOL.DEC_LAYERS": 2, "MODEL.IDOL.NUM_OBJECT_QUERIES": 110,
                                                 "MODEL.IDOL.DIM_FEEDFORWARD": 64, "MODEL.IDOL.DROPOUT": 0.0})).train()
+        clips = T.synthetic_clips(2, 2, 96, 160, "cuda:0", seed=12, num_instances=2)
+        if graph:      # BEFORE the wrapper (train.capture_training_graphs says why)
+            assert T.capture_training_graphs(model, clips)["enabled"]
         ddp = DistributedDataParallel(model, device_ids=[0], broadcast_buffers=False, find_unused_parameters=False,
                                       static_graph=True, gradient_as_bucket_view=True)
         opt = T.build_optimizer(model)
-        clips = T.synthetic_clips(2, 2, 96, 160, "cuda:0", seed=12, num_instances=2)
         losses = [float(T.train_step(ddp, opt, clips)) for _ in range(3)]
         assert all(np.isfinite(losses))
+        if graph:
+            assert len(model._train_trunks) == 1
+            # one more backward through DDP, replayed, against the same model's eager backward through DDP
+            import random
+            grads = []
+            for g in (True, False):
+                model.graph_training = g
+                for m in model.modules():
+                    if isinstance(m, torch.nn.Dropout):
+                        m.p = 0.0
+                    if isinstance(m, torch.nn.MultiheadAttention):
+                        m.dropout = 0.0
+                random.seed(3)
+                ddp.zero_grad(set_to_none=True)
+                sum(ddp(clips).values()).backward()
+                grads.append({n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+            assert set(grads[0]) == set(grads[1])
+            for n in grads[0]:
+                scale = float(grads[1][n].abs().max()) + 1e-12
+                assert float((grads[0][n] - grads[1][n]).abs().max()) <= 1e-2 * scale + 1e-7, n
     finally:
         dist.destroy_process_group()
 

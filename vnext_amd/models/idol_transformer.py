@@ -19,6 +19,7 @@ from torch import nn
 from torch.nn.init import constant_, normal_, xavier_uniform_
 
 from ..ops.fused_ffn import autocast_once, ffn_block
+from ..ops import shadow_weights
 from ..ops.fused_norm import add_dropout_norm
 from ..ops.self_attention import query_self_attention_block
 from ..ops.modules import MSDeformAttnIDOL
@@ -40,6 +41,7 @@ class DeformableTransformerEncoderLayer(nn.Module):
         self.linear2 = nn.Linear(d_ffn, d_model)
         self.dropout3 = nn.Dropout(dropout)
         self.norm2 = nn.LayerNorm(d_model)
+        shadow_weights.install(self)     # under autocast: this layer's GEMM weights cast once, together
 
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None):
         q = src if pos is None else src + pos
@@ -82,6 +84,7 @@ class DeformableTransformerDecoderLayer(nn.Module):
         self.linear2 = nn.Linear(d_ffn, d_model)
         self.dropout4 = nn.Dropout(dropout)
         self.norm3 = nn.LayerNorm(d_model)
+        shadow_weights.install(self)     # under autocast: this layer's GEMM weights cast once, together
 
     def forward(self, tgt, query_pos, reference_points, src, src_spatial_shapes, level_start_index,
                 src_padding_mask=None):

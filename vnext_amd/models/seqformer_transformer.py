@@ -22,6 +22,7 @@ from torch import nn
 from torch.nn.init import constant_, normal_, xavier_uniform_
 
 from ..ops.fused_ffn import autocast_once, ffn_block
+from ..ops import shadow_weights
 from ..ops.fused_norm import add_dropout_norm
 from ..ops.decoder_glue import time_weighted_sum
 from ..ops.modules import MSDeformAttnSeqFormer
@@ -58,6 +59,7 @@ class DeformableTransformerEncoderLayer(nn.Module):
         self.linear2 = nn.Linear(d_ffn, d_model)
         self.dropout3 = nn.Dropout(dropout)
         self.norm2 = nn.LayerNorm(d_model)
+        shadow_weights.install(self)     # under autocast: this layer's GEMM weights cast once, together
 
     @staticmethod
     def with_pos_embed(tensor, pos):
@@ -134,6 +136,7 @@ class DeformableTransformerDecoderLayer(nn.Module):
         self.dropout4_box = nn.Dropout(dropout)
         self.norm3_box = nn.LayerNorm(d_model)
         self.time_attention_weights = nn.Linear(d_model, 1)
+        shadow_weights.install(self)     # under autocast: this layer's GEMM weights cast once, together
 
     @staticmethod
     def with_pos_embed(tensor, pos):

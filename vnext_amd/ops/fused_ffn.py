@@ -64,12 +64,12 @@ def _gemm_dtype_ok(x, *weights) -> bool:
     """fp32 activations and weights: plain fp32 GEMMs, or -- under torch.autocast(bfloat16 / float16) -- 16-bit GEMMs whose
     outputs the in-place passes take as they are (ffn_act.hip / add_norm.hip read 16-bit rows and compute in fp32); the
     activation may already be in the autocast dtype (autocast_once)."""
-    if any(w.dtype != torch.float32 for w in weights):
-        return False
     if not torch.is_autocast_enabled():
-        return x.dtype == torch.float32
+        return x.dtype == torch.float32 and all(w.dtype == torch.float32 for w in weights)
     adt = torch.get_autocast_dtype("cuda")
-    return adt in (torch.bfloat16, torch.float16) and x.dtype in (torch.float32, adt)
+    # (a weight may already be in the autocast dtype: the layer's shadow copies, ops/shadow_weights.py)
+    return (adt in (torch.bfloat16, torch.float16) and x.dtype in (torch.float32, adt)
+            and all(w.dtype in (torch.float32, adt) for w in weights))
 
 
 class _BiasReluDropout(torch.autograd.Function):

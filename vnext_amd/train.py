@@ -232,6 +232,57 @@ def enable_channels_last() -> dict:
     return {"enabled": True, "why": "PYTORCH_MIOPEN_SUGGEST_NHWC=1 set before the first convolution; training trunk in channels-last"}
 
 
+def capture_training_graphs(model, clips, autocast_dtype=None) -> dict:
+    """Opt in to the graph-replayed training trunk (`SeqFormer.graph_training` / `IDOL.graph_training`: backbone, transformer
+    and heads -- forward AND backward -- as two hipGraphs per input shape) and capture it NOW, on `clips`: one forward +
+    backward whose gradients are dropped.  For fixed-size inputs only (every new frame size is a new capture and a new static
+    memory pool; Detectron2's multi-scale augmentation wants the eager trunk).
+
+    Call it BEFORE `wrap_ddp`: captured inside DistributedDataParallel.forward, `torch.cuda.make_graphed_callables` dies in
+    hipStreamEndCapture on this stack (round 6, one-rank RCCL group: segmentation fault; with the process group alone it
+    captures fine).  Captured first, the replayed backward hands the trunk's gradients to the parameters' accumulators like any
+    autograd node and DDP's bucket hooks fire there (tests/test_model_ddp.py) -- all of the trunk's buckets when the replayed
+    backward returns, i.e. the all-reduce no longer overlaps the trunk's backward.
+
+    What it buys is the host's time, and only where the host is the bound (MI355X, one GPU, the eager figure taken BEFORE the
+    capture: a captured graph's private memory pool slows the eager steps that follow it by ~5 ms, which is how a first A/B
+    of this misread the fp32 legs): IDOL 720p pair bf16 57.7 -> 49.6 ms, SeqFormer 720p clip bf16 68.9 -> 65.5, two 360p clips
+    bf16 ~54 -> ~51; the fp32 SeqFormer steps are bound by their kernels and a replay of ~2 800 graph nodes is SLOWER than
+    launching them (59.2 -> 62.5 ms, 720p 92.6 -> 95.5).  So: opt-in, for bf16 / small-batch steps.
+    -> {"enabled", "why"} for the bench line."""
+    if not hasattr(model, "graph_training"):
+        return {"enabled": False, "why": "%s has no graph_training switch" % type(model).__name__}
+    if not torch.cuda.is_available() or not next(model.parameters()).is_cuda:
+        return {"enabled": False, "why": "no GPU"}
+    if dist.is_available() and dist.is_initialized() and isinstance(model, DistributedDataParallel):
+        raise ValueError("capture_training_graphs: pass the bare model, before wrap_ddp")
+    model.graph_training = True
+    was_training = model.training
+    model.train()
+    with torch.autocast("cuda", dtype=autocast_dtype or torch.bfloat16, enabled=autocast_dtype is not None):
+        losses = sum(model(clips).values())
+    losses.backward()
+    model.zero_grad(set_to_none=True)
+    model.train(was_training)
+    torch.cuda.synchronize()
+    return {"enabled": True, "why": "training trunk captured (forward + backward hipGraphs) for %d input shape(s)"
+                                    % len(getattr(model, "_train_trunks", {}))}
+
+
+def release_training_graphs(model) -> None:
+    """Back to the eager trunk, the captured graphs destroyed NOW (they sit in a reference cycle with the model: `del` alone leaves
+    them to the collector).  While a captured training graph is alive, every EAGER step of the process is slower -- 58.6 -> 64.6
+    ms on the SeqFormer step, back to 59.1 once the graphs are gone (MI355X, round 6) -- so a process that measures or runs
+    both forms releases the graphs in between."""
+    import gc
+    if hasattr(model, "graph_training"):
+        model.graph_training = False
+    getattr(model, "_train_trunks", {}).clear()
+    gc.collect()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+
+
 def build_optimizer(model, base_lr=2e-4, backbone_multiplier=0.1, weight_decay=1e-4):
     """AdamW, backbone at base_lr * multiplier (train_net.py:85-113)."""
     backbone, rest = [], []
