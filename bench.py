@@ -964,6 +964,8 @@ def main():
     device = torch.device("cuda", local_rank)
     from vnext_amd.train import enable_channels_last
     channels_last = enable_channels_last()      # before the process's first convolution (the model legs train in channels-last)
+    from vnext_amd import tuning as _tuning
+    conv_search = _tuning.enable_conv_search()  # (likewise: MIOpen reads MIOPEN_USER_DB_PATH at its first convolution)
     affinity = None
     if world > 1:
         import torch.distributed as dist
@@ -1013,6 +1015,7 @@ def main():
                       (a.repeats, a.steps, chunk, a.steps // chunk))
     line["rank_cpu_affinity"] = affinity      # rank 0's share of the host cores (None at one GPU: nothing pinned)
     line["channels_last_trunk"] = channels_last
+    line["conv_search"] = conv_search           # MIOpen's algorithms by measurement, from the recorded find-db (tuning/miopen_userdb)
 
     # ---- model-level leg: SeqFormer-R50 T=5 360p training step under DDP (all ranks) ----------
     model_leg = None

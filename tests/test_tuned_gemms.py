@@ -126,3 +126,52 @@ def test_recorded_bf16_solutions_leave_the_autocast_losses_unchanged():
     assert plain.keys() == tuned.keys()
     for k in plain:
         assert tuned[k] == pytest.approx(plain[k], rel=1e-2, abs=1e-3), k
+
+
+# ---- MIOpen find-db recorded offline (tuning.enable_conv_search) -----------------------------------------------------------------
+def test_recorded_miopen_find_db_is_well_formed():
+    """tuning/miopen_userdb: MIOpen's user find-db (and perf-db) for gfx950, one line per convolution problem =
+    `<problem key>=<solver>:<ms>,<workspace>,<algorithm>;...` -- the trunk's stem convolution (3 -> 64 channels, 7 x 7, stride 2,
+    channels-last) of the 360p and 720p legs among them, in fp32 and bf16."""
+    import os
+    files = sorted(os.listdir(tuning.CONV_DB_DIR))
+    ufdb = [f for f in files if f.endswith(".ufdb.txt")]
+    assert len(ufdb) == 1 and ufdb[0].startswith("gfx950"), files
+    lines = [l for l in open(os.path.join(tuning.CONV_DB_DIR, ufdb[0])).read().splitlines() if l]
+    assert len(lines) > 100
+    for l in lines:
+        key, _, val = l.partition("=")
+        assert key.count("-") >= 10 and val, l[:80]
+        for entry in val.split(";"):
+            solver, _, rest = entry.partition(":")
+            assert solver and float(rest.split(",")[0]) > 0, entry
+    stem = [l for l in lines if l.startswith("3-") and "-7x7-64-" in l]
+    assert any("-384-640-" in l and "FP32" in l for l in stem) and any("-736-1280-" in l and "BF16" in l for l in stem), \
+        [l[:60] for l in stem]
+
+
+def test_enable_conv_search_is_a_noop_without_a_rocm_device():
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    st = tuning.enable_conv_search()
+    assert st["enabled"] is False and "no ROCm device" in st["why"]
+    assert torch.backends.cudnn.benchmark is False
+
+
+@pytest.mark.gpu
+def test_enable_conv_search_hands_miopen_a_private_copy_of_the_recorded_db(monkeypatch):
+    import os
+    monkeypatch.delenv("MIOPEN_USER_DB_PATH", raising=False)
+    monkeypatch.setitem(tuning._conv_state, "enabled", False)
+    before = torch.backends.cudnn.benchmark
+    try:
+        st = tuning.enable_conv_search()
+        assert st["enabled"] and "private copy" in st["db"], st
+        dst = os.environ["MIOPEN_USER_DB_PATH"]
+        assert dst != tuning.CONV_DB_DIR and sorted(os.listdir(dst)) == sorted(os.listdir(tuning.CONV_DB_DIR))
+        assert torch.backends.cudnn.benchmark is True
+        assert tuning.enable_conv_search() == st          # idempotent
+    finally:
+        torch.backends.cudnn.benchmark = before
+        tuning._conv_state.update(enabled=False, why="not requested")
+        os.environ.pop("MIOPEN_USER_DB_PATH", None)

@@ -21,6 +21,8 @@ ap.add_argument("--top", type=int, default=0)
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 torch.cuda.set_device(dev)
+from vnext_amd import train as _T  # noqa: E402
+print("channels-last:", _T.enable_channels_last(), "conv search:", _T.enable_conv_search(), file=sys.stderr)      # as bench.py's main()
 legs = a.legs.split(",")
 out = {}
 

@@ -210,6 +210,14 @@ def enable_tuned_gemms(path=None):
     return tuning.enable(path)
 
 
+def enable_conv_search(db_dir=None) -> dict:
+    """MIOpen's convolution algorithms by measurement instead of by heuristic, answered from the find-db recorded on MI355X
+    (vnext_amd/tuning: `enable_conv_search`; SeqFormer-R50 step 59.0 -> 55.4 ms fp32, 54.0 -> 46.0 ms bf16).  Like
+    `enable_channels_last`: once per process, BEFORE its first convolution."""
+    from . import tuning
+    return tuning.enable_conv_search(db_dir)
+
+
 def enable_channels_last() -> dict:
     """Opt in to the channels-last ResNet trunk for TRAINING steps (vnext_amd/models/seqformer.py: MIOpen's fp32 backward
     convolutions are NHWC kernels either way; given NCHW tensors it transposes around each: SeqFormer step 66.2 -> 64.3 ms).

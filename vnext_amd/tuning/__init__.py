@@ -75,3 +75,52 @@ def disable() -> None:
 
 def status() -> dict:
     return dict(_state)
+
+
+# ---- MIOpen: convolution algorithms found by measurement, recorded offline (round 6) -------------------------------------------
+CONV_DB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "miopen_userdb")
+_conv_state = {"enabled": False, "why": "not requested"}
+
+
+def enable_conv_search(db_dir: str | None = None) -> dict:
+    """MIOpen picks the trunk's convolution algorithms by MEASUREMENT instead of by its heuristic
+    (`torch.backends.cudnn.benchmark = True`), answering from the find-db recorded on MI355X for the models' problems
+    (tools/record_miopen_db.py -> tuning/miopen_userdb/): SeqFormer-R50 training step 59.0 -> 55.4 ms fp32, 54.0 -> 46.0 ms under
+    bf16 autocast (two T = 5 360p clips, one GPU, round 6).  A recorded problem costs nothing at run time; a problem that is
+    not in the file (another frame size or batch) is searched once per process -- tens of seconds for a new resolution, which
+    is why this is an explicit call and not an import side effect.
+
+    MIOpen reads MIOPEN_USER_DB_PATH when the process runs its first convolution: call this BEFORE it.  The library also
+    WRITES there, so it is handed a private copy of the recorded directory (per process: DDP ranks do not share a file).
+    An explicit MIOPEN_USER_DB_PATH in the environment is respected (only the search is switched on); VNX_CONV_SEARCH=0
+    opts out.  -> {"enabled", "why", "db"} for the bench line."""
+    import shutil
+    import torch
+    if _conv_state["enabled"]:
+        return dict(_conv_state)
+    if os.environ.get("VNX_CONV_SEARCH", "1") == "0":
+        _conv_state.update(why="VNX_CONV_SEARCH=0")
+        return dict(_conv_state)
+    if not torch.cuda.is_available() or getattr(torch.version, "hip", None) is None:
+        _conv_state.update(why="no ROCm device")
+        return dict(_conv_state)
+    db = "MIOPEN_USER_DB_PATH from the environment"
+    if "MIOPEN_USER_DB_PATH" not in os.environ:
+        src = db_dir or CONV_DB_DIR
+        dst = os.path.join(tempfile.gettempdir(), "vnx_miopen_userdb_%d" % os.getpid())
+        try:
+            if os.path.isdir(dst):
+                shutil.rmtree(dst)
+            if os.path.isdir(src) and any(f.endswith(".txt") for f in os.listdir(src)):
+                shutil.copytree(src, dst)
+                db = "a private copy of " + os.path.relpath(src, os.path.dirname(os.path.dirname(CONV_DB_DIR)))
+            else:
+                os.makedirs(dst, exist_ok=True)
+                db = "empty (no recorded find-db at %s): every problem is searched once" % src
+            os.environ["MIOPEN_USER_DB_PATH"] = dst
+        except OSError as e:       # never cost the run: MIOpen then keeps its own default location
+            db = "MIOpen's default location (%s: %s)" % (type(e).__name__, e)
+    torch.backends.cudnn.benchmark = True
+    _conv_state.update(enabled=True, why="torch.backends.cudnn.benchmark = True: MIOpen answers from its find-db, or times its solvers "
+                                         "the first time it sees a problem", db=db)
+    return dict(_conv_state)
