@@ -18,6 +18,8 @@ from vnext_amd import tuning  # noqa: E402
 
 STEPS = int(os.environ.get("VNX_PROF_STEPS", "6"))
 print("library gemms:", tuning.enable())                      # recorded rocBLAS / hipBLASLt solutions (VNX_TUNED_GEMMS=0: default)
+print("channels-last trunk:", T.enable_channels_last())       # as bench.py's main(): both before the first convolution
+print("conv search:", T.enable_conv_search())
 if os.environ.get("VNX_CUDNN_BENCHMARK", "0") == "1":
     torch.backends.cudnn.benchmark = True                     # MIOpen: find the convolution algorithms by measurement
 dev = "cuda:0"
