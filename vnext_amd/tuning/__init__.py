@@ -118,6 +118,8 @@ def enable_conv_search(db_dir: str | None = None) -> dict:
                 os.makedirs(dst, exist_ok=True)
                 db = "empty (no recorded find-db at %s): every problem is searched once" % src
             os.environ["MIOPEN_USER_DB_PATH"] = dst
+            import atexit
+            atexit.register(shutil.rmtree, dst, True)      # (the private copy goes with the process)
         except OSError as e:       # never cost the run: MIOpen then keeps its own default location
             db = "MIOpen's default location (%s: %s)" % (type(e).__name__, e)
     torch.backends.cudnn.benchmark = True
