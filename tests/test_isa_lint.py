@@ -108,10 +108,12 @@ def test_nothing_touches_the_slab_forwards_prefetched_samples_before_the_wait(tm
                            "--cuda-device-only", "-o", str(out), D32], stderr=subprocess.DEVNULL)
     text = open(out).read()
     # every unfused instantiation with fp32 locations prefetches its samples this way: fp32, bf16 and f16 values (round 6)
-    for tv in ("f", "NS_6bf16_tE", "NS_5f16_tE"):
-        m = re.search(r"^(_ZN3vnx20msda_fwd_slab_kernelI" + tv + r"fLb0EEE\w*):[^\n]*\n(.*?)^\.Lfunc_end", text, re.S | re.M)
-        assert m, "the unfused slab kernel (%s) is gone?" % tv
-        _check_slab_prefetch(m)
+    # -- and, for 16-bit values, in both slab sizes (8 waves x 320 rows of 128 B; 16 waves x 600: the 720p slab)
+    for tv, want in (("f", 1), ("NS_6bf16_tE", 2), ("NS_5f16_tE", 2)):
+        found = list(re.finditer(r"^(_ZN3vnx20msda_fwd_slab_kernelI" + tv + r"fLb0E(?:Li\d+E)*E\w*):[^\n]*\n(.*?)^\.Lfunc_end", text, re.S | re.M))
+        assert len(found) == want, "the unfused slab kernels (%s): %d instantiations, expected %d" % (tv, len(found), want)
+        for m in found:
+            _check_slab_prefetch(m)
 
 
 def _check_slab_prefetch(m):

@@ -116,6 +116,25 @@ def test_sixteen_bit_values_through_the_slab_kernel(vdt, shapes, B):
     assert float(np.abs(got - gather).max()) <= 2 * ulp * float(np.abs(gather).max())
 
 
+@pytest.mark.parametrize("vdt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shapes,B", [(S720, 1),                                             # levels 2 + 3 = 1 160 rows staged (the case it was built for)
+                                      ([(40, 60), (30, 30), (15, 15), (8, 8)], 2),           # 1 189 rows behind level 0: three levels staged
+                                      ([(40, 60), (30, 30), (16, 16), (4, 5)], 2),           # 1 176 + ...: 900 + 256 + 20 = 1 176: three again
+                                      ([(50, 50), (35, 35), (5, 5), (1, 1)], 2)])            # 1 251 behind level 0: only the last two (26 rows)
+def test_the_large_slab_of_sixteen_bit_values(vdt, shapes, B):
+    """Development variant 737: a 16-wave workgroup with a 77-KB slab (1 201 rows of 64 bytes) -- the two coarsest levels of a
+    720p pyramid.  Measured no faster than the small slab and therefore not the product path (msda_d32.hip: use_large_slab);
+    exact all the same: the oracle on the 16-bit-rounded values, and the gather kernel to one unit in the last place."""
+    sh, lsi, value, loc, attn = encoder_case(shapes, B, seed=17)
+    v16 = value.to(vdt)
+    want = oracle(v16.float(), sh, lsi, loc, attn)
+    got = fwd(v16, sh, lsi, loc, attn, 737)
+    close(got, want, 8e-3 if vdt == torch.bfloat16 else 1e-3)
+    gather = fwd(v16, sh, lsi, loc, attn, 731)
+    ulp = 2.0 ** -8 if vdt == torch.bfloat16 else 2.0 ** -11
+    assert float(np.abs(got - gather).max()) <= 2 * ulp * float(np.abs(gather).max())
+
+
 def test_fused_prologue_with_bf16_values_takes_the_slab_kernel_and_matches_the_gather_form():
     from vnext_amd.ops.functions import MSDeformAttnFusedFunction, level_tensors
     shapes = [tuple(x) for x in S360]

@@ -608,8 +608,16 @@ msda_fwd_d32_kernel(const TV* __restrict__ value, const int64_t* __restrict__ sh
 // LDS = slab + zero row + the waves' sample records: 76 KB, two workgroups per CU.  fp32 values, 4 levels x 4 points.
 constexpr int kSlabWaves = 8, kSlabQpw = 8, kSlabRowsCap = 320;
 constexpr int kSlabEnt = kSlabQpw * 17;                                             // records per wave: [8 queries][16 + 1]
-constexpr size_t kSlabRecBytes = size_t(kSlabWaves) * 2 * kSlabEnt * 16;            // offsets (uint4) + weights (float4)
-constexpr size_t kSlabLdsBytes = size_t(kSlabRowsCap + 1) * 128 + kSlabRecBytes + 64;
+constexpr size_t slab_rec_bytes(int waves) { return size_t(waves) * 2 * kSlabEnt * 16; }      // offsets (uint4) + weights (float4)
+constexpr size_t slab_lds_bytes(int waves, int cap128) { return size_t(cap128 + 1) * 128 + slab_rec_bytes(waves) + 64; }
+constexpr size_t kSlabRecBytes = slab_rec_bytes(kSlabWaves);
+constexpr size_t kSlabLdsBytes = slab_lds_bytes(kSlabWaves, kSlabRowsCap);
+// Round 6, the LARGE slab for 16-bit values at 720p: there the two coarsest levels are 1 160 rows of 64 bytes = 74 KB -- with
+// them staged half of the taps leave the L1's queue instead of a quarter (the small slab holds level 3 only; in fp32 the two
+// levels are 148 KB and do not fit beside anything).  One workgroup of SIXTEEN waves per CU (the same four waves per SIMD as
+// two workgroups of eight): slab 77 KB + records 70 KB = 147 KB.
+constexpr int kSlabWavesL = 16, kSlabRowsCapL = 600;      // 600 x 128 B = 1 200 rows of 64 B (+ the zero row)
+static_assert(slab_lds_bytes(kSlabWavesL, kSlabRowsCapL) <= 160 * 1024, "the large slab's workgroup fits a CU's LDS");
 
 // a staged row's four channels of this lane, as fp32 (fp32 rows: 16 bytes; 16-bit rows: 8)
 template <typename TV> __device__ __forceinline__ float4_t slab_tap(const unsigned char* p);
@@ -627,18 +635,19 @@ template <> __device__ __forceinline__ float4_t slab_tap<f16_t>(const unsigned c
 // (41 KB) holds 641 of them -- the same two coarsest levels at 360p (300 rows, 19 KB) and level 3 at 720p -- a staged tap is a
 // `ds_read_b64`, a gathered one the 8-byte load of the gather kernel's 8-lane map.  Until round 6 calls with 16-bit values (every
 // encoder layer of a model under bf16 autocast) kept the gather kernel.
-template <typename TV, typename TL, bool FUSED>
-__global__ void __launch_bounds__(64 * kSlabWaves, 2 * kSlabWaves / 4)      // two workgroups per CU: 4 waves per SIMD, <= 128 VGPRs
+template <typename TV, typename TL, bool FUSED, int WAVES = kSlabWaves, int CAP128 = kSlabRowsCap>
+__global__ void __launch_bounds__(64 * WAVES, 4)      // 4 waves per SIMD (two workgroups of 8 waves per CU, or one of 16), <= 128 VGPRs
 msda_fwd_slab_kernel(const TV* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
                      const TL* __restrict__ loc, const TL* __restrict__ attn, TV* __restrict__ out, MsdaDims d,
                      int parts, unsigned long long* stamps, FusedArgs fa) {
   stamp_begin(stamps);
   constexpr int D = 32, LP = 16, kRowBytes = D * int(sizeof(TV)), kPieces = kRowBytes / 16, kLaneBytes = kRowBytes / 8;
-  constexpr int kRowsCap = (kSlabRowsCap + 1) * 128 / kRowBytes - 1;      // rows the slab region holds (+ the zero row)
+  constexpr int kRowsCap = (CAP128 + 1) * 128 / kRowBytes - 1;      // rows the slab region holds (+ the zero row)
+  constexpr int kSlabWaves = WAVES;                                 // (shadows the namespace's: the workgroup's waves)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* slab = smem;                                                        // [rows + 1][row bytes]
-  uint4_t* rec_base = reinterpret_cast<uint4_t*>(smem + size_t(kSlabRowsCap + 1) * 128);
-  int* s_lvl = reinterpret_cast<int*>(smem + size_t(kSlabRowsCap + 1) * 128 + kSlabRecBytes);      // [4][4]: H, W, start, -
+  uint4_t* rec_base = reinterpret_cast<uint4_t*>(smem + size_t(CAP128 + 1) * 128);
+  int* s_lvl = reinterpret_cast<int*>(smem + size_t(CAP128 + 1) * 128 + slab_rec_bytes(WAVES));      // [4][4]: H, W, start, -
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #ifndef VNX_SLAB_BATCH_MAJOR
@@ -888,8 +897,8 @@ static bool use_slab_forward(int vdt, int ldt, const MsdaDims& d, int variant) {
 // calls shorter workgroups pack the launch's tail better (encoder-720p B = 5: one round = 25 tiles each 247 us, four rounds
 // 231-234; B = 2, 9.6 tiles each: 85 us with one round, 87 with two; encoder-360p at B = 10 -- two clips -- 13.3 tiles in one
 // round 88.5 us, 6.7 in two rounds 83.4, the gather kernel 110.9; VNX_SLAB_TILES_MAX 8 / 12 / 16 measured: 12).
-static int slab_parts(const MsdaDims& d, int n_tiles) {
-  const int per_round = 512 / (d.B * d.M) > 0 ? 512 / (d.B * d.M) : 1;
+static int slab_parts(const MsdaDims& d, int n_tiles, int resident = 512) {
+  const int per_round = resident / (d.B * d.M) > 0 ? resident / (d.B * d.M) : 1;
   int parts = per_round;
 #ifndef VNX_SLAB_TILES_MAX
 #define VNX_SLAB_TILES_MAX 12
@@ -898,32 +907,51 @@ static int slab_parts(const MsdaDims& d, int n_tiles) {
   return parts > n_tiles ? n_tiles : parts;
 }
 
-template <typename TV, typename TL>
-static int launch_fwd_slab(const void* value, const int64_t* shapes, const int64_t* lsi, const void* loc, const void* attn,
-                           void* out, const MsdaDims& d, const FusedArgs* fa, hipStream_t stream) {
-  const int n_tiles = (d.Lq + kSlabWaves * kSlabQpw - 1) / (kSlabWaves * kSlabQpw);
-  const int parts = slab_parts(d, n_tiles);
+template <typename TV, typename TL, int WAVES, int CAP128>
+static int launch_fwd_slab_cfg(const void* value, const int64_t* shapes, const int64_t* lsi, const void* loc, const void* attn,
+                               void* out, const MsdaDims& d, const FusedArgs* fa, hipStream_t stream) {
+  constexpr size_t lds = slab_lds_bytes(WAVES, CAP128);
+  const int n_tiles = (d.Lq + WAVES * kSlabQpw - 1) / (WAVES * kSlabQpw);
+  const int parts = slab_parts(d, n_tiles, lds * 2 <= 160 * 1024 ? 512 : 256);
   const int64_t blocks = int64_t(parts) * d.B * d.M;
   static thread_local int raised_on[2] = {-1, -1};
   int dev = 0;
   (void)hipGetDevice(&dev);
   const int which = fa != nullptr;
   if (raised_on[which] != dev) {
-    const void* fn = fa ? reinterpret_cast<const void*>(&msda_fwd_slab_kernel<TV, TL, true>)
-                        : reinterpret_cast<const void*>(&msda_fwd_slab_kernel<TV, TL, false>);
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(kSlabLdsBytes)) != hipSuccess)
+    const void* fn = fa ? reinterpret_cast<const void*>(&msda_fwd_slab_kernel<TV, TL, true, WAVES, CAP128>)
+                        : reinterpret_cast<const void*>(&msda_fwd_slab_kernel<TV, TL, false, WAVES, CAP128>);
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)) != hipSuccess)
       return check_launch("msda_fwd_slab (LDS limit)");
     raised_on[which] = dev;
   }
   if (fa)
-    hipLaunchKernelGGL((msda_fwd_slab_kernel<TV, TL, true>), dim3(uint32_t(blocks)), dim3(64 * kSlabWaves), kSlabLdsBytes, stream,
+    hipLaunchKernelGGL((msda_fwd_slab_kernel<TV, TL, true, WAVES, CAP128>), dim3(uint32_t(blocks)), dim3(64 * WAVES), lds, stream,
                        (const TV*)value, shapes, lsi, (const TL*)loc, (const TL*)attn, (TV*)out, d, parts,
                        take_stamp_region(kStampFwd, blocks), *fa);
   else
-    hipLaunchKernelGGL((msda_fwd_slab_kernel<TV, TL, false>), dim3(uint32_t(blocks)), dim3(64 * kSlabWaves), kSlabLdsBytes, stream,
+    hipLaunchKernelGGL((msda_fwd_slab_kernel<TV, TL, false, WAVES, CAP128>), dim3(uint32_t(blocks)), dim3(64 * WAVES), lds, stream,
                        (const TV*)value, shapes, lsi, (const TL*)loc, (const TL*)attn, (TV*)out, d, parts,
                        take_stamp_region(kStampFwd, blocks), FusedArgs{});
   return check_launch("msda_fwd_slab");
+}
+
+// 16-bit values, the large slab: built, exact, measured (round 6, kbench cold, encoder-720p bf16, small / large slab: B = 5
+// 167.4 / 168.0 us unfused -- warm 135 / 147 --, 200.8 / 207.2 fused; B = 2 65.1 / 61.9; forced at 360p 39.7 / 41.5; the gather
+// kernel 177.6 / 68.8) -- and NOT the product path: with half of the taps staged instead of a quarter the call is no faster.
+// With 64-byte rows the gathered half was not bound by the L1's delivery to begin with (the same finding as at 360p,
+// DESIGN.md section 3.1g), and a CU's one 16-wave workgroup copies 77 KB per 6-13 tiles where two 8-wave ones copy 15 KB each.
+// Development build: variant 737 takes it (tests/test_msda_slab.py holds it to the oracle), anything else the small slab.
+static bool use_large_slab(const MsdaDims&, int variant) { return variant == 737; }
+
+template <typename TV, typename TL>
+static int launch_fwd_slab(const void* value, const int64_t* shapes, const int64_t* lsi, const void* loc, const void* attn,
+                           void* out, const MsdaDims& d, const FusedArgs* fa, hipStream_t stream) {
+  if constexpr (sizeof(TV) == 2) {
+    if (use_large_slab(d, kernel_variant()))
+      return launch_fwd_slab_cfg<TV, TL, kSlabWavesL, kSlabRowsCapL>(value, shapes, lsi, loc, attn, out, d, fa, stream);
+  }
+  return launch_fwd_slab_cfg<TV, TL, kSlabWaves, kSlabRowsCap>(value, shapes, lsi, loc, attn, out, d, fa, stream);
 }
 
 struct FwdCfg { int qpw; int wpb; };
