@@ -260,3 +260,65 @@ def test_backward_accepts_a_4_byte_aligned_grad_feats_pointer(shift):
     _close(gfeats.double().cpu().numpy().reshape(of.shape), of, 2e-5)
     _close(gparams.double().cpu().numpy(), op, 2e-5)
     assert bool((buf[:shift] == guard).all()) and bool((buf[shift + feats.numel():] == guard).all())
+
+
+@pytest.mark.gpu
+def test_training_pair_zero_fills_in_the_forward_and_a_second_backward_still_works():
+    """ABI 15: `vnx_dynamic_mask_head_forward_train` zero-fills the backward's three gradient buffers in the forward's own launch
+    and `vnx_dynamic_mask_head_backward_zeroed` accumulates into them without a zero-fill of its own.  Through the C ABI on
+    buffers filled with garbage, at a misaligned grad_feats pointer: the same output as the plain forward, the oracle's
+    gradients, nothing written outside the views.  Through autograd: the buffers serve ONE backward -- a second backward over the
+    retained graph takes the self-zeroing entry point and gives the same gradients (the mask head's sums over instances of a frame
+    are atomic: equal to the oracle's tolerance, not bit for bit)."""
+    from vnext_amd import _lib
+    from vnext_amd.heads import dynamic_mask_head
+    gen = torch.Generator().manual_seed(77)
+    counts, H_, W_ = [4, 0, 3], 13, 37
+    n_all = sum(counts)
+    feats = torch.randn(len(counts), 8, H_, W_, generator=gen).cuda()
+    ref = (torch.rand(n_all, 2, generator=gen) * torch.tensor([W_ * 8.0, H_ * 8.0])).cuda()
+    params = (0.3 * torch.randn(n_all, 169, generator=gen)).cuda()
+    gout = torch.randn(n_all, 2 * H_, 2 * W_, generator=gen).cuda()
+    image = torch.repeat_interleave(torch.arange(len(counts), dtype=torch.int32), torch.tensor(counts)).cuda()
+    stream = torch.cuda.current_stream().cuda_stream
+    guard = 7.0
+    buf = torch.full((feats.numel() + 8,), guard, device="cuda:0")
+    gfeats = buf[1:1 + feats.numel()]
+    gref, gparams = torch.full_like(ref, guard), torch.full_like(params, guard)
+    out_plain, out_train = torch.empty(n_all, 2 * H_, 2 * W_, device="cuda:0"), torch.empty(n_all, 2 * H_, 2 * W_, device="cuda:0")
+    dims = (len(counts), 8, H_, W_, n_all, 169, 8, stream)
+    _lib.check(_lib.lib().vnx_dynamic_mask_head_forward(_lib.VNX_F32, feats.data_ptr(), ref.data_ptr(), params.data_ptr(),
+                                                        image.data_ptr(), out_plain.data_ptr(), *dims))
+    _lib.check(_lib.lib().vnx_dynamic_mask_head_forward_train(_lib.VNX_F32, feats.data_ptr(), ref.data_ptr(), params.data_ptr(),
+                                                              image.data_ptr(), out_train.data_ptr(), gfeats.data_ptr(),
+                                                              gref.data_ptr(), gparams.data_ptr(), *dims))
+    torch.cuda.synchronize()
+    assert torch.equal(out_plain, out_train)
+    assert not gfeats.any() and not gref.any() and not gparams.any()
+    assert float(buf[0]) == guard and bool((buf[1 + feats.numel():] == guard).all())
+    _lib.check(_lib.lib().vnx_dynamic_mask_head_backward_zeroed(
+        _lib.VNX_F32, feats.data_ptr(), ref.data_ptr(), params.data_ptr(), image.data_ptr(), gout.data_ptr(),
+        gfeats.data_ptr(), gref.data_ptr(), gparams.data_ptr(), *dims))
+    torch.cuda.synchronize()
+    of, orf, op = H.dynamic_mask_head_backward(feats.double().cpu().numpy(), ref.double().cpu().numpy(),
+                                               params.double().cpu().numpy(), counts, gout.double().cpu().numpy())
+    _close(gfeats.double().cpu().numpy().reshape(of.shape), of, 2e-5)
+    _close(gref.double().cpu().numpy(), orf, 2e-5)
+    _close(gparams.double().cpu().numpy(), op, 2e-5)
+    assert float(buf[0]) == guard and bool((buf[1 + feats.numel():] == guard).all())
+    # no instances at all: the training forward still leaves zeros (its own zero-fill launch)
+    g0 = torch.full((2, 8, 3, 5), guard, device="cuda:0")
+    _lib.check(_lib.lib().vnx_dynamic_mask_head_forward_train(_lib.VNX_F32, g0.data_ptr(), None, None, None, None, g0.data_ptr(), None,
+                                                              None, 2, 8, 3, 5, 0, 169, 8, stream))
+    torch.cuda.synchronize()
+    assert not g0.any()
+    # autograd: first backward = the forward-zeroed buffers, second (retained graph) = fresh buffers, self-zeroing entry point
+    f, p, w = feats.clone().requires_grad_(True), ref.clone().requires_grad_(True), params.clone().requires_grad_(True)
+    out = dynamic_mask_head(f, p, w, image, 8)
+    first = torch.autograd.grad(out, (f, p, w), gout, retain_graph=True)
+    second = torch.autograd.grad(out, (f, p, w), gout)
+    for a, b, want in zip(first, second, (of, orf, op)):
+        _close(a.double().cpu().numpy().reshape(want.shape), want, 2e-5)
+        _close(b.double().cpu().numpy().reshape(want.shape), want, 2e-5)
+    with torch.no_grad():      # no backward will follow: the plain forward, no buffers
+        assert torch.equal(dynamic_mask_head(feats, ref, params, image, 8), out_plain)

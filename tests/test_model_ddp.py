@@ -430,9 +430,9 @@ def test_ddp_wrapper_over_rccl_on_one_gpu(arch, graph):
                 sum(ddp(clips).values()).backward()
                 grads.append({n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
             assert set(grads[0]) == set(grads[1])
-            for n in grads[0]:      # (MIOpen's weight-gradient kernels sum in run-dependent order: a few per cent on single elements)
-                scale = float(grads[1][n].abs().max()) + 1e-12
-                assert float((grads[0][n] - grads[1][n]).abs().max()) <= 5e-2 * scale + 1e-7, n
+            for n in grads[0]:      # (MIOpen's weight-gradient kernels sum in run-dependent order: several per cent on single
+                #                         elements of the trunk's filters -- a tensor's gradient as a whole is the stable quantity)
+                assert float((grads[0][n] - grads[1][n]).norm()) <= 2e-2 * float(grads[1][n].norm()) + 1e-7, n
     finally:
         dist.destroy_process_group()
 

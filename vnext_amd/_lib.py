@@ -16,7 +16,7 @@ DEV_LIB_PATH = os.path.join(_HERE, "lib", "libvnext_hip_dev.so")
 
 VNX_F32, VNX_F64, VNX_BF16, VNX_F16 = 0, 1, 2, 3
 VNX_OK = 0
-ABI_VERSION = 14
+ABI_VERSION = 15
 MSDA_LEVELS_PACKED = 1
 MSDA_REF_F32 = 0x100       # or-ed into ref_dim of vnx_msda_fused_*: fp32 reference points beside 16-bit offsets / logits
 MSDA_FORK = 2              # vnx_msda_backward: grad_value kernel on the library's side stream (include/vnext_hip.h)
@@ -36,6 +36,8 @@ SIGNATURES = {
     "vnx_msda_fused_backward": (_i, [_i, _i] + [_vp] * 11 + [_i] * 9 + [_vp, _sz, _vp]),
     "vnx_dynamic_mask_head_forward": (_i, [_i] + [_vp] * 5 + [_i] * 7 + [_vp]),
     "vnx_dynamic_mask_head_backward": (_i, [_i] + [_vp] * 8 + [_i] * 7 + [_vp]),
+    "vnx_dynamic_mask_head_forward_train": (_i, [_i] + [_vp] * 8 + [_i] * 7 + [_vp]),
+    "vnx_dynamic_mask_head_backward_zeroed": (_i, [_i] + [_vp] * 8 + [_i] * 7 + [_vp]),
     "vnx_reid_similarity": (_i, [_i] + [_vp] * 3 + [_i] * 7 + [_vp]),
     "vnx_reid_bisoftmax": (_i, [_i] + [_vp] * 2 + [_i] * 4 + [_vp]),
     "vnx_mask_intersections_workspace_bytes": (_sz, [_i, _i]),

@@ -329,12 +329,35 @@ dynamic_mask_head_kernel(const float* __restrict__ feats, const float* __restric
 //     reads the next plane or, in the last one, zero -- nothing is clamped, nothing past the tensor is touched;
 //   * stores: the descriptor covers exactly the run's own output rows, offsets are relative to them -- the halo's lanes
 //     come out negative, the lanes past the run's end beyond the range, and the hardware drops both.
-template <int kDummy>
+// The three gradient buffers of the backward zero-filled by a slice of threads each (grid-stride; scalar stores up to the first
+// 16-byte boundary of `a` -- a caller's pointer, a view with a storage offset is only 4-byte aligned -- 16-byte
+// stores for its body, scalar stores for its tail and for the two small buffers).
+__device__ __forceinline__ void zero3_slice(float* __restrict__ a, size_t na, float* __restrict__ b, size_t nb,
+                                            float* __restrict__ c, size_t nc, size_t t0, size_t stride) {
+  size_t head = (size_t(16) - (reinterpret_cast<uintptr_t>(a) & 15u)) & 15u;
+  head = head / 4 < na ? head / 4 : na;                    // floats before the boundary (the pointer is 4-byte aligned)
+  const size_t na4 = (na - head) / 4;
+  float4_t* a4 = reinterpret_cast<float4_t*>(a + head);
+  for (size_t i = t0; i < head; i += stride) a[i] = 0.f;
+  for (size_t i = t0; i < na4; i += stride) a4[i] = float4_t{0.f, 0.f, 0.f, 0.f};
+  for (size_t i = head + na4 * 4 + t0; i < na; i += stride) a[i] = 0.f;
+  for (size_t i = t0; i < nb; i += stride) b[i] = 0.f;
+  for (size_t i = t0; i < nc; i += stride) c[i] = 0.f;
+}
+
+// ZERO = 1 (the training forward, vnx_dynamic_mask_head_forward_train): before anything else every thread of the grid
+// zero-fills its slice of the backward's three gradient buffers (za / zb / zc) -- the zero-fill the backward otherwise
+// launches for itself (4.8 us of the 35-us training forward + backward; round 6).  ZERO = 0: the same kernel without it.
+template <int ZERO>
 __global__ void __launch_bounds__(256)
 dynamic_mask_head_runs_kernel(const float* __restrict__ feats, const float* __restrict__ ref,
                               const float* __restrict__ params, const int* __restrict__ inst_image,
-                              float* __restrict__ out, int H, int W, int n_inst, int stride, int runs, int halo) {
+                              float* __restrict__ out, int H, int W, int n_inst, int stride, int runs, int halo,
+                              float* __restrict__ za, size_t zna, float* __restrict__ zb, size_t znb,
+                              float* __restrict__ zc, size_t znc) {
   extern __shared__ float mh_lds[];
+  if constexpr (ZERO != 0)
+    zero3_slice(za, zna, zb, znb, zc, znc, size_t(blockIdx.x) * blockDim.x + threadIdx.x, size_t(gridDim.x) * blockDim.x);
   const int lane = threadIdx.x & 63;
   const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t wave_id = blockIdx.x * 4u + uint32_t(wave_in_block);     // the launcher keeps this below 2^31
@@ -1002,18 +1025,7 @@ mask_head_bwd_part(const int block, const float* __restrict__ feats, const float
 // 16-byte multiples)
 __global__ void __launch_bounds__(256)
 zero3_kernel(float* __restrict__ a, size_t na, float* __restrict__ b, size_t nb, float* __restrict__ c, size_t nc) {
-  const size_t stride = size_t(gridDim.x) * blockDim.x, t0 = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  // grad_feats is a caller's pointer: a view with a storage offset is only 4-byte aligned.  A scalar head up to
-  // the first 16-byte boundary, 16-byte stores for the body, a scalar tail.
-  size_t head = (size_t(16) - (reinterpret_cast<uintptr_t>(a) & 15u)) & 15u;
-  head = head / 4 < na ? head / 4 : na;                    // floats before the boundary (the pointer is 4-byte aligned)
-  const size_t na4 = (na - head) / 4;
-  float4_t* a4 = reinterpret_cast<float4_t*>(a + head);
-  for (size_t i = t0; i < head; i += stride) a[i] = 0.f;
-  for (size_t i = t0; i < na4; i += stride) a4[i] = float4_t{0.f, 0.f, 0.f, 0.f};
-  for (size_t i = head + na4 * 4 + t0; i < na; i += stride) a[i] = 0.f;
-  for (size_t i = t0; i < nb; i += stride) b[i] = 0.f;
-  for (size_t i = t0; i < nc; i += stride) c[i] = 0.f;
+  zero3_slice(a, na, b, nb, c, nc, size_t(blockIdx.x) * blockDim.x + threadIdx.x, size_t(gridDim.x) * blockDim.x);
 }
 
 // one launch, the two parts of a strip in neighbouring workgroups (they read the same features and upstream gradients)
@@ -1047,11 +1059,14 @@ dynamic_mask_head_bwd_kernel(const float* __restrict__ feats, const float* __res
 
 using namespace vnx;
 
-extern "C" int vnx_dynamic_mask_head_forward(int dtype, const void* mask_feats,
-                                             const void* reference_points, const void* params,
-                                             const int32_t* inst_image, void* out, int num_images,
-                                             int channels, int height, int width, int num_insts,
-                                             int num_params, int stride, void* hip_stream) {
+// forward; zero != nullptr: the training forward -- grad_feats / grad_ref / grad_params zero-filled by the same launch
+struct MaskHeadZero { void* grad_feats; void* grad_ref; void* grad_params; };
+
+static int mask_head_forward_impl(int dtype, const void* mask_feats,
+                                  const void* reference_points, const void* params,
+                                  const int32_t* inst_image, void* out, int num_images,
+                                  int channels, int height, int width, int num_insts,
+                                  int num_params, int stride, const MaskHeadZero* zero, void* hip_stream) {
   if (dtype != VNX_F32) {
     set_error("vnx_dynamic_mask_head_forward: only f32 is built (got dtype %d)", dtype);
     return VNX_ERR_UNSUPPORTED;
@@ -1066,12 +1081,30 @@ extern "C" int vnx_dynamic_mask_head_forward(int dtype, const void* mask_feats,
     set_error("vnx_dynamic_mask_head_forward: bad sizes");
     return VNX_ERR_INVALID_ARGUMENT;
   }
+  const size_t zn0 = size_t(num_images) * kMhChannels * size_t(height) * size_t(width), zn1 = size_t(num_insts) * 2,
+               zn2 = size_t(num_insts) * kMhParams;
+  if (zero && ((zn0 && !zero->grad_feats) || (num_insts && (!zero->grad_ref || !zero->grad_params)))) {
+    set_error("vnx_dynamic_mask_head_forward_train: null gradient buffer");
+    return VNX_ERR_INVALID_ARGUMENT;
+  }
+  const int variant = kernel_variant();
+  if (zero && (num_insts == 0 || height == 0 || width == 0 || variant == 799)) {
+    // no forward launch to fold the zero-fill into (or the development build's strip kernel): its own launch
+    if (zn0 + zn1 + zn2) {
+      size_t blocks = ((zn0 + zn1 + zn2) / 4 + 255) / 256;
+      blocks = blocks > 2048 ? 2048 : (blocks < 1 ? 1 : blocks);
+      hipLaunchKernelGGL(zero3_kernel, dim3(uint32_t(blocks)), dim3(256), 0, (hipStream_t)hip_stream, (float*)zero->grad_feats, zn0,
+                         (float*)zero->grad_ref, zn1, (float*)zero->grad_params, zn2);
+      const int zs = check_launch("mask_head_fwd zero");
+      if (zs != VNX_OK) return zs;
+    }
+    zero = nullptr;
+  }
   if (num_insts == 0 || height == 0 || width == 0) return VNX_OK;
   if (!mask_feats || !reference_points || !params || !inst_image || !out) {
     set_error("vnx_dynamic_mask_head_forward: null pointer argument");
     return VNX_ERR_INVALID_ARGUMENT;
   }
-  const int variant = kernel_variant();
   if (variant != 799) {                      // (development build: 799 = the strip kernel, 700 + r = r runs per instance)
     const int runs = mask_head_runs(num_insts, height, width, variant > 700 && variant < 799 ? variant - 700 : 0);
     const int halo = (width + 1 + 63) / 64 * 64;      // logits kept from the chunk before: the row above + the pixel to the left
@@ -1081,10 +1114,18 @@ extern "C" int vnx_dynamic_mask_head_forward(int dtype, const void* mask_feats,
       set_error("vnx_dynamic_mask_head_forward: %lld waves / frame %d x %d exceed the kernel's limits", (long long)waves, height, width);
       return VNX_ERR_UNSUPPORTED;
     }
-    hipLaunchKernelGGL(dynamic_mask_head_runs_kernel<0>, dim3(uint32_t((waves + 3) / 4)), dim3(256), lds_bytes,
-                       (hipStream_t)hip_stream, (const float*)mask_feats, (const float*)reference_points,
-                       (const float*)params, num_images == 1 ? (const int*)nullptr : (const int*)inst_image, (float*)out,
-                       height, width, num_insts, stride, runs, halo);
+    if (zero)
+      hipLaunchKernelGGL(dynamic_mask_head_runs_kernel<1>, dim3(uint32_t((waves + 3) / 4)), dim3(256), lds_bytes,
+                         (hipStream_t)hip_stream, (const float*)mask_feats, (const float*)reference_points,
+                         (const float*)params, num_images == 1 ? (const int*)nullptr : (const int*)inst_image, (float*)out,
+                         height, width, num_insts, stride, runs, halo, (float*)zero->grad_feats, zn0, (float*)zero->grad_ref, zn1,
+                         (float*)zero->grad_params, zn2);
+    else
+      hipLaunchKernelGGL(dynamic_mask_head_runs_kernel<0>, dim3(uint32_t((waves + 3) / 4)), dim3(256), lds_bytes,
+                         (hipStream_t)hip_stream, (const float*)mask_feats, (const float*)reference_points,
+                         (const float*)params, num_images == 1 ? (const int*)nullptr : (const int*)inst_image, (float*)out,
+                         height, width, num_insts, stride, runs, halo, (float*)nullptr, size_t(0), (float*)nullptr, size_t(0),
+                         (float*)nullptr, size_t(0));
     return check_launch("dynamic_mask_head");
   }
 #ifdef VNX_DEV_VARIANTS
@@ -1115,12 +1156,31 @@ extern "C" int vnx_dynamic_mask_head_forward(int dtype, const void* mask_feats,
 #endif
 }
 
-extern "C" int vnx_dynamic_mask_head_backward(int dtype, const void* mask_feats, const void* reference_points,
-                                              const void* params, const int32_t* inst_image,
-                                              const void* grad_out, void* grad_feats, void* grad_ref,
-                                              void* grad_params, int num_images, int channels, int height,
-                                              int width, int num_insts, int num_params, int stride,
-                                              void* hip_stream) {
+extern "C" int vnx_dynamic_mask_head_forward(int dtype, const void* mask_feats,
+                                             const void* reference_points, const void* params,
+                                             const int32_t* inst_image, void* out, int num_images,
+                                             int channels, int height, int width, int num_insts,
+                                             int num_params, int stride, void* hip_stream) {
+  return mask_head_forward_impl(dtype, mask_feats, reference_points, params, inst_image, out, num_images, channels, height, width,
+                                num_insts, num_params, stride, nullptr, hip_stream);
+}
+
+extern "C" int vnx_dynamic_mask_head_forward_train(int dtype, const void* mask_feats,
+                                                   const void* reference_points, const void* params,
+                                                   const int32_t* inst_image, void* out, void* grad_feats, void* grad_ref,
+                                                   void* grad_params, int num_images, int channels, int height, int width,
+                                                   int num_insts, int num_params, int stride, void* hip_stream) {
+  const MaskHeadZero zero{grad_feats, grad_ref, grad_params};
+  return mask_head_forward_impl(dtype, mask_feats, reference_points, params, inst_image, out, num_images, channels, height, width,
+                                num_insts, num_params, stride, &zero, hip_stream);
+}
+
+static int mask_head_backward_impl(int dtype, const void* mask_feats, const void* reference_points,
+                                   const void* params, const int32_t* inst_image,
+                                   const void* grad_out, void* grad_feats, void* grad_ref,
+                                   void* grad_params, int num_images, int channels, int height,
+                                   int width, int num_insts, int num_params, int stride, bool zero_first,
+                                   void* hip_stream) {
   if (dtype != VNX_F32) {
     set_error("vnx_dynamic_mask_head_backward: only f32 is built (got dtype %d)", dtype);
     return VNX_ERR_UNSUPPORTED;
@@ -1145,7 +1205,7 @@ extern "C" int vnx_dynamic_mask_head_backward(int dtype, const void* mask_feats,
   {
     const size_t n0 = feat_bytes / 4, n1 = size_t(num_insts) * 2, n2 = size_t(num_insts) * kMhParams;
     const size_t n = n0 + n1 + n2;
-    if (n) {
+    if (n && zero_first) {
       size_t blocks = (n / 4 + 255) / 256;
       if (blocks > 2048) blocks = 2048;
       if (blocks < 1) blocks = 1;
@@ -1173,4 +1233,24 @@ extern "C" int vnx_dynamic_mask_head_backward(int dtype, const void* mask_feats,
                      (const int*)inst_image, (const float*)grad_out, (float*)grad_feats, (float*)grad_ref,
                      (float*)grad_params, height, width, num_insts, stride, strips_x, strips_y);
   return check_launch("dynamic_mask_head_bwd");
+}
+
+extern "C" int vnx_dynamic_mask_head_backward(int dtype, const void* mask_feats, const void* reference_points,
+                                              const void* params, const int32_t* inst_image,
+                                              const void* grad_out, void* grad_feats, void* grad_ref,
+                                              void* grad_params, int num_images, int channels, int height,
+                                              int width, int num_insts, int num_params, int stride,
+                                              void* hip_stream) {
+  return mask_head_backward_impl(dtype, mask_feats, reference_points, params, inst_image, grad_out, grad_feats, grad_ref, grad_params,
+                                 num_images, channels, height, width, num_insts, num_params, stride, true, hip_stream);
+}
+
+extern "C" int vnx_dynamic_mask_head_backward_zeroed(int dtype, const void* mask_feats, const void* reference_points,
+                                                     const void* params, const int32_t* inst_image,
+                                                     const void* grad_out, void* grad_feats, void* grad_ref,
+                                                     void* grad_params, int num_images, int channels, int height,
+                                                     int width, int num_insts, int num_params, int stride,
+                                                     void* hip_stream) {
+  return mask_head_backward_impl(dtype, mask_feats, reference_points, params, inst_image, grad_out, grad_feats, grad_ref, grad_params,
+                                 num_images, channels, height, width, num_insts, num_params, stride, false, hip_stream);
 }

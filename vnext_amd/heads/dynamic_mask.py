@@ -51,11 +51,23 @@ class _DynamicMaskHead(torch.autograd.Function):
         N, C, H, W = feats.shape
         n_all = ref.shape[0]
         out = torch.empty((n_all, 2 * H, 2 * W), dtype=torch.float32, device=feats.device)
+        # A forward whose backward will follow (any differentiable input): the three gradient buffers are allocated NOW and
+        # zero-filled by the forward's own launch (vnx_dynamic_mask_head_forward_train, ABI 15) -- the backward then
+        # accumulates into them without a zero-fill launch of its own: one launch fewer per training step.
+        ctx.grad_bufs = None
         with torch.cuda.device(feats.device):
-            st = _lib.lib().vnx_dynamic_mask_head_forward(
-                _lib.VNX_F32, feats.data_ptr(), ref.data_ptr(), params.data_ptr(), inst_image.data_ptr(),
-                out.data_ptr(), N, C, H, W, n_all, params.shape[1], int(stride),
-                torch.cuda.current_stream(feats.device).cuda_stream)
+            if any(ctx.needs_input_grad[:3]):
+                bufs = (torch.empty_like(feats), torch.empty_like(ref), torch.empty_like(params))
+                st = _lib.lib().vnx_dynamic_mask_head_forward_train(
+                    _lib.VNX_F32, feats.data_ptr(), ref.data_ptr(), params.data_ptr(), inst_image.data_ptr(),
+                    out.data_ptr(), bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr(),
+                    N, C, H, W, n_all, params.shape[1], int(stride), torch.cuda.current_stream(feats.device).cuda_stream)
+                ctx.grad_bufs = bufs
+            else:
+                st = _lib.lib().vnx_dynamic_mask_head_forward(
+                    _lib.VNX_F32, feats.data_ptr(), ref.data_ptr(), params.data_ptr(), inst_image.data_ptr(),
+                    out.data_ptr(), N, C, H, W, n_all, params.shape[1], int(stride),
+                    torch.cuda.current_stream(feats.device).cuda_stream)
         _lib.check(st)
         ctx.save_for_backward(feats, ref, params, inst_image)
         ctx.stride = int(stride)
@@ -68,11 +80,17 @@ class _DynamicMaskHead(torch.autograd.Function):
         N, C, H, W = feats.shape
         n_all = ref.shape[0]
         grad_out = grad_out.to(torch.float32).contiguous()
-        gfeats = torch.empty_like(feats)
-        gref = torch.empty_like(ref)
-        gparams = torch.empty_like(params)
+        # the buffers the forward zero-filled -- handed to autograd as the gradients, so they serve ONE backward; a second
+        # backward over a retained graph allocates fresh ones and takes the entry point that zero-fills for itself
+        bufs, ctx.grad_bufs = ctx.grad_bufs, None
+        if bufs is not None:
+            gfeats, gref, gparams = bufs
+            entry = _lib.lib().vnx_dynamic_mask_head_backward_zeroed
+        else:
+            gfeats, gref, gparams = torch.empty_like(feats), torch.empty_like(ref), torch.empty_like(params)
+            entry = _lib.lib().vnx_dynamic_mask_head_backward
         with torch.cuda.device(feats.device):
-            st = _lib.lib().vnx_dynamic_mask_head_backward(
+            st = entry(
                 _lib.VNX_F32, feats.data_ptr(), ref.data_ptr(), params.data_ptr(), inst_image.data_ptr(),
                 grad_out.data_ptr(), gfeats.data_ptr(), gref.data_ptr(), gparams.data_ptr(),
                 N, C, H, W, n_all, params.shape[1], ctx.stride,
