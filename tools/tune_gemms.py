@@ -5,7 +5,8 @@ inference, IDOL video inference at 360p and 720p -- once with tuning enabled and
 
     python tools/tune_gemms.py gpurun_out/tunableop_mi355x.csv      # on an MI355X; then copy to vnext_amd/tuning/
 
-bf16 (autocast) GEMMs are NOT tuned: a hipBLASLt candidate faulted during that pass on this stack (round 4).
+bf16 (autocast) GEMMs are not tuned HERE: online, inside the autocast step, a library candidate faulted on this stack (round 4);
+tools/tune_gemms_bf16.py records their shapes and tunes them offline, one shape at a time (round 6).
 The GEMMs are plain library GEMMs; nothing here touches the kernels of this library.
 """
 import os

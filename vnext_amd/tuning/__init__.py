@@ -9,8 +9,12 @@ the tuned solution takes 197 -- and the training step of SeqFormer-R50 (two clip
 library default, nothing is ever timed at run time.  TunableOp itself refuses the file when the PyTorch / ROCm / hipBLASLt
 / rocBLAS versions or the GPU architecture differ from the ones it was recorded with (the `Validator` rows).
 
-Only fp32 entries are recorded: the bf16 tuning pass took a GPU memory-access fault inside a library candidate on this
-stack, with and without the hipBLASLt candidates (two attempts, round 4).
+fp32 entries since round 4; bf16 entries (the autocast legs: BASELINE config 3) since round 6.  Tuned ONLINE, inside the autocast
+step, the bf16 pass took a GPU memory-access fault inside a library candidate on this stack (two attempts, round 4);
+tools/tune_gemms_bf16.py records the step's GEMM signatures with tuning off and tunes each offline, on random operands, in a worker
+process -- a fault would cost one shape; there was none (155 shapes, 73 s).  `bf16_step_shapes.csv` is that recorded list.
+
+`enable_conv_search()` (below) does the same for MIOpen's convolution algorithms: a find-db recorded offline, no search at run time.
 """
 from __future__ import annotations
 
