@@ -285,16 +285,9 @@ def extra_model_legs(device):
         return (time.perf_counter() - t0) * 1e3 / n
     out = {}
     torch.manual_seed(0)
-    model = build_model(get_seqformer_cfg(**{"MODEL.DEVICE": str(device)})).eval()
-    clip = T.synthetic_clips(1, 5, 360, 640, device, seed=7, num_instances=0)
-    for _ in range(2):
-        model(clip)
-    ms = timed(lambda: model(clip), 10)
-    out["seqformer_inference"] = {"ms_per_clip": ms, "clips_per_s": 1e3 / ms, "frames_per_s": 5e3 / ms,
-                                  "config": "SeqFormer R50, T=5, 360x640, 300 queries, trunk replayed from a hipGraph, "
-                                            "top-10 masks at input resolution"}
-    del model
-    gc.collect()      # (the replayed inference trunk's graph must be gone before the eager training legs: train.release_training_graphs)
+    # Order: every EAGER training figure first, then the graph-replayed forms, then the inference legs (whose trunks are replayed
+    # too) -- a captured graph slows the eager steps of its process while it lives, and some of that outlasts it (round 6:
+    # SeqFormer step 56.1 ms before a capture, 57.1 after capture + release).
     model = build_model(get_idol_cfg(**{"MODEL.DEVICE": str(device)})).train()
     opt = T.build_optimizer(model, base_lr=1e-4)
     pair = T.synthetic_clips(1, 2, 720, 1280, device, seed=8, num_instances=8)
@@ -305,19 +298,33 @@ def extra_model_legs(device):
     for _ in range(3):
         idol_step()
     ms = timed(idol_step, 5)
-    graph_state = T.capture_training_graphs(model, pair, torch.bfloat16)      # (after the eager figure: a captured graph's
-    for _ in range(3):                                                        #  memory pool slows the eager step that follows)
-        idol_step()
-    ms_graph = timed(idol_step, 5)
     out["idol_train_step"] = {"ms_per_step": ms, "pairs_per_s": 1e3 / ms,
-                              "graphed_trunk": {"ms_per_step": ms_graph, "pairs_per_s": 1e3 / ms_graph, "graph_training": graph_state,
-                                                "note": "the same step with the trunk replayed from hipGraphs (IDOL.graph_training): "
-                                                        "a key / reference pair is two frames, the eager step is bound by the host's launches"},
                               "config": "IDOL R50, one key/reference pair 720x1280, 8 objects, bf16 autocast (bf16 GEMMs and op "
                                         "value, fp32 locations / losses / reid kernels), simOTA + reid losses, AdamW"}
+    out["seqformer_train_step_720p"], graph_720p = seqformer_720p_leg(device, timed)
+    # -- the graph-replayed forms
+    graph_state = T.capture_training_graphs(model, pair, torch.bfloat16)
+    for _ in range(3):
+        idol_step()
+    ms_graph = timed(idol_step, 5)
+    out["idol_train_step"]["graphed_trunk"] = {
+        "ms_per_step": ms_graph, "pairs_per_s": 1e3 / ms_graph, "graph_training": graph_state,
+        "note": "the same step with the trunk replayed from hipGraphs (IDOL.graph_training): a key / reference pair is two frames, "
+                "the eager step is bound by the host's launches"}
     T.release_training_graphs(model)
     del opt, model
-    out["seqformer_train_step_720p"] = seqformer_720p_leg(device, timed)
+    out["seqformer_train_step_720p"]["bf16_autocast"]["graphed_trunk"] = graph_720p()
+    # -- inference (trunks replayed from hipGraphs)
+    model = build_model(get_seqformer_cfg(**{"MODEL.DEVICE": str(device)})).eval()
+    clip = T.synthetic_clips(1, 5, 360, 640, device, seed=7, num_instances=0)
+    for _ in range(2):
+        model(clip)
+    ms = timed(lambda: model(clip), 10)
+    out["seqformer_inference"] = {"ms_per_clip": ms, "clips_per_s": 1e3 / ms, "frames_per_s": 5e3 / ms,
+                                  "config": "SeqFormer R50, T=5, 360x640, 300 queries, trunk replayed from a hipGraph, "
+                                            "top-10 masks at input resolution"}
+    del model
+    gc.collect()
     model = build_model(get_idol_cfg(**{"MODEL.DEVICE": str(device)})).eval()
     g = torch.Generator(device=device).manual_seed(1)
     for name, (h, w) in (("360p", (360, 640)), ("720p", (720, 1280))):
@@ -350,7 +357,7 @@ def seqformer_720p_leg(device, timed):
         opt = T.build_optimizer(model)
         clips = T.synthetic_clips(1, 5, 720, 1280, device, seed=104, num_instances=4)
 
-        def step():
+        def step(model=model, opt=opt, clips=clips, amp=amp):      # (bound now: the bf16 step outlives this loop, see below)
             if amp:
                 with torch.autocast("cuda", dtype=torch.bfloat16):
                     return T.train_step(model, opt, clips)
@@ -360,16 +367,18 @@ def seqformer_720p_leg(device, timed):
         ms = timed(step, 6)
         res[key] = {"ms_per_step": ms, "clips_per_s": 1e3 / ms, "launches_per_step": count_launches(step),
                     "peak_memory_GiB": torch.cuda.max_memory_allocated(device) / 2**30}
-        if amp:      # (fp32: bound by its kernels, the replay is the slower form -- model_step_leg)
-            graph_state = T.capture_training_graphs(model, clips, torch.bfloat16)
-            for _ in range(3):
-                step()
-            msg = timed(step, 6)
-            res[key]["graphed_trunk"] = {"ms_per_step": msg, "clips_per_s": 1e3 / msg, "graph_training": graph_state}
-            T.release_training_graphs(model)
+        if amp:      # the bf16 model stays for the graph-replayed figure, taken by the caller AFTER its other eager legs
+            #          (fp32: bound by its kernels, the replay is the slower form -- model_step_leg)
+            def graphed(model=model, clips=clips, step=step):
+                graph_state = T.capture_training_graphs(model, clips, torch.bfloat16)
+                for _ in range(3):
+                    step()
+                msg = timed(step, 6)
+                T.release_training_graphs(model)
+                return {"ms_per_step": msg, "clips_per_s": 1e3 / msg, "graph_training": graph_state}
         del model, opt, clips
     torch.cuda.empty_cache()
-    return res
+    return res, graphed
 
 
 def latest_profile(suffix):
@@ -1033,11 +1042,6 @@ def main():
             model_leg["bf16_autocast"] = {**{k: amp[k] for k in ("clips_per_s", "ms_per_step")},
                                           "note": "same step under torch.autocast(bfloat16): bf16 GEMMs and op value, fp32 "
                                                   "locations / losses; the reference trains in fp32, so this is not the headline"}
-            ampg = model_step_leg(rank, local_rank, world, device, a.model_steps, bf16=True, graph=True)
-            model_leg["bf16_autocast"]["graphed_trunk"] = {
-                **{k: ampg[k] for k in ("clips_per_s", "ms_per_step", "graph_training")},
-                "note": "the bf16 step with its trunk (backbone, transformer, heads; forward and backward) replayed from hipGraphs: "
-                        "the bf16 kernels are short enough for the host's ~3 400 launches to bound the eager step"}
 
     if rank == 0:
         if model_leg is not None:
@@ -1051,6 +1055,12 @@ def main():
             line["exposed_allreduce_ms"] = comm.get("exposed_allreduce_ms") if isinstance(comm, dict) else None
             if world == 1:
                 line["other_configs"] = extra_model_legs(device)
+                # (last: every eager training figure of this process is taken before its first captured training graph)
+                ampg = model_step_leg(rank, local_rank, world, device, a.model_steps, bf16=True, graph=True)
+                model_leg["bf16_autocast"]["graphed_trunk"] = {
+                    **{k: ampg[k] for k in ("clips_per_s", "ms_per_step", "graph_training")},
+                    "note": "the bf16 step with its trunk (backbone, transformer, heads; forward and backward) replayed from hipGraphs: "
+                            "the bf16 kernels are short enough for the host's ~3 400 launches to bound the eager step"}
         # ---- per-kernel rooflines, measured live --------------------------------------------
         # `us_per_launch` (what `achieved` and `frac` are computed from): HIP events on the launch stream
         # around a hipGraph of back-to-back launches over the rotating (cold) input sets -- the figure the
