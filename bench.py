@@ -266,6 +266,67 @@ def model_step_leg(rank, local_rank, world, device, steps, warmup=3, clips_per_r
                       "SetCriterion on 4 synthetic tracks per clip (matcher + focal/L1/GIoU/mask losses, deep supervision); DDP static_graph + gradient_as_bucket_view over RCCL"}
 
 
+GRAPH_LEGS = {      # name -> (architecture, clips, frames per clip, height, width, instances, seed)
+    "seqformer_360p_bf16": ("seqformer", 2, 5, 360, 640, 4, 100),
+    "seqformer_720p_bf16": ("seqformer", 1, 5, 720, 1280, 4, 104),
+    "idol_720p_bf16": ("idol", 1, 2, 720, 1280, 8, 8),
+}
+
+
+def graph_leg_child(name, steps):
+    """`python bench.py --graph-leg <name>`: ONE bf16 training leg with its trunk replayed from hipGraphs
+    (train.capture_training_graphs), in a process of its own -> one JSON object on stdout.  The parent bench runs these as child
+    processes: a captured graph slows the eager steps of ITS process, and a fault inside a capture --
+    there has been one kind, under DistributedDataParallel -- must not cost the bench its line."""
+    import vnext_amd.models  # noqa: F401
+    from vnext_amd import train as T
+    from vnext_amd import tuning
+    from vnext_amd.registry import build_model, get_idol_cfg, get_seqformer_cfg
+    arch, n_clips, frames, h, w, inst, seed = GRAPH_LEGS[name]
+    device = torch.device("cuda", 0)
+    torch.cuda.set_device(device)
+    state = {"channels_last_trunk": T.enable_channels_last(), "conv_search": tuning.enable_conv_search(), "library_gemms": tuning.enable()}
+    torch.manual_seed(0)
+    if arch == "idol":
+        model = build_model(get_idol_cfg(**{"MODEL.DEVICE": str(device)})).train()
+        opt = T.build_optimizer(model, base_lr=1e-4)
+    else:
+        model = build_model(get_seqformer_cfg(**{"MODEL.DEVICE": str(device)})).train()
+        opt = T.build_optimizer(model)
+    clips = T.synthetic_clips(n_clips, frames, h, w, device, seed=seed, num_instances=inst)
+    graph_state = T.capture_training_graphs(model, clips, torch.bfloat16)
+
+    def step():
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            return T.train_step(model, opt, clips)
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3 / steps
+    print(json.dumps({"ms_per_step": ms, "clips_per_s": n_clips * 1e3 / ms, "steps": steps, "graph_training": graph_state, **state}))
+
+
+def graph_leg(name, steps=10, timeout_s=420):
+    """The graph-replayed bf16 leg `name`, measured by a child process (graph_leg_child) -> its dict, or {"error": ...}."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--graph-leg", name, "--model-steps", str(steps)]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MIOPEN_USER_DB_PATH")}
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env)
+        lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"error": "child exited with %s: %s" % (r.returncode, (r.stderr or "").strip()[-300:])}
+        out = json.loads(lines[-1])
+        out["how"] = "measured in a child process (python bench.py --graph-leg %s): captured graphs stay out of this process" % name
+        return out
+    except (subprocess.TimeoutExpired, OSError, ValueError) as e:
+        return {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+
+
 def extra_model_legs(device):
     """Single-GPU legs for the other SURVEY section 8d configs (rank 0, N=1 only; a few seconds each):
     C2 SeqFormer-R50 whole-clip inference, C3-like IDOL-R50 key/reference training step, C5 IDOL-R50
@@ -285,9 +346,10 @@ def extra_model_legs(device):
         return (time.perf_counter() - t0) * 1e3 / n
     out = {}
     torch.manual_seed(0)
-    # Order: every EAGER training figure first, then the graph-replayed forms, then the inference legs (whose trunks are replayed
-    # too) -- a captured graph slows the eager steps of its process while it lives, and some of that outlasts it (round 6:
-    # SeqFormer step 56.1 ms before a capture, 57.1 after capture + release).
+    # Order: the eager training figures first, then the inference legs (whose trunks are replayed from hipGraphs); the
+    # graph-replayed TRAINING forms run in child processes (graph_leg) -- a captured training graph slows the eager steps of its
+    # process while it lives, and some of that outlasts it (round 6: SeqFormer step 56.1 ms before a capture, 57.1 after capture +
+    # release).
     model = build_model(get_idol_cfg(**{"MODEL.DEVICE": str(device)})).train()
     opt = T.build_optimizer(model, base_lr=1e-4)
     pair = T.synthetic_clips(1, 2, 720, 1280, device, seed=8, num_instances=8)
@@ -301,19 +363,15 @@ def extra_model_legs(device):
     out["idol_train_step"] = {"ms_per_step": ms, "pairs_per_s": 1e3 / ms,
                               "config": "IDOL R50, one key/reference pair 720x1280, 8 objects, bf16 autocast (bf16 GEMMs and op "
                                         "value, fp32 locations / losses / reid kernels), simOTA + reid losses, AdamW"}
-    out["seqformer_train_step_720p"], graph_720p = seqformer_720p_leg(device, timed)
-    # -- the graph-replayed forms
-    graph_state = T.capture_training_graphs(model, pair, torch.bfloat16)
-    for _ in range(3):
-        idol_step()
-    ms_graph = timed(idol_step, 5)
+    del opt, model
+    out["seqformer_train_step_720p"] = seqformer_720p_leg(device, timed)
+    # -- the graph-replayed forms of the two bf16 legs above, each in a child process
+    torch.cuda.empty_cache()
     out["idol_train_step"]["graphed_trunk"] = {
-        "ms_per_step": ms_graph, "pairs_per_s": 1e3 / ms_graph, "graph_training": graph_state,
+        **graph_leg("idol_720p_bf16", 5),
         "note": "the same step with the trunk replayed from hipGraphs (IDOL.graph_training): a key / reference pair is two frames, "
                 "the eager step is bound by the host's launches"}
-    T.release_training_graphs(model)
-    del opt, model
-    out["seqformer_train_step_720p"]["bf16_autocast"]["graphed_trunk"] = graph_720p()
+    out["seqformer_train_step_720p"]["bf16_autocast"]["graphed_trunk"] = graph_leg("seqformer_720p_bf16", 6)
     # -- inference (trunks replayed from hipGraphs)
     model = build_model(get_seqformer_cfg(**{"MODEL.DEVICE": str(device)})).eval()
     clip = T.synthetic_clips(1, 5, 360, 640, device, seed=7, num_instances=0)
@@ -367,18 +425,9 @@ def seqformer_720p_leg(device, timed):
         ms = timed(step, 6)
         res[key] = {"ms_per_step": ms, "clips_per_s": 1e3 / ms, "launches_per_step": count_launches(step),
                     "peak_memory_GiB": torch.cuda.max_memory_allocated(device) / 2**30}
-        if amp:      # the bf16 model stays for the graph-replayed figure, taken by the caller AFTER its other eager legs
-            #          (fp32: bound by its kernels, the replay is the slower form -- model_step_leg)
-            def graphed(model=model, clips=clips, step=step):
-                graph_state = T.capture_training_graphs(model, clips, torch.bfloat16)
-                for _ in range(3):
-                    step()
-                msg = timed(step, 6)
-                T.release_training_graphs(model)
-                return {"ms_per_step": msg, "clips_per_s": 1e3 / msg, "graph_training": graph_state}
         del model, opt, clips
     torch.cuda.empty_cache()
-    return res, graphed
+    return res
 
 
 def latest_profile(suffix):
@@ -954,8 +1003,12 @@ def main():
                     help="skip the stamped (kernel-span) replays: under rocprofv3 every traced launch is then a plain one")
     ap.add_argument("--no-warm", action="store_true",
                     help="skip the cache-warm forward leg (profiling runs: keeps rocprofv3's per-kernel average cold-only)")
+    ap.add_argument("--graph-leg", default=None, choices=list(GRAPH_LEGS),
+                    help="child mode: one bf16 training leg with its trunk replayed from hipGraphs -> a JSON object (graph_leg_child)")
     a = ap.parse_args()
 
+    if a.graph_leg:
+        return graph_leg_child(a.graph_leg, a.model_steps)
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(a.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -1055,10 +1108,9 @@ def main():
             line["exposed_allreduce_ms"] = comm.get("exposed_allreduce_ms") if isinstance(comm, dict) else None
             if world == 1:
                 line["other_configs"] = extra_model_legs(device)
-                # (last: every eager training figure of this process is taken before its first captured training graph)
-                ampg = model_step_leg(rank, local_rank, world, device, a.model_steps, bf16=True, graph=True)
+                # (the graph-replayed form of the bf16 step: a child process, graph_leg)
                 model_leg["bf16_autocast"]["graphed_trunk"] = {
-                    **{k: ampg[k] for k in ("clips_per_s", "ms_per_step", "graph_training")},
+                    **graph_leg("seqformer_360p_bf16", a.model_steps),
                     "note": "the bf16 step with its trunk (backbone, transformer, heads; forward and backward) replayed from hipGraphs: "
                             "the bf16 kernels are short enough for the host's ~3 400 launches to bound the eager step"}
         # ---- per-kernel rooflines, measured live --------------------------------------------

@@ -60,3 +60,16 @@ def test_the_drivers_own_eight_rank_command():
     line = json.loads(lines[0])
     assert line["n_gpus"] == line["rccl_world_size"] == 8 and line["steps"] == 4 and line["warmup"] == 1
     assert line["scaling"] == "weak" and line["config"]["parallelism"].startswith("dp8")
+
+
+def test_a_graph_leg_that_cannot_run_costs_the_bench_nothing_but_that_entry():
+    """bench.graph_leg runs the graph-replayed bf16 training legs in child processes (`python bench.py --graph-leg <name>`): a
+    child that dies -- here: no GPU in this container -- comes back as {"error": ...}, never as an exception in the parent."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible: the child would run the leg")
+    sys.path.insert(0, ROOT)
+    import bench
+    out = bench.graph_leg("idol_720p_bf16", steps=1, timeout_s=300)
+    assert set(out) == {"error"} and "child exited" in out["error"], out
+    assert set(bench.GRAPH_LEGS) == {"seqformer_360p_bf16", "seqformer_720p_bf16", "idol_720p_bf16"}

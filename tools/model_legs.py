@@ -41,8 +41,8 @@ if "360" in legs:
         r = bench.model_step_leg(0, 0, 1, dev, 10, bf16=amp, count=True)
         out["seqformer_train_step_360p_" + key] = {k: r[k] for k in ("ms_per_step", "clips_per_s", "launches_per_step")}
 if "720" in legs:
-    r, graphed_720p = bench.seqformer_720p_leg(dev, timed)
-    r["bf16_autocast"]["graphed_trunk"] = graphed_720p()      # (the eager figures of this leg are taken before it)
+    r = bench.seqformer_720p_leg(dev, timed)
+    r["bf16_autocast"]["graphed_trunk"] = bench.graph_leg("seqformer_720p_bf16", 6)      # (a child process)
     out["seqformer_train_step_720p"] = {k: v for k, v in r.items() if k != "config"}
 if "idol" in legs or a.top:
     import vnext_amd.models  # noqa: F401
